@@ -1,0 +1,731 @@
+// C-ABI of gtav_amd (see include/gtav_amd.h): handles own repacked weights + workspace in HBM and
+// enqueue the kernel sequence of each reference entry point on the caller's stream.
+#include "../../include/gtav_amd.h"
+#include "ops.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace gtav {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+}  // namespace gtav
+
+using namespace gtav;
+
+#define RET_IF(expr)            \
+    do {                        \
+        int _rc = (expr);       \
+        if (_rc) return _rc;    \
+    } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+struct Arena {  // owns every device allocation of a handle
+    std::vector<void*> ptrs;
+    size_t total = 0;
+    int alloc(void** out, size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        GTAV_CHECK_HIP(hipMalloc(out, bytes));
+        GTAV_CHECK_HIP(hipMemset(*out, 0, bytes));
+        ptrs.push_back(*out);
+        total += bytes;
+        return 0;
+    }
+    template <typename T>
+    int alloc_t(T** out, size_t count) { return alloc((void**)out, count * sizeof(T)); }
+    ~Arena() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+enum SlotKind { SLOT_F16_PAD, SLOT_F32 };
+struct Slot {
+    SlotKind kind;
+    int R, C;        // logical (torch) shape flattened to 2-D
+    void* dst;       // f16 [Rp][Cp] or f32 base
+    int Rp, Cp;      // padded shape (f16) ; for f32: Cp = destination leading dim
+    int c0;          // f32: column offset in destination
+    bool set = false;
+    bool required = true;
+};
+
+struct WeightTable {
+    std::map<std::string, Slot> slots;
+    void add_f16(const std::string& n, int R, int C, f16* dst, int Rp, int Cp) {
+        slots[n] = Slot{SLOT_F16_PAD, R, C, dst, Rp, Cp, 0, false, true};
+    }
+    void add_f32(const std::string& n, int R, int C, float* dst, int ldd, int c0 = 0, bool required = true) {
+        slots[n] = Slot{SLOT_F32, R, C, dst, R, ldd, c0, false, required};
+    }
+    int set(const char* name, const float* src, int64_t numel, hipStream_t s) {
+        auto it = slots.find(name);
+        GTAV_REQUIRE(it != slots.end(), "set_weight: unexpected key '%s'", name);
+        Slot& sl = it->second;
+        GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "set_weight: '%s' has %lld elements, expected %d x %d", name,
+                     (long long)numel, sl.R, sl.C);
+        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_convert_pad_f16(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, s));
+        else RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, (float*)sl.dst, sl.Cp, sl.c0, s));
+        sl.set = true;
+        return 0;
+    }
+    int get(const char* name, float* dst, int64_t numel, hipStream_t s) {
+        auto it = slots.find(name);
+        GTAV_REQUIRE(it != slots.end(), "get_weight: unknown key '%s'", name);
+        Slot& sl = it->second;
+        GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "get_weight: '%s' size mismatch", name);
+        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_unpad_f16_to_f32((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, s));
+        else RET_IF(launch_copy_f32_strided((const float*)sl.dst + sl.c0, sl.Cp, sl.R, sl.C, dst, sl.C, s));
+        return 0;
+    }
+    int check_complete() {
+        for (auto& kv : slots)
+            GTAV_REQUIRE(kv.second.set || !kv.second.required, "finalize: missing weight '%s'", kv.first.c_str());
+        return 0;
+    }
+};
+
+// torch.linspace(start, end, steps) in fp32 (symmetric two-sided evaluation of the CPU kernel)
+static std::vector<float> linspace_f32(float start, float end, int steps) {
+    std::vector<float> v(steps);
+    if (steps == 1) {
+        v[0] = start;
+        return v;
+    }
+    const float step = (end - start) / (float)(steps - 1);
+    const int half = steps / 2;
+    for (int i = 0; i < steps; ++i) v[i] = i < half ? start + step * (float)i : end - step * (float)(steps - i - 1);
+    return v;
+}
+
+struct RopeTable {
+    float* cos_dev = nullptr;
+    float* sin_dev = nullptr;
+    int npos = 0;
+    bool set_cos = false, set_sin = false;
+};
+
+static int upload(float* dst, const std::vector<float>& v) {
+    GTAV_CHECK_HIP(hipMemcpy(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// axial "pixel" RoPE table (rotary_embedding_torch.py:290-317): per position (r, c) of a gh x gw grid,
+// head dims [0, 2F) rotate with the row angle, [2F, 4F) with the column angle (each freq repeated twice),
+// remaining dims are identity.
+static void build_axial_table(const std::vector<float>& freqs, int gh, int gw, std::vector<float>& c, std::vector<float>& s) {
+    const int F = (int)freqs.size();
+    c.assign((size_t)gh * gw * 64, 1.0f);
+    s.assign((size_t)gh * gw * 64, 0.0f);
+    std::vector<float> ph = linspace_f32(-1.f, 1.f, gh), pw = linspace_f32(-1.f, 1.f, gw);
+    for (int r = 0; r < gh; ++r)
+        for (int q = 0; q < gw; ++q)
+            for (int d = 0; d < 4 * F && d < 64; ++d) {
+                const float ang = d < 2 * F ? ph[r] * freqs[d / 2] : pw[q] * freqs[(d - 2 * F) / 2];
+                c[((size_t)r * gw + q) * 64 + d] = cosf(ang);
+                s[((size_t)r * gw + q) * 64 + d] = sinf(ang);
+            }
+}
+
+}  // namespace
+
+// ================================================================================================
+// DiT
+// ================================================================================================
+struct gtav_dit {
+    gtav_dit_config cfg;
+    int D, L, heads, P, gh, gw, C, p, H, W, Hm, Hm_pad, A, Apad, MODW, Kpe, Nfin, maxB, maxT, Mmax, max_rows;
+    Arena arena;
+    WeightTable wt;
+    // fp16 GEMM weights
+    f16 *w_pe = nullptr, *w_final = nullptr;
+    struct Half { f16 *w_qkv, *w_out, *w_fc1, *w_fc2; float *b_out, *b_fc1, *b_fc2; };
+    std::vector<Half> halves;  // [L*2]
+    float *b_pe = nullptr, *b_final = nullptr;
+    // fp32 conditioning path
+    float *w_t0, *b_t0, *w_t2cat, *b_t2, *b_ext, *b_t2a, *w_ada, *b_ada;
+    float* sincos = nullptr;  // [1000][256]
+    bool sincos_set = false;
+    RopeTable rope_s, rope_t;
+    std::vector<float> freqs_s, freqs_t;
+    float *freqs_s_dev = nullptr, *freqs_t_dev = nullptr;
+    // workspace
+    f16 *xp, *xn, *qs, *ks, *vts, *qt, *ao, *hbuf;
+    std::vector<f16*> kvcache;  // [L]
+    float *resid, *fo, *vout, *E, *HC, *Sc, *mod;
+    int* err_flag = nullptr;
+    int* frame_idx = nullptr;   // [maxB * maxT]
+    float* ac_table = nullptr;  // alphas_cumprod [1000]
+    std::vector<float> ac_host;
+    bool finalized = false;
+};
+
+static int dit_cond(gtav_dit* h, const int64_t* t64, int rows, int Tq, int t_ctx, int t_cur, const float* actions,
+                    int64_t act_outer, int64_t act_inner, hipStream_t s) {
+    GTAV_REQUIRE(rows <= h->max_rows, "conditioning rows %d exceed max_cond_rows %d", rows, h->max_rows);
+    const int ldhc = h->D + h->Apad;
+    RET_IF(launch_cond_inputs(t64, rows, Tq, t_ctx, t_cur, h->sincos, h->E, actions, act_outer, act_inner, h->A, h->HC, ldhc,
+                              h->D, h->Apad, h->err_flag, s));
+    RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, h->HC, ldhc, rows, h->D, 256, 1, s));
+    RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, h->Sc, h->D, rows, h->D, ldhc, 1, s));
+    RET_IF(launch_skinny_f32(h->Sc, h->D, h->w_ada, h->b_ada, h->mod, h->MODW, rows, h->MODW, h->D, 0, s));
+    return 0;
+}
+
+// x_src: frames of C*H*W floats; frame_index (device, optional) selects the NB = B*Tq frames to process.
+static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_index, int B, int Tq, int t0,
+                            const float* mod, const int* mod_rows, float* v_out, hipStream_t s) {
+    const int D = h->D, P = h->P, NB = B * Tq, M = NB * P;
+    GTAV_REQUIRE(M <= h->Mmax, "forward: %d tokens exceed workspace (%d)", M, h->Mmax);
+    RET_IF(launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, s));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = h->xp; g.ldx = h->Kpe; g.W = h->w_pe; g.M = M; g.N = D; g.K = h->Kpe; g.bias = h->b_pe; g.out = h->resid; g.ldo = D;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    for (int l = 0; l < h->L; ++l) {
+        for (int hf = 0; hf < 2; ++hf) {
+            const gtav_dit::Half& w = h->halves[l * 2 + hf];
+            const float* mb = mod + (size_t)(l * 2 + hf) * 6 * D;
+            RET_IF(launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, s));
+            memset(&g, 0, sizeof(g));
+            g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
+            if (hf == 0) {
+                g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
+                g.rope_cos = h->rope_s.cos_dev; g.rope_sin = h->rope_s.sin_dev;
+            } else {
+                g.qkv_mode = QKV_TEMPORAL; g.q = h->qt; g.k = h->kvcache[l]; g.v = h->kvcache[l];
+                g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
+                g.rope_cos = h->rope_t.cos_dev; g.rope_sin = h->rope_t.sin_dev;
+            }
+            RET_IF(launch_gemm(g, EPI_QKV, s));
+            if (hf == 0) RET_IF(launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
+            else RET_IF(launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
+            memset(&g, 0, sizeof(g));
+            g.X = h->ao; g.ldx = D; g.W = w.w_out; g.M = M; g.N = D; g.K = D; g.bias = w.b_out; g.out = h->resid; g.ldo = D;
+            g.gate = mb + 2 * D; g.gate_stride = h->MODW; g.gate_rows = mod_rows; g.rows_per_gate = P;
+            RET_IF(launch_gemm(g, EPI_RESID, s));
+            RET_IF(launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, s));
+            memset(&g, 0, sizeof(g));
+            g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad;
+            RET_IF(launch_gemm(g, EPI_GELU_TANH, s));
+            memset(&g, 0, sizeof(g));
+            g.X = h->hbuf; g.ldx = h->Hm_pad; g.W = w.w_fc2; g.M = M; g.N = D; g.K = h->Hm_pad; g.bias = w.b_fc2; g.out = h->resid; g.ldo = D;
+            g.gate = mb + 5 * D; g.gate_stride = h->MODW; g.gate_rows = mod_rows; g.rows_per_gate = P;
+            RET_IF(launch_gemm(g, EPI_RESID, s));
+        }
+    }
+    const float* mf = mod + (size_t)h->L * 12 * D;
+    RET_IF(launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, s));
+    memset(&g, 0, sizeof(g));
+    g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    RET_IF(launch_unpatchify(h->fo, h->Nfin, v_out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
+    return 0;
+}
+
+extern "C" {
+
+const char* gtav_last_error(void) { return gtav::last_error(); }
+int gtav_abi_version(void) { return 1; }
+
+int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
+    GTAV_REQUIRE(c && out, "dit_create: null argument");
+    GTAV_REQUIRE(c->hidden_size % 256 == 0 && c->hidden_size <= 2048, "hidden_size=%d must be a multiple of 256, <= 2048", c->hidden_size);
+    GTAV_REQUIRE(c->num_heads > 0 && c->hidden_size / c->num_heads == 64 && c->hidden_size % c->num_heads == 0,
+                 "only head_dim 64 is implemented (hidden %d, heads %d)", c->hidden_size, c->num_heads);
+    GTAV_REQUIRE(c->input_h % c->patch_size == 0 && c->input_w % c->patch_size == 0, "input %dx%d not divisible by patch %d",
+                 c->input_h, c->input_w, c->patch_size);
+    GTAV_REQUIRE(c->max_frames >= 1 && c->max_frames <= 8, "max_frames=%d must be in [1, 8]", c->max_frames);
+    GTAV_REQUIRE(c->max_batch >= 1 && c->depth >= 1, "bad max_batch/depth");
+    RET_IF(skinny_init());
+    gtav_dit* h = new gtav_dit();
+    h->cfg = *c;
+    h->D = c->hidden_size; h->L = c->depth; h->heads = c->num_heads; h->C = c->in_channels; h->p = c->patch_size;
+    h->H = c->input_h; h->W = c->input_w; h->gh = h->H / h->p; h->gw = h->W / h->p; h->P = h->gh * h->gw;
+    const int D = h->D;
+    if ((h->P % 8) != 0) {
+        set_error("tokens per frame P=%d must be a multiple of 8", h->P);
+        delete h;
+        return 2;
+    }
+    h->Hm = (int)(D * c->mlp_ratio); h->Hm_pad = round_up(h->Hm, 128);
+    h->A = c->external_cond_dim > 0 ? c->external_cond_dim : 0; h->Apad = round_up(h->A > 0 ? h->A : 1, 32);
+    h->MODW = h->L * 12 * D + 2 * D;
+    h->Kpe = round_up(h->C * h->p * h->p, 64);
+    h->Nfin = h->p * h->p * h->C;
+    h->maxB = c->max_batch; h->maxT = c->max_frames; h->Mmax = h->maxB * h->maxT * h->P;
+    h->max_rows = c->max_cond_rows > h->maxB * h->maxT ? c->max_cond_rows : h->maxB * h->maxT;
+    Arena& a = h->arena;
+    WeightTable& wt = h->wt;
+    int rc = 0;
+#define A_(expr) do { if (!rc) rc = (expr); } while (0)
+    A_(a.alloc_t(&h->w_pe, (size_t)round_up(D, 128) * h->Kpe));
+    wt.add_f16("x_embedder.proj.weight", D, h->C * h->p * h->p, h->w_pe, round_up(D, 128), h->Kpe);
+    A_(a.alloc_t(&h->b_pe, D)); wt.add_f32("x_embedder.proj.bias", 1, D, h->b_pe, D);
+    A_(a.alloc_t(&h->w_t0, (size_t)D * 256)); wt.add_f32("t_embedder.mlp.0.weight", D, 256, h->w_t0, 256);
+    A_(a.alloc_t(&h->b_t0, D)); wt.add_f32("t_embedder.mlp.0.bias", 1, D, h->b_t0, D);
+    const int ldhc = D + h->Apad;
+    A_(a.alloc_t(&h->w_t2cat, (size_t)D * ldhc)); wt.add_f32("t_embedder.mlp.2.weight", D, D, h->w_t2cat, ldhc, 0);
+    A_(a.alloc_t(&h->b_t2, D)); wt.add_f32("t_embedder.mlp.2.bias", 1, D, h->b_t2, D);
+    A_(a.alloc_t(&h->b_ext, D)); A_(a.alloc_t(&h->b_t2a, D));
+    if (h->A > 0) {
+        wt.add_f32("external_cond.weight", D, h->A, h->w_t2cat, ldhc, D);
+        wt.add_f32("external_cond.bias", 1, D, h->b_ext, D);
+    }
+    A_(a.alloc_t(&h->w_ada, (size_t)h->MODW * D)); A_(a.alloc_t(&h->b_ada, h->MODW));
+    h->halves.resize(h->L * 2);
+    for (int l = 0; l < h->L && !rc; ++l)
+        for (int hf = 0; hf < 2; ++hf) {
+            gtav_dit::Half& w = h->halves[l * 2 + hf];
+            char pre[64];
+            snprintf(pre, sizeof(pre), "blocks.%d.%c_", l, hf == 0 ? 's' : 't');
+            std::string P_(pre);
+            A_(a.alloc_t(&w.w_qkv, (size_t)3 * D * D)); wt.add_f16(P_ + "attn.to_qkv.weight", 3 * D, D, w.w_qkv, 3 * D, D);
+            A_(a.alloc_t(&w.w_out, (size_t)D * D)); wt.add_f16(P_ + "attn.to_out.weight", D, D, w.w_out, D, D);
+            A_(a.alloc_t(&w.b_out, D)); wt.add_f32(P_ + "attn.to_out.bias", 1, D, w.b_out, D);
+            A_(a.alloc_t(&w.w_fc1, (size_t)h->Hm_pad * D)); wt.add_f16(P_ + "mlp.fc1.weight", h->Hm, D, w.w_fc1, h->Hm_pad, D);
+            A_(a.alloc_t(&w.b_fc1, h->Hm_pad)); wt.add_f32(P_ + "mlp.fc1.bias", 1, h->Hm, w.b_fc1, h->Hm);
+            A_(a.alloc_t(&w.w_fc2, (size_t)D * h->Hm_pad)); wt.add_f16(P_ + "mlp.fc2.weight", D, h->Hm, w.w_fc2, D, h->Hm_pad);
+            A_(a.alloc_t(&w.b_fc2, D)); wt.add_f32(P_ + "mlp.fc2.bias", 1, D, w.b_fc2, D);
+            const size_t row0 = (size_t)(l * 2 + hf) * 6 * D;
+            wt.add_f32(P_ + "adaLN_modulation.1.weight", 6 * D, D, h->w_ada + row0 * D, D);
+            wt.add_f32(P_ + "adaLN_modulation.1.bias", 1, 6 * D, h->b_ada + row0, 6 * D);
+        }
+    A_(a.alloc_t(&h->w_final, (size_t)round_up(h->Nfin, 128) * D));
+    wt.add_f16("final_layer.linear.weight", h->Nfin, D, h->w_final, round_up(h->Nfin, 128), D);
+    A_(a.alloc_t(&h->b_final, round_up(h->Nfin, 128))); wt.add_f32("final_layer.linear.bias", 1, h->Nfin, h->b_final, h->Nfin);
+    {
+        const size_t row0 = (size_t)h->L * 12 * D;
+        wt.add_f32("final_layer.adaLN_modulation.1.weight", 2 * D, D, h->w_ada + row0 * D, D);
+        wt.add_f32("final_layer.adaLN_modulation.1.bias", 1, 2 * D, h->b_ada + row0, 2 * D);
+    }
+    // tables (optional overrides; computed in finalize when absent)
+    A_(a.alloc_t(&h->sincos, (size_t)1000 * 256)); wt.add_f32("tables.timestep_sincos", 1000, 256, h->sincos, 256, 0, false);
+    h->rope_s.npos = h->P; h->rope_t.npos = h->maxT;
+    A_(a.alloc_t(&h->rope_s.cos_dev, (size_t)h->P * 64)); wt.add_f32("tables.rope_spatial_cos", h->P, 64, h->rope_s.cos_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_s.sin_dev, (size_t)h->P * 64)); wt.add_f32("tables.rope_spatial_sin", h->P, 64, h->rope_s.sin_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_t.cos_dev, (size_t)h->maxT * 64)); wt.add_f32("tables.rope_temporal_cos", h->maxT, 64, h->rope_t.cos_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_t.sin_dev, (size_t)h->maxT * 64)); wt.add_f32("tables.rope_temporal_sin", h->maxT, 64, h->rope_t.sin_dev, 64, 0, false);
+    A_(a.alloc_t(&h->freqs_s_dev, 16)); wt.add_f32("spatial_rotary_emb.freqs", 1, 16, h->freqs_s_dev, 16, 0, false);
+    A_(a.alloc_t(&h->freqs_t_dev, 32)); wt.add_f32("temporal_rotary_emb.freqs", 1, 32, h->freqs_t_dev, 32, 0, false);
+    // workspace
+    const size_t Mx = h->Mmax;
+    A_(a.alloc_t(&h->xp, Mx * h->Kpe)); A_(a.alloc_t(&h->xn, Mx * D)); A_(a.alloc_t(&h->qs, Mx * D)); A_(a.alloc_t(&h->ks, Mx * D));
+    A_(a.alloc_t(&h->vts, Mx * D)); A_(a.alloc_t(&h->qt, Mx * D)); A_(a.alloc_t(&h->ao, Mx * D)); A_(a.alloc_t(&h->hbuf, Mx * h->Hm_pad));
+    h->kvcache.resize(h->L);
+    for (int l = 0; l < h->L; ++l) A_(a.alloc_t(&h->kvcache[l], Mx * 2 * D));
+    A_(a.alloc_t(&h->resid, Mx * D)); A_(a.alloc_t(&h->fo, Mx * h->Nfin));
+    A_(a.alloc_t(&h->vout, Mx / h->P * h->C * h->H * h->W));
+    const size_t R = h->max_rows;
+    A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
+    A_(a.alloc_t(&h->err_flag, 4)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
+#undef A_
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void gtav_dit_destroy(gtav_dit* h) { delete h; }
+
+int gtav_dit_set_weight(gtav_dit* h, const char* name, const float* src, int64_t numel, void* stream) {
+    GTAV_REQUIRE(h && name && src, "dit_set_weight: null argument");
+    std::string n(name);
+    // any alias of the two shared rotary freqs parameters
+    if (n.size() > 16 && n.compare(n.size() - 16, 16, "rotary_emb.freqs") == 0) {
+        const bool spatial = n.rfind("spatial_", 0) == 0 || n.find(".s_attn.") != std::string::npos;
+        n = spatial ? "spatial_rotary_emb.freqs" : "temporal_rotary_emb.freqs";
+    }
+    h->finalized = false;
+    return h->wt.set(n.c_str(), src, numel, (hipStream_t)stream);
+}
+
+int gtav_dit_get_weight(gtav_dit* h, const char* name, float* dst, int64_t numel, void* stream) {
+    GTAV_REQUIRE(h && name && dst, "dit_get_weight: null argument");
+    return h->wt.get(name, dst, numel, (hipStream_t)stream);
+}
+
+int gtav_dit_finalize(gtav_dit* h, void* stream) {
+    GTAV_REQUIRE(h, "dit_finalize: null handle");
+    hipStream_t s = (hipStream_t)stream;
+    RET_IF(h->wt.check_complete());
+    GTAV_CHECK_HIP(hipStreamSynchronize(s));
+    const int D = h->D;
+    // b_t2a = b_t2 + b_ext (bias of c when actions are given, model/dit.py:363-364)
+    RET_IF(launch_add_f32(h->b_t2, h->b_ext, h->b_t2a, D, s));
+    // rotary frequencies: loaded values win, otherwise the constructor formulas (dit.py:259-262)
+    std::vector<float> fs(16), ft(32);
+    if (h->wt.slots["spatial_rotary_emb.freqs"].set) GTAV_CHECK_HIP(hipMemcpy(fs.data(), h->freqs_s_dev, 64, hipMemcpyDeviceToHost));
+    else { std::vector<float> l = linspace_f32(1.0f, 128.0f, 16); for (int i = 0; i < 16; ++i) fs[i] = l[i] * (float)M_PI; }
+    if (h->wt.slots["temporal_rotary_emb.freqs"].set) GTAV_CHECK_HIP(hipMemcpy(ft.data(), h->freqs_t_dev, 128, hipMemcpyDeviceToHost));
+    else for (int i = 0; i < 32; ++i) ft[i] = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+    if (!(h->wt.slots["tables.rope_spatial_cos"].set && h->wt.slots["tables.rope_spatial_sin"].set)) {
+        std::vector<float> c, sn;
+        build_axial_table(fs, h->gh, h->gw, c, sn);
+        RET_IF(upload(h->rope_s.cos_dev, c)); RET_IF(upload(h->rope_s.sin_dev, sn));
+    }
+    if (!(h->wt.slots["tables.rope_temporal_cos"].set && h->wt.slots["tables.rope_temporal_sin"].set)) {
+        std::vector<float> c((size_t)h->maxT * 64), sn((size_t)h->maxT * 64);
+        for (int t = 0; t < h->maxT; ++t)
+            for (int d = 0; d < 64; ++d) {
+                const float ang = (float)t * ft[d / 2];
+                c[t * 64 + d] = cosf(ang); sn[t * 64 + d] = sinf(ang);
+            }
+        RET_IF(upload(h->rope_t.cos_dev, c)); RET_IF(upload(h->rope_t.sin_dev, sn));
+    }
+    if (!h->wt.slots["tables.timestep_sincos"].set) {
+        std::vector<float> tab((size_t)1000 * 256);
+        for (int k = 0; k < 128; ++k) {
+            const float f = expf(-logf(10000.0f) * (float)k / 128.0f);
+            for (int t = 0; t < 1000; ++t) {
+                const float arg = (float)t * f;
+                tab[(size_t)t * 256 + k] = cosf(arg);
+                tab[(size_t)t * 256 + 128 + k] = sinf(arg);
+            }
+        }
+        RET_IF(upload(h->sincos, tab));
+    }
+    GTAV_CHECK_HIP(hipStreamSynchronize(s));
+    h->finalized = true;
+    return 0;
+}
+
+int gtav_dit_forward(gtav_dit* h, const float* x, const int64_t* t, const float* actions, float* out, int32_t B, int32_t T,
+                     void* stream) {
+    GTAV_REQUIRE(h && x && t && out, "dit_forward: null argument");
+    GTAV_REQUIRE(h->finalized, "dit_forward: call gtav_dit_finalize first");
+    GTAV_REQUIRE(B >= 1 && B <= h->maxB && T >= 1 && T <= h->maxT, "dit_forward: B=%d T=%d outside capacity (%d, %d)", B, T, h->maxB, h->maxT);
+    GTAV_REQUIRE(!actions || h->A > 0, "dit_forward: model has no external_cond");
+    hipStream_t s = (hipStream_t)stream;
+    RET_IF(dit_cond(h, t, B * T, 1, 0, 0, actions, h->A, 0, s));
+    return dit_forward_core(h, x, nullptr, B, T, 0, h->mod, nullptr, out, s);
+}
+
+int gtav_dit_set_schedule(gtav_dit* h, const float* ac, int32_t n) {
+    GTAV_REQUIRE(h && ac && n == 1000, "dit_set_schedule: expected 1000 alphas_cumprod values");
+    h->ac_host.assign(ac, ac + n);
+    GTAV_CHECK_HIP(hipMemcpy(h->ac_table, ac, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
+                          int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions, int32_t mode, float* v_out,
+                          void* stream) {
+    GTAV_REQUIRE(h && x, "denoise_step: null argument");
+    GTAV_REQUIRE(h->finalized && !h->ac_host.empty(), "denoise_step: finalize the model and set the schedule first");
+    const int T = cur - start + 1;
+    GTAV_REQUIRE(start >= 0 && cur < F && T >= 1 && T <= h->maxT && B >= 1 && B <= h->maxB, "denoise_step: bad window [%d, %d] of %d frames", start, cur, F);
+    GTAV_REQUIRE(t_cur >= 0 && t_cur < 1000 && t_next >= 0 && t_next < 1000 && t_ctx >= 0 && t_ctx < 1000, "denoise_step: timestep out of range");
+    GTAV_REQUIRE(!actions || h->A > 0, "denoise_step: model has no external_cond");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t fsz = (size_t)h->C * h->H * h->W;
+    const int Tq = mode == 1 ? 1 : T, t0 = mode == 1 ? T - 1 : 0;
+    // frame indices of the processed frames inside x (B, F, ...)
+    RET_IF(launch_frame_index(h->frame_idx, B, Tq, F, mode == 1 ? cur : start, s));
+    const float* act = actions ? actions + (size_t)(mode == 1 ? cur : start) * h->A : nullptr;
+    RET_IF(dit_cond(h, nullptr, B * Tq, Tq, t_ctx, t_cur, act, (int64_t)F * h->A, h->A, s));
+    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, h->mod, nullptr, h->vout, s));
+    // DDIM update of frame `cur` (train_dit.py:110-125, generate.py:220)
+    const float* vlast = h->vout + (size_t)(Tq - 1) * fsz;
+    RET_IF(launch_ddim_update(x + (size_t)cur * fsz, (size_t)F * fsz, vlast, (size_t)Tq * fsz, x + (size_t)cur * fsz, (size_t)F * fsz,
+                              B, (int)fsz, nullptr, nullptr, h->ac_host[t_cur], h->ac_host[t_next], is_final, s));
+    if (v_out) RET_IF(launch_copy_rows_f32(vlast, (size_t)Tq * fsz, v_out, fsz, B, fsz, s));
+    return 0;
+}
+
+int gtav_dit_check(gtav_dit* h, void* stream) {
+    GTAV_REQUIRE(h, "dit_check: null handle");
+    int flag = 0;
+    GTAV_CHECK_HIP(hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    GTAV_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, sizeof(int), (hipStream_t)stream));
+    GTAV_REQUIRE(flag == 0, "a timestep outside [0, 999] was passed to the DiT");
+    return 0;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// ViT-VAE
+// ================================================================================================
+struct gtav_vae {
+    gtav_vae_config cfg;
+    int S, gh, gw, p, H, W, Kp, Npred, Lat, Mom, maxN, Mmax, Dmax, Hmax;
+    Arena arena;
+    WeightTable wt;
+    struct Block { float *g1, *b1, *g2, *b2, *b_qkv, *b_proj, *b_fc1, *b_fc2; f16 *w_qkv, *w_proj, *w_fc1, *w_fc2; };
+    std::vector<Block> enc, dec;
+    f16 *w_patch, *w_quant, *w_post, *w_pred;
+    float *b_patch, *b_quant, *b_post, *b_pred, *g_enc, *be_enc, *g_dec, *be_dec;
+    RopeTable rope_e, rope_d;
+    f16 *xp, *xn, *q, *k, *vt, *ao, *hbuf, *zin;
+    float *resid, *po;
+    bool finalized = false;
+};
+
+static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim, int heads, const RopeTable& rope, int N,
+                      hipStream_t s) {
+    const int M = N * h->S, Hm = (int)(dim * h->cfg.mlp_ratio), Hm_pad = round_up(Hm, 128);
+    GemmParams g;
+    for (auto& b : blocks) {
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, s));
+        memset(&g, 0, sizeof(g));
+        g.X = h->xn; g.ldx = dim; g.W = b.w_qkv; g.M = M; g.N = 3 * dim; g.K = dim; g.bias = b.b_qkv; g.D = dim; g.S = h->S;
+        g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cos = rope.cos_dev; g.rope_sin = rope.sin_dev;
+        RET_IF(launch_gemm(g, EPI_QKV, s));
+        RET_IF(launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s));
+        memset(&g, 0, sizeof(g));
+        g.X = h->ao; g.ldx = dim; g.W = b.w_proj; g.M = M; g.N = dim; g.K = dim; g.bias = b.b_proj; g.out = h->resid; g.ldo = dim;
+        RET_IF(launch_gemm(g, EPI_RESID, s));
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, s));
+        memset(&g, 0, sizeof(g));
+        g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad;
+        RET_IF(launch_gemm(g, EPI_GELU_ERF, s));
+        memset(&g, 0, sizeof(g));
+        g.X = h->hbuf; g.ldx = Hm_pad; g.W = b.w_fc2; g.M = M; g.N = dim; g.K = Hm_pad; g.bias = b.b_fc2; g.out = h->resid; g.ldo = dim;
+        RET_IF(launch_gemm(g, EPI_RESID, s));
+    }
+    return 0;
+}
+
+extern "C" {
+
+int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
+    GTAV_REQUIRE(c && out, "vae_create: null argument");
+    GTAV_REQUIRE(c->enc_dim % 128 == 0 && c->dec_dim % 128 == 0 && c->enc_dim / c->enc_heads == 64 && c->dec_dim / c->dec_heads == 64,
+                 "VAE widths must be multiples of 128 with head_dim 64");
+    GTAV_REQUIRE(c->input_height % c->patch_size == 0 && c->input_width % c->patch_size == 0, "VAE input not divisible by patch");
+    GTAV_REQUIRE(c->latent_dim % 4 == 0 && c->latent_dim <= 64, "latent_dim=%d must be a multiple of 4, <= 64", c->latent_dim);
+    gtav_vae* h = new gtav_vae();
+    h->cfg = *c;
+    h->p = c->patch_size; h->H = c->input_height; h->W = c->input_width; h->gh = h->H / h->p; h->gw = h->W / h->p; h->S = h->gh * h->gw;
+    if (h->S % 8 != 0) {
+        set_error("VAE seq_len=%d must be a multiple of 8", h->S);
+        delete h;
+        return 2;
+    }
+    h->Npred = 3 * h->p * h->p; h->Kp = round_up(h->Npred, 64); h->Lat = c->latent_dim; h->Mom = (c->use_variational ? 2 : 1) * h->Lat;
+    h->maxN = c->max_frames_per_call > 0 ? c->max_frames_per_call : 8; h->Mmax = h->maxN * h->S;
+    h->Dmax = c->enc_dim > c->dec_dim ? c->enc_dim : c->dec_dim;
+    h->Hmax = round_up((int)(h->Dmax * c->mlp_ratio), 128);
+    Arena& a = h->arena;
+    WeightTable& wt = h->wt;
+    int rc = 0;
+#define A_(expr) do { if (!rc) rc = (expr); } while (0)
+    const int De = c->enc_dim, Dd = c->dec_dim;
+    A_(a.alloc_t(&h->w_patch, (size_t)round_up(De, 128) * h->Kp)); wt.add_f16("patch_embed.proj.weight", De, h->Npred, h->w_patch, round_up(De, 128), h->Kp);
+    A_(a.alloc_t(&h->b_patch, De)); wt.add_f32("patch_embed.proj.bias", 1, De, h->b_patch, De);
+    auto mk = [&](std::vector<gtav_vae::Block>& v, const char* prefix, int depth, int dim) {
+        const int Hm = (int)(dim * c->mlp_ratio), Hm_pad = round_up(Hm, 128);
+        v.resize(depth);
+        for (int i = 0; i < depth && !rc; ++i) {
+            gtav_vae::Block& b = v[i];
+            char pre[64];
+            snprintf(pre, sizeof(pre), "%s.%d.", prefix, i);
+            std::string P_(pre);
+            A_(a.alloc_t(&b.g1, dim)); wt.add_f32(P_ + "norm1.weight", 1, dim, b.g1, dim);
+            A_(a.alloc_t(&b.b1, dim)); wt.add_f32(P_ + "norm1.bias", 1, dim, b.b1, dim);
+            A_(a.alloc_t(&b.w_qkv, (size_t)round_up(3 * dim, 128) * dim)); wt.add_f16(P_ + "attn.qkv.weight", 3 * dim, dim, b.w_qkv, round_up(3 * dim, 128), dim);
+            A_(a.alloc_t(&b.b_qkv, 3 * dim)); wt.add_f32(P_ + "attn.qkv.bias", 1, 3 * dim, b.b_qkv, 3 * dim);
+            A_(a.alloc_t(&b.w_proj, (size_t)dim * dim)); wt.add_f16(P_ + "attn.proj.weight", dim, dim, b.w_proj, dim, dim);
+            A_(a.alloc_t(&b.b_proj, dim)); wt.add_f32(P_ + "attn.proj.bias", 1, dim, b.b_proj, dim);
+            A_(a.alloc_t(&b.g2, dim)); wt.add_f32(P_ + "norm2.weight", 1, dim, b.g2, dim);
+            A_(a.alloc_t(&b.b2, dim)); wt.add_f32(P_ + "norm2.bias", 1, dim, b.b2, dim);
+            A_(a.alloc_t(&b.w_fc1, (size_t)Hm_pad * dim)); wt.add_f16(P_ + "mlp.fc1.weight", Hm, dim, b.w_fc1, Hm_pad, dim);
+            A_(a.alloc_t(&b.b_fc1, Hm_pad)); wt.add_f32(P_ + "mlp.fc1.bias", 1, Hm, b.b_fc1, Hm);
+            A_(a.alloc_t(&b.w_fc2, (size_t)dim * Hm_pad)); wt.add_f16(P_ + "mlp.fc2.weight", dim, Hm, b.w_fc2, dim, Hm_pad);
+            A_(a.alloc_t(&b.b_fc2, dim)); wt.add_f32(P_ + "mlp.fc2.bias", 1, dim, b.b_fc2, dim);
+        }
+    };
+    mk(h->enc, "encoder", c->enc_depth, De);
+    A_(a.alloc_t(&h->g_enc, De)); wt.add_f32("enc_norm.weight", 1, De, h->g_enc, De);
+    A_(a.alloc_t(&h->be_enc, De)); wt.add_f32("enc_norm.bias", 1, De, h->be_enc, De);
+    A_(a.alloc_t(&h->w_quant, (size_t)128 * De)); wt.add_f16("quant_conv.weight", h->Mom, De, h->w_quant, 128, De);
+    A_(a.alloc_t(&h->b_quant, 128)); wt.add_f32("quant_conv.bias", 1, h->Mom, h->b_quant, h->Mom);
+    A_(a.alloc_t(&h->w_post, (size_t)round_up(Dd, 128) * 64)); wt.add_f16("post_quant_conv.weight", Dd, h->Lat, h->w_post, round_up(Dd, 128), 64);
+    A_(a.alloc_t(&h->b_post, Dd)); wt.add_f32("post_quant_conv.bias", 1, Dd, h->b_post, Dd);
+    mk(h->dec, "decoder", c->dec_depth, Dd);
+    A_(a.alloc_t(&h->g_dec, Dd)); wt.add_f32("dec_norm.weight", 1, Dd, h->g_dec, Dd);
+    A_(a.alloc_t(&h->be_dec, Dd)); wt.add_f32("dec_norm.bias", 1, Dd, h->be_dec, Dd);
+    A_(a.alloc_t(&h->w_pred, (size_t)round_up(h->Npred, 128) * Dd)); wt.add_f16("predictor.weight", h->Npred, Dd, h->w_pred, round_up(h->Npred, 128), Dd);
+    A_(a.alloc_t(&h->b_pred, round_up(h->Npred, 128))); wt.add_f32("predictor.bias", 1, h->Npred, h->b_pred, h->Npred);
+    h->rope_e.npos = h->rope_d.npos = h->S;
+    A_(a.alloc_t(&h->rope_e.cos_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_enc_cos", h->S, 64, h->rope_e.cos_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_e.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_enc_sin", h->S, 64, h->rope_e.sin_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_d.cos_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_cos", h->S, 64, h->rope_d.cos_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_d.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_sin", h->S, 64, h->rope_d.sin_dev, 64, 0, false);
+    const size_t Mx = h->Mmax, Dm = h->Dmax;
+    A_(a.alloc_t(&h->xp, Mx * h->Kp)); A_(a.alloc_t(&h->xn, Mx * Dm)); A_(a.alloc_t(&h->q, Mx * Dm)); A_(a.alloc_t(&h->k, Mx * Dm));
+    A_(a.alloc_t(&h->vt, Mx * Dm)); A_(a.alloc_t(&h->ao, Mx * Dm)); A_(a.alloc_t(&h->hbuf, Mx * h->Hmax)); A_(a.alloc_t(&h->zin, Mx * 64));
+    A_(a.alloc_t(&h->resid, Mx * Dm)); A_(a.alloc_t(&h->po, Mx * h->Npred));
+#undef A_
+    if (rc) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+void gtav_vae_destroy(gtav_vae* h) { delete h; }
+
+int gtav_vae_set_weight(gtav_vae* h, const char* name, const float* src, int64_t numel, void* stream) {
+    GTAV_REQUIRE(h && name && src, "vae_set_weight: null argument");
+    h->finalized = false;
+    return h->wt.set(name, src, numel, (hipStream_t)stream);
+}
+int gtav_vae_get_weight(gtav_vae* h, const char* name, float* dst, int64_t numel, void* stream) {
+    GTAV_REQUIRE(h && name && dst, "vae_get_weight: null argument");
+    return h->wt.get(name, dst, numel, (hipStream_t)stream);
+}
+
+int gtav_vae_finalize(gtav_vae* h, void* stream) {
+    GTAV_REQUIRE(h, "vae_finalize: null handle");
+    RET_IF(h->wt.check_complete());
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    // model/vae.py:71-76: RotaryEmbedding(dim = head_dim // 4 = 16, pixel, max_freq = H*W) -> 8 freqs, 32 rotated dims
+    auto build = [&](RopeTable& r, const char* cn, const char* sn_) -> int {
+        if (h->wt.slots[cn].set && h->wt.slots[sn_].set) return 0;
+        std::vector<float> l = linspace_f32(1.0f, (float)(h->S) / 2.0f, 8), fr(8), c, sn;
+        for (int i = 0; i < 8; ++i) fr[i] = l[i] * (float)M_PI;
+        build_axial_table(fr, h->gh, h->gw, c, sn);
+        RET_IF(upload(r.cos_dev, c));
+        return upload(r.sin_dev, sn);
+    };
+    RET_IF(build(h->rope_e, "tables.rope_enc_cos", "tables.rope_enc_sin"));
+    RET_IF(build(h->rope_d, "tables.rope_dec_cos", "tables.rope_dec_sin"));
+    h->finalized = true;
+    return 0;
+}
+
+int gtav_vae_encode(gtav_vae* h, const float* img, float in_scale, float in_shift, float* moments, int32_t N, void* stream) {
+    GTAV_REQUIRE(h && img && moments, "vae_encode: null argument");
+    GTAV_REQUIRE(h->finalized, "vae_encode: call gtav_vae_finalize first");
+    GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_encode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
+    hipStream_t s = (hipStream_t)stream;
+    const int De = h->cfg.enc_dim, M = N * h->S;
+    RET_IF(launch_patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, s));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = h->xp; g.ldx = h->Kp; g.W = h->w_patch; g.M = M; g.N = De; g.K = h->Kp; g.bias = h->b_patch; g.out = h->resid; g.ldo = De;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    RET_IF(vae_blocks(h, h->enc, De, h->cfg.enc_heads, h->rope_e, N, s));
+    RET_IF(launch_ln_affine(h->resid, De, h->xn, De, M, De, h->g_enc, h->be_enc, s));
+    memset(&g, 0, sizeof(g));
+    g.X = h->xn; g.ldx = De; g.W = h->w_quant; g.M = M; g.N = h->Mom; g.K = De; g.bias = h->b_quant; g.out = moments; g.ldo = h->Mom;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    if (h->cfg.use_variational) RET_IF(launch_clamp_cols(moments, M, h->Mom, h->Lat, h->Mom, -30.f, 20.f, s));
+    return 0;
+}
+
+int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, float out_scale, float out_shift, int32_t N,
+                    void* stream) {
+    GTAV_REQUIRE(h && z && img, "vae_decode: null argument");
+    GTAV_REQUIRE(h->finalized, "vae_decode: call gtav_vae_finalize first");
+    GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_decode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
+    hipStream_t s = (hipStream_t)stream;
+    const int Dd = h->cfg.dec_dim, M = N * h->S;
+    RET_IF(launch_convert_pad_f16(z, h->Lat, M, h->Lat, h->zin, M, 64, z_scale, s));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = h->zin; g.ldx = 64; g.W = h->w_post; g.M = M; g.N = Dd; g.K = 64; g.bias = h->b_post; g.out = h->resid; g.ldo = Dd;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    RET_IF(vae_blocks(h, h->dec, Dd, h->cfg.dec_heads, h->rope_d, N, s));
+    RET_IF(launch_ln_affine(h->resid, Dd, h->xn, Dd, M, Dd, h->g_dec, h->be_dec, s));
+    memset(&g, 0, sizeof(g));
+    g.X = h->xn; g.ldx = Dd; g.W = h->w_pred; g.M = M; g.N = h->Npred; g.K = Dd; g.bias = h->b_pred; g.out = h->po; g.ldo = h->Npred;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    RET_IF(launch_unpatchify(h->po, h->Npred, img, N, 3, h->H, h->W, h->p, 1, out_scale, out_shift, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise entry points
+// ------------------------------------------------------------------------------------------------
+int gtav_ddim_update(const float* x, const float* v, float* out, int32_t rows, int32_t n, const float* alpha_t,
+                     const float* alpha_next, int32_t is_final, void* stream) {
+    GTAV_REQUIRE(x && v && out && alpha_t && (alpha_next || is_final), "ddim_update: null argument");
+    return launch_ddim_update(x, n, v, n, out, n, rows, n, alpha_t, alpha_next, 0.f, 0.f, is_final, (hipStream_t)stream);
+}
+int gtav_add_noise(const float* x, const float* noise, const float* alpha, float* out, int32_t rows, int32_t n, float clamp_abs,
+                   void* stream) {
+    return launch_add_noise(x, noise, alpha, out, rows, n, clamp_abs, (hipStream_t)stream);
+}
+int gtav_vtarget(const float* x, const float* noise, const float* alpha, float* vt, int32_t rows, int32_t n, float clamp_abs,
+                 void* stream) {
+    return launch_vtarget(x, noise, alpha, vt, rows, n, clamp_abs, (hipStream_t)stream);
+}
+int gtav_mse(const float* a, int64_t a_stride, const float* b, int64_t b_stride, int32_t rows, int32_t n, float* out, void* stream) {
+    return launch_mse(a, (size_t)a_stride, b, (size_t)b_stride, rows, n, out, (hipStream_t)stream);
+}
+int gtav_frames_to_u8(const float* img, uint8_t* out, int32_t N, int32_t H, int32_t W, void* stream) {
+    return launch_frames_to_u8(img, out, N, H, W, (hipStream_t)stream);
+}
+int gtav_moments_to_latents(const float* mom, float* lat, int32_t N, int32_t hw, int32_t latent, int32_t mom_ch, float scale,
+                            void* stream) {
+    return launch_moments_to_latents(mom, lat, N, hw, latent, mom_ch, scale, (hipStream_t)stream);
+}
+int gtav_latents_to_tokens(const float* lat, float* z, int32_t N, int32_t hw, int32_t latent, void* stream) {
+    return launch_latents_to_tokens(lat, z, N, hw, latent, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel-level entry points
+// ------------------------------------------------------------------------------------------------
+int gtav_op_gemm_f16(const void* x, int32_t ldx, const void* w, const float* bias, void* out, int32_t ldo, int32_t M, int32_t N,
+                     int32_t K, int32_t epilogue, const float* gate, int32_t gate_stride, int32_t rows_per_gate, void* stream) {
+    GTAV_REQUIRE(epilogue >= 0 && epilogue <= 4, "op_gemm_f16: epilogue %d", epilogue);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)x; g.ldx = ldx; g.W = (const f16*)w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.gate = gate; g.gate_stride = gate_stride; g.rows_per_gate = rows_per_gate;
+    return launch_gemm(g, epilogue, (hipStream_t)stream);
+}
+int gtav_op_gemm_qkv(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t D, int32_t mode, void* q,
+                     void* k, void* v, int32_t S, int32_t Tq, int32_t t0, int32_t Tmax, const float* rope_cos,
+                     const float* rope_sin, void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)x; g.ldx = ldx; g.W = (const f16*)w; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.D = D; g.S = S;
+    g.qkv_mode = mode; g.q = (f16*)q; g.k = (f16*)k; g.v = (f16*)v; g.Tq = Tq; g.t0 = t0; g.Tmax = Tmax;
+    g.rope_cos = rope_cos; g.rope_sin = rope_sin;
+    return launch_gemm(g, EPI_QKV, (hipStream_t)stream);
+}
+int gtav_op_skinny_f32(const float* x, int32_t ldx, const float* w, const float* bias, float* y, int32_t ldy, int32_t M,
+                       int32_t N, int32_t K, int32_t act_silu, void* stream) {
+    RET_IF(skinny_init());
+    return launch_skinny_f32(x, ldx, w, bias, y, ldy, M, N, K, act_silu, (hipStream_t)stream);
+}
+int gtav_op_ln_modulate(const float* x, void* out, int32_t M, int32_t D, const float* shift, const float* scale,
+                        int32_t mod_stride, int32_t rows_per_mod, void* stream) {
+    return launch_ln_modulate(x, D, (f16*)out, D, M, D, shift, scale, mod_stride, nullptr, rows_per_mod, (hipStream_t)stream);
+}
+int gtav_op_ln_affine(const float* x, void* out, int32_t M, int32_t D, const float* gamma, const float* beta, void* stream) {
+    return launch_ln_affine(x, D, (f16*)out, D, M, D, gamma, beta, (hipStream_t)stream);
+}
+int gtav_op_attn_spatial(const void* q, const void* k, const void* vt, void* o, int32_t NB, int32_t heads, int32_t S, void* stream) {
+    return launch_attn_spatial((const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, NB, heads, S, (hipStream_t)stream);
+}
+int gtav_op_attn_temporal(const void* q, const void* kv, void* o, int32_t B, int32_t P, int32_t D, int32_t Tq, int32_t t0,
+                          int32_t Tmax, void* stream) {
+    return launch_attn_temporal((const f16*)q, (const f16*)kv, (f16*)o, B, P, D, Tq, t0, Tmax, (hipStream_t)stream);
+}
+int gtav_op_convert_f16(const float* src, int32_t lds, int32_t R, int32_t C, void* dst, int32_t Rp, int32_t Cp, void* stream) {
+    return launch_convert_pad_f16(src, lds, R, C, (f16*)dst, Rp, Cp, 1.0f, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+// Attention kernels for gfx950.
+//
+// attn_spatial: non-causal attention over S tokens (S = 144 DiT frame tokens, 576 VAE tokens) per
+// (frame, head), head_dim 64.  One block per (frame, head, q-split): K [S][64] and Vt [64][S] of the
+// head are staged once in LDS (K rows XOR-swizzled for conflict-free ds_read_b128, Vt rows padded so
+// ds_read_b64 is conflict-free), every wave then walks 16-query tiles:
+//     S^T = K . Q^T          (v_mfma_f32_16x16x32_f16; keys on accumulator ROWS, queries on lanes)
+//     online softmax         (row max/sum = in-lane over 4..16 values + two xor-shuffles)
+//     O^T += Vt . P^T        (P^T is taken straight from the S^T accumulators: the k-slot -> key map
+//                             key = 32 s + 16 (j >> 2) + 4 g + (j & 3) is applied to the Vt read instead)
+// so P never moves between lanes or through LDS.
+//
+// attn_temporal: causal attention over the <= 8 frames of the sliding window per (b, position, head);
+// 25 dot products of length 64 per head: VALU + 16-lane xor-shuffle reductions, everything in registers.
+#include "ops.h"
+
+namespace gtav {
+
+namespace {
+
+constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+
+__global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
+                                                           const f16* __restrict__ Vt, f16* __restrict__ O, int heads, int S,
+                                                           int S_pad, int qsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                              // [S_pad][128 B], 16-B chunk c of row r stored at c ^ (r & 7)
+    const int vstride = (S_pad + 8) * 2;          // bytes per Vt row
+    char* Vs = smem + (size_t)S_pad * 128;        // [64][S_pad + 8] halves
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x;                    // nb * heads + head
+    const int nb = bh / heads, head = bh - nb * heads;
+    const f16* Kg = K + (size_t)bh * S * 64;
+    const f16* Vg = Vt + (size_t)bh * 64 * S;
+    const f16* Qg = Q + (size_t)bh * S * 64;
+
+    // ---- stage K (swizzled) and Vt (padded), zero the padding ----
+    for (int idx = tid; idx < S_pad * 8; idx += 256) {
+        const int r = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < S) v = *(const uint4*)(Kg + (size_t)r * 64 + c * 8);
+        *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = v;
+    }
+    const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
+    for (int idx = tid; idx < 64 * vchunks; idx += 256) {
+        const int d = idx / vchunks, c = idx - d * vchunks;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c * 8 < S) v = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
+        *(uint4*)(Vs + d * vstride + c * 16) = v;
+    }
+    __syncthreads();
+
+    const int nqt = (S + 15) >> 4;
+    const int nkb = (S_pad + 63) >> 6;
+    const int Dm = heads * 64;
+    for (int qt = blockIdx.y * 4 + w; qt < nqt; qt += 4 * qsplit) {
+        const int q0 = qt * 16;
+        int qr = q0 + li;
+        qr = qr < S ? qr : S - 1;
+        f16x8 qf[2];
+        qf[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
+        qf[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mrun = -INFINITY, lrun = 0.f;
+
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int key0 = kb * 64;
+            const int nkt = (S_pad - key0) >= 64 ? 4 : 2;  // S_pad % 32 == 0
+            f32x4 sc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kt < nkt) {
+                    const int key = key0 + kt * 16 + li;
+                    const char* kr = Ks + key * 128;
+                    const f16x8 k0 = *(const f16x8*)(kr + (((0 + g) ^ (key & 7)) << 4));
+                    const f16x8 k1 = *(const f16x8*)(kr + (((4 + g) ^ (key & 7)) << 4));
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], sc[kt], 0, 0, 0);
+                }
+            }
+            // mask padded keys, block max
+            float bmax = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kt * 16 + 4 * g + r;
+                    float v = (kt < nkt && key < S) ? sc[kt][r] : -INFINITY;
+                    sc[kt][r] = v;
+                    bmax = fmaxf(bmax, v);
+                }
+            }
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            const float mnew = fmaxf(mrun, bmax);
+            const float alpha = exp2f((mrun - mnew) * kScaleLog2e);
+            mrun = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = exp2f((sc[kt][r] - mnew) * kScaleLog2e);
+                    sc[kt][r] = pv;
+                    psum += pv;
+                }
+            lrun = lrun * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
+            // O^T += Vt . P^T, two 32-key steps
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (2 * s2 < nkt) {
+                    f16x8 pf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pf[r] = (f16)sc[2 * s2][r];
+                        pf[4 + r] = (f16)sc[2 * s2 + 1][r];
+                    }
+                    const int kcol = (key0 + 32 * s2 + 4 * g) * 2;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const char* vr = Vs + (dt * 16 + li) * vstride + kcol;
+                        union { f16x8 v8; f16x4 v4[2]; } vf;
+                        vf.v4[0] = *(const f16x4*)(vr);
+                        vf.v4[1] = *(const f16x4*)(vr + 32);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v8, pf, o[dt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        float lt = lrun + __shfl_xor(lrun, 16, 64);
+        lt = lt + __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        if (q0 + li < S) {
+            f16* orow = O + ((size_t)nb * S + q0 + li) * Dm + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (f16)(o[dt][r] * inv);
+                *(f16x4*)(orow + dt * 16 + 4 * g) = h;
+            }
+        }
+    }
+}
+
+// block = D/4 threads: thread -> (head = tid / 16, d = 4 * (tid % 16)); one block per (b, p)
+__global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ kv,
+                                                            f16* __restrict__ O, int P, int D, int Tq, int t0, int Tmax) {
+    const int bp = blockIdx.x;
+    const int b = bp / P, p = bp - b * P;
+    const int c = threadIdx.x * 4;
+    const int Tk = t0 + Tq;
+    float kf[8][4], vf[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < Tk) {
+            const f16* base = kv + (((size_t)b * Tmax + t) * P + p) * 2 * D;
+            const f16x4 k4 = *(const f16x4*)(base + c);
+            const f16x4 v4 = *(const f16x4*)(base + D + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                kf[t][e] = (float)k4[e];
+                vf[t][e] = (float)v4[e];
+            }
+        }
+    }
+    for (int tl = 0; tl < Tq; ++tl) {
+        const int tq = t0 + tl;
+        const size_t row = ((size_t)b * Tq + tl) * P + p;
+        const f16x4 q4 = *(const f16x4*)(q + row * D + c);
+        float qf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qf[e] = (float)q4[e];
+        float s[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            s[t] = -INFINITY;
+            if (t <= tq) {  // causal (model/attention.py:62-64), wave-uniform
+                float d = (qf[0] * kf[t][0] + qf[1] * kf[t][1]) + (qf[2] * kf[t][2] + qf[3] * kf[t][3]);
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                d += __shfl_xor(d, 8, 64);
+                s[t] = d * 0.125f;
+                mx = fmaxf(mx, s[t]);
+            }
+        }
+        float den = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t <= tq) {
+                const float pr = expf(s[t] - mx);
+                den += pr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += pr * vf[t][e];
+            }
+        }
+        const float inv = 1.0f / den;
+        f16x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = (f16)(acc[e] * inv);
+        *(f16x4*)(O + row * D + c) = o4;
+    }
+}
+
+}  // namespace
+
+static bool g_attn_attr_set = false;
+
+int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream) {
+    GTAV_REQUIRE(S > 0 && S % 8 == 0, "attn_spatial: S=%d must be a positive multiple of 8", S);
+    const int S_pad = round_up(S, 32);
+    const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
+    GTAV_REQUIRE(lds <= 160 * 1024, "attn_spatial: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
+    if (!g_attn_attr_set) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        g_attn_attr_set = true;
+    }
+    const int nqt = cdiv(S, 16);
+    // enough blocks to fill 256 CUs when there are few (frame, head) pairs; each block re-stages K/Vt from L2
+    int qsplit = 1;
+    const int max_split = cdiv(nqt, 4);
+    while (NB * heads * qsplit < 512 && qsplit < max_split) ++qsplit;
+    dim3 grid(NB * heads, qsplit), block(256);
+    hipLaunchKernelGGL(attn_spatial_kernel, grid, block, lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax,
+                         hipStream_t stream) {
+    GTAV_REQUIRE(D % 256 == 0 && D <= 2048, "attn_temporal: D=%d must be a multiple of 256 and <= 2048", D);
+    GTAV_REQUIRE(Tq > 0 && t0 >= 0 && t0 + Tq <= Tmax && Tmax <= 8, "attn_temporal: window t0=%d Tq=%d Tmax=%d (max 8)", t0, Tq, Tmax);
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gtav

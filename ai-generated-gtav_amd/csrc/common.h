@@ -1,0 +1,69 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of gtav_amd.
+// Wavefront = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace gtav {
+
+typedef _Float16 f16;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing (C-ABI functions never throw; they return an int and set this string) ----
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define GTAV_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            gtav::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+#define GTAV_REQUIRE(cond, ...)                                                           \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            gtav::set_error(__VA_ARGS__);                                                 \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- small device math ------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// GELU(approximate="tanh") as torch computes it: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1); exact at both tails, no fast-math
+    float e = __expf(2.0f * u);
+    float th = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + th);
+}
+
+// exact (erf) GELU: 0.5 x (1 + erf(x / sqrt(2)))
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace gtav

@@ -1,0 +1,272 @@
+// fp16 MFMA GEMM for gfx950 with fused epilogues (see gemm.h).
+//
+// Tile: 128 features (W rows) x 128 tokens (X rows) x 64 K per step, 256 threads = 4 waves (2 x 2),
+// each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_f16.  Both operands are K-contiguous, so both
+// tiles are staged with 16-byte direct-to-LDS loads (global_load_lds_dwordx4, 1 KiB = 8 rows per
+// wave-instruction).  The LDS image is lane-linear; the bank-conflict swizzle (16-B chunk ^= row & 7)
+// is applied to the per-lane SOURCE address and to the ds_read_b128 address (same involution).
+//
+// Orientation: the MFMA "A" operand is the W tile and "B" the X tile, so D[row = feature][col = token]:
+// every lane owns 4 CONSECUTIVE FEATURES of one token -> RoPE pairs, float4 bias/gate/residual and
+// packed fp16x4 stores are lane-local.  Blocks that produce V for the spatial/VAE attention swap the
+// operands (D[row = token][col = feature]) so that V is written already transposed (Vt[d][s]), which
+// is the layout the PV product wants as its MFMA A operand.
+#include "gemm.h"
+
+namespace gtav {
+
+namespace {
+
+constexpr int TN = 128, TM = 128, TK = 64;
+constexpr int TILE_BYTES = 128 * TK * 2;  // 16 KiB per operand tile
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    union { f16x4 h; uint2 u; } cv;
+    cv.h = f16x4{(f16)a, (f16)b, (f16)c, (f16)d};
+    return cv.u;
+}
+
+template <bool TR>
+__device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0, int m0, f32x4 (&acc)[4][4]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w >> 1, wm = w & 1;
+    const int nk = p.K / TK;
+
+    // ---- staging: wave w issues instructions q = 4w .. 4w+3 of each 16-instruction tile ----
+    const int srow = lane >> 3, sc = lane & 7;
+    const int gc = sc ^ srow;  // source chunk for the linear LDS slot (row & 7 == srow)
+    const char* wsrc[4];
+    const char* xsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * (4 * w + i) + srow;
+        wsrc[i] = (const char*)(p.W + (size_t)(n0 + r) * p.K + gc * 8);
+        int xr = m0 + r;
+        xr = xr < p.M ? xr : p.M - 1;  // ragged last M tile: clamp (results are masked in the epilogue)
+        xsrc[i] = (const char*)(p.X + (size_t)xr * p.ldx + gc * 8);
+    }
+    auto stage = [&](int buf, int t) {
+        char* base = smem + buf * 2 * TILE_BYTES + (4 * w) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(wsrc[i] + (size_t)t * (TK * 2), base + i * 1024);
+            glds16(xsrc[i] + (size_t)t * (TK * 2), base + TILE_BYTES + i * 1024);
+        }
+    };
+
+    // ---- fragment read offsets ----
+    const int li = lane & 15, g = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = (64 * wn + li) * 128 + ch;
+        xoff[s] = TILE_BYTES + (64 * wm + li) * 128 + ch;
+    }
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) stage(cur ^ 1, t + 1);
+        const char* b = smem + cur * 2 * TILE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 wf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+                xf[i] = *(const f16x8*)(b + xoff[s] + i * 16 * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (TR)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[j], wf[i], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tiles_m = (p.M + TM - 1) / TM;
+
+    // XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous
+    // run of tiles, m fastest, so neighbours on one L2 stream the same W panel.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int tile_n = swz / tiles_m, tile_m = swz - tile_n * tiles_m;
+    const int n0 = tile_n * TN, m0 = tile_m * TM;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bool tr = false;
+    if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+    if constexpr (EPI == EPI_QKV) {
+        if (tr) mainloop<true>(p, smem, n0, m0, acc);
+        else mainloop<false>(p, smem, n0, m0, acc);
+    } else {
+        mainloop<false>(p, smem, n0, m0, acc);
+    }
+
+    // ------------------------------------ epilogue ------------------------------------
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wn = w >> 1, wm = w & 1, li = lane & 15, g = lane >> 4;
+
+    if constexpr (EPI == EPI_QKV) {
+        if (tr) {
+            // D[row = token][col = feature]: lane owns tokens m..m+3 of feature n (V part, spatial mode)
+            const int heads = p.D >> 6;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + 64 * wn + 16 * i + li;
+                const int nn = n - 2 * p.D;
+                const float bv = p.bias ? p.bias[n] : 0.f;
+                const int head = nn >> 6, d = nn & 63;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + 64 * wm + 16 * j + 4 * g;
+                    if (m >= p.M) continue;
+                    const int nb = m / p.S, s = m - nb * p.S;
+                    f16* dst = p.v + ((size_t)(nb * heads + head) * 64 + d) * p.S + s;
+                    const f32x4 a = acc[i][j];
+                    *(uint2*)dst = pack4(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+                }
+            }
+            return;
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + 64 * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
+        if (n >= p.N) continue;
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 64 * wm + 16 * j + li;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if constexpr (EPI == EPI_F32) {
+                *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
+            } else if constexpr (EPI == EPI_F16) {
+                *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
+            } else if constexpr (EPI == EPI_GELU_TANH) {
+                *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) =
+                    pack4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+            } else if constexpr (EPI == EPI_GELU_ERF) {
+                *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) =
+                    pack4(gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
+            } else if constexpr (EPI == EPI_RESID) {
+                float* dst = (float*)p.out + (size_t)m * p.ldo + n;
+                f32x4 x = *(const f32x4*)dst;
+                if (p.gate) {
+                    int row = m / p.rows_per_gate;
+                    if (p.gate_rows) row = p.gate_rows[row];
+                    const f32x4 gt = *(const f32x4*)(p.gate + (size_t)row * p.gate_stride + n);
+                    x = x + gt * v;
+                } else {
+                    x = x + v;
+                }
+                *(f32x4*)dst = x;
+            } else if constexpr (EPI == EPI_QKV) {
+                const int which = n / p.D, nn = n - which * p.D;
+                const int head = nn >> 6, d = nn & 63;
+                int pos, b = 0, tfr = 0, pp = 0, nb = 0, s = 0;
+                if (p.qkv_mode == QKV_SPATIAL) {
+                    nb = m / p.S;
+                    s = m - nb * p.S;
+                    pos = s;
+                } else {
+                    const int fr = m / p.S;  // frame counter over (b, tl)
+                    pp = m - fr * p.S;
+                    b = fr / p.Tq;
+                    tfr = p.t0 + (fr - b * p.Tq);
+                    pos = tfr;
+                }
+                if (which < 2) {
+                    const f32x4 c = *(const f32x4*)(p.rope_cos + pos * 64 + d);
+                    const f32x4 sn = *(const f32x4*)(p.rope_sin + pos * 64 + d);
+                    f32x4 r;
+                    r[0] = v[0] * c[0] - v[1] * sn[0];
+                    r[1] = v[1] * c[1] + v[0] * sn[1];
+                    r[2] = v[2] * c[2] - v[3] * sn[2];
+                    r[3] = v[3] * c[3] + v[2] * sn[3];
+                    v = r;
+                }
+                const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
+                if (p.qkv_mode == QKV_SPATIAL) {
+                    const int heads = p.D >> 6;
+                    f16* base = which == 0 ? p.q : p.k;
+                    *(uint2*)(base + ((size_t)(nb * heads + head) * p.S + s) * 64 + d) = pk;
+                } else {
+                    if (which == 0) {
+                        *(uint2*)(p.q + (size_t)m * p.D + nn) = pk;
+                    } else {
+                        const size_t tok = ((size_t)b * p.Tmax + tfr) * p.S + pp;
+                        f16* base = p.k + tok * 2 * p.D + (which == 2 ? p.D : 0);
+                        *(uint2*)(base + nn) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
+    GTAV_REQUIRE(p.K > 0 && p.K % TK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, TK);
+    GTAV_REQUIRE(p.M > 0 && p.N > 0 && p.N % 4 == 0, "gemm: bad M=%d N=%d", p.M, p.N);
+    GTAV_REQUIRE(p.ldx >= p.K && p.ldx % 8 == 0, "gemm: ldx=%d must be >= K and a multiple of 8", p.ldx);
+    GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    if (epi == EPI_QKV) {
+        GTAV_REQUIRE(p.N == 3 * p.D && p.D % 128 == 0, "gemm/qkv: N=%d must equal 3*D, D=%d %% 128 == 0", p.N, p.D);
+        GTAV_REQUIRE(p.S > 0 && p.q && p.k && p.rope_cos && p.rope_sin, "gemm/qkv: missing buffers");
+        if (p.qkv_mode == QKV_SPATIAL) {
+            GTAV_REQUIRE(p.S % 4 == 0 && p.M % p.S == 0 && p.v, "gemm/qkv spatial: S=%d must divide M=%d, S %% 4 == 0", p.S, p.M);
+        } else {
+            GTAV_REQUIRE(p.Tq > 0 && p.M % (p.S * p.Tq) == 0 && p.t0 + p.Tq <= p.Tmax, "gemm/qkv temporal: bad frame geometry");
+        }
+    } else {
+        GTAV_REQUIRE(p.out && p.ldo >= p.N && p.ldo % 4 == 0, "gemm: bad output ldo=%d", p.ldo);
+        if (epi == EPI_RESID && p.gate) GTAV_REQUIRE(p.rows_per_gate > 0, "gemm/resid: rows_per_gate");
+    }
+    const int tiles = cdiv(p.M, TM) * cdiv(p.N, TN);
+    dim3 grid(tiles), block(256);
+    switch (epi) {
+        case EPI_F32: hipLaunchKernelGGL(gemm_kernel<EPI_F32>, grid, block, 0, stream, p); break;
+        case EPI_F16: hipLaunchKernelGGL(gemm_kernel<EPI_F16>, grid, block, 0, stream, p); break;
+        case EPI_GELU_TANH: hipLaunchKernelGGL(gemm_kernel<EPI_GELU_TANH>, grid, block, 0, stream, p); break;
+        case EPI_GELU_ERF: hipLaunchKernelGGL(gemm_kernel<EPI_GELU_ERF>, grid, block, 0, stream, p); break;
+        case EPI_RESID: hipLaunchKernelGGL(gemm_kernel<EPI_RESID>, grid, block, 0, stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL(gemm_kernel<EPI_QKV>, grid, block, 0, stream, p); break;
+        default: GTAV_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+    }
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gtav

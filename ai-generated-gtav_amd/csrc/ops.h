@@ -1,0 +1,84 @@
+// Launchers of the non-GEMM kernels (all enqueue on `stream`, return 0 on success, never sync).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace gtav {
+
+// ---- skinny.hip --------------------------------------------------------------------------
+int launch_skinny_f32(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M, int N,
+                      int K, int act_silu, hipStream_t stream);
+int skinny_init();  // raises the dynamic-LDS limit of the skinny kernels (call once per process)
+
+// ---- elementwise.hip ---------------------------------------------------------------------
+// LayerNorm(eps=1e-6, no affine) + adaLN modulate -> fp16  (model/dit.py:19-27,163-181)
+//   out[m] = LN(x[m]) * (1 + (scale[row] + 1e-6)) + shift[row],  row = rows ? rows[m / rows_per_mod] : m / rows_per_mod
+int launch_ln_modulate(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
+                       int mod_stride, const int* rows, int rows_per_mod, hipStream_t stream);
+// LayerNorm(eps=1e-6) with affine weight/bias -> fp16   (model/vae.py:139,146,174)
+int launch_ln_affine(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
+                     hipStream_t stream);
+
+// Non-overlapping patch gather (im2col of a k = s = p conv):  img (NB, C, H, W) f32 with strides -> A [M][ldo] fp16,
+// token m = (nb, gh, gw), column k = (c, ph, pw); value = a * img + b.  Columns [C p p, ldo) are zeroed.
+// `frame_index` (optional, length NB) picks frame f = frame_index[nb] out of the source buffer (frame stride =
+// C*H*W floats), which is how the sampler reads its sliding window in place.
+int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo,
+                    float a, float b, hipStream_t stream);
+// Inverse scatter of the projection output.  order 0: features (ph, pw, c) (DiT, model/dit.py:328-341);
+// order 1: features (c, ph, pw) (VAE, model/vae.py:279-304).  out (NB, C, H, W) f32 = a * y + b.
+int launch_unpatchify(const float* y, int ldy, float* img, int NB, int C, int H, int W, int p, int order, float a,
+                      float b, hipStream_t stream);
+
+// fp32 -> fp16 with zero padding: src [R][C] (ld = lds) -> dst [Rp][Cp]
+int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, hipStream_t stream);
+// inverse of the above without padding (state_dict round trip): dst[r][c] = (float)src[r][c]
+int launch_unpad_f16_to_f32(const f16* src, int lds, int R, int C, float* dst, hipStream_t stream);
+int launch_copy_f32_strided(const float* src, int lds, int R, int C, float* dst, int ldd, hipStream_t stream);
+int launch_copy_rows_f32(const float* src, size_t src_stride, float* dst, size_t dst_stride, int rows, size_t n, hipStream_t stream);
+// buf[m][c] = clamp(buf[m][c], lo, hi) for c in [c0, c1)
+int launch_clamp_cols(float* buf, int M, int ld, int c0, int c1, float lo, float hi, hipStream_t stream);
+// idx[b * Tq + tl] = b * F + first + tl
+int launch_frame_index(int* idx, int B, int Tq, int F, int first, hipStream_t stream);
+int launch_frames_to_u8(const float* img, uint8_t* out, int N, int H, int W, hipStream_t stream);
+int launch_moments_to_latents(const float* mom, float* lat, int N, int hw, int latent, int mom_ch, float scale, hipStream_t stream);
+int launch_latents_to_tokens(const float* lat, float* z, int N, int hw, int latent, hipStream_t stream);
+// fp32 strided copy with padding (used to build concatenated fp32 weights): dst[r][c0 + c] = src[r][c]
+int launch_copy_f32(const float* src, int lds, int R, int C, float* dst, int ldd, int c0, hipStream_t stream);
+int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
+int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
+
+// Conditioning inputs (model/dit.py:96-118,359-364) for `rows` (b, frame) pairs, row r = (r / Tq, r % Tq):
+//   E[r][0:256] = sincos_table[t_r],  t_r = t64 ? t64[r] : (r % Tq == Tq - 1 ? t_cur : t_ctx)   (train_dit.py:64-91)
+//   HC[r][D : D+Apad] = actions[(r / Tq) * act_outer + (r % Tq) * act_inner + 0:A]  (zeros when actions == nullptr)
+int launch_cond_inputs(const int64_t* t64, int rows, int Tq, int t_ctx, int t_cur, const float* sincos /*[1000][256]*/,
+                       float* E, const float* actions, int64_t act_outer, int64_t act_inner, int A, float* HC, int ldhc,
+                       int D, int Apad, int* err_flag, hipStream_t stream);
+
+// DDIM-style v-prediction update of the newest frame (train_dit.py:110-125), per sample b:
+//   x0 = sqrt(a_t) x - sqrt(1 - a_t) v;  eps = (sqrt(1/a_t) x - x0) / sqrt(1/a_t - 1);
+//   out = final ? x0 : sqrt(a_n) x0 + sqrt(1 - a_n) eps
+// x, v, out: n elements per sample with given sample strides (floats).
+int launch_ddim_update(const float* x, size_t x_stride, const float* v, size_t v_stride, float* out, size_t out_stride,
+                       int B, int n, const float* alpha_t, const float* alpha_next, float alpha_t_s, float alpha_next_s,
+                       int is_final, hipStream_t stream);  // per-row device alphas, or the two scalars when alpha_t == nullptr
+
+// Training-side noising, v-target and squared-error partial sums (train_dit.py:621-650).
+int launch_add_noise(const float* x, const float* noise, const float* alpha /*[rows]*/, float* out, int rows, int n,
+                     float clamp_abs, hipStream_t stream);
+int launch_vtarget(const float* x, const float* noise, const float* alpha /*[rows]*/, float* vt, int rows, int n,
+                   float clamp_abs, hipStream_t stream);
+int launch_mse(const float* a, size_t a_stride, const float* b, size_t b_stride, int rows, int n, float* out_scalar,
+               hipStream_t stream);
+
+// ---- attention.hip -----------------------------------------------------------------------
+// Full (non-causal) attention over S tokens per (nb, head), head_dim 64 (model/attention.py:127-129, model/vae.py:101).
+// Q,K [nb][heads][S][64], Vt [nb][heads][64][S] fp16 (layouts written by the QKV GEMM epilogue);
+// O [nb*S][heads*64] fp16 token-major.
+int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream);
+// Causal attention over the frames of a window per (b, p, head) (model/attention.py:62-64).
+// q [B*Tq*P][D] for frames t0 .. t0+Tq-1; kv cache [B][Tmax][P][2][D]; O like q.
+int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax,
+                         hipStream_t stream);
+
+}  // namespace gtav

@@ -1,0 +1,93 @@
+"""Batch-generic generation harness (reference generate.py:50-66,186-244): VAE-encode the prompt frames,
+autoregressive denoising with a sliding window, VAE-decode.  The per-frame initial noise is an input
+(CPU-generated, so CPU-oracle and GPU runs see identical noise) and the batch can be sharded across
+ranks (one process per GPU) with a final all-gather of the latents."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+from .utils import alphas_cumprod as _alphas_cumprod
+
+SCALING_FACTOR = 0.07843137255  # generate.py:50
+
+
+@torch.inference_mode()
+def vae_encode(x: torch.Tensor, vae, n_prompt_frames: int, scaling_factor: float = SCALING_FACTOR) -> torch.Tensor:
+    """generate.py:50-66: frames (B,t,3,H,W) in [0,1] -> latents (B,t,C,h,w) = vae.encode(2x-1).mean * s."""
+    B, t = x.shape[:2]
+    H, W = x.shape[-2:]
+    mom = vae.encode_moments(x.reshape(B * t, *x.shape[2:]), 2.0, -1.0)
+    N, hw, mom_ch = mom.shape
+    lat = torch.empty((N, vae.latent_dim, hw), device=mom.device, dtype=torch.float32)
+    with torch.cuda.device(mom.device):
+        _lib.check(_lib.load().gtav_moments_to_latents(mom.data_ptr(), lat.data_ptr(), N, hw, vae.latent_dim, mom_ch,
+                                                       scaling_factor, _lib.current_stream()))
+    return lat.reshape(B, t, vae.latent_dim, H // vae.patch_size, W // vae.patch_size)
+
+
+@torch.inference_mode()
+def vae_decode_frames(x: torch.Tensor, vae, scaling_factor: float = SCALING_FACTOR, to_uint8: bool = True) -> torch.Tensor:
+    """generate.py:238-244: latents (B,t,C,h,w) -> uint8 frames (B,t,H,W,3) (or float (B,t,3,H,W) in [0,1]-ish)."""
+    B, t, Cc, h, w = x.shape
+    xd = x.to(vae.device, torch.float32).contiguous()
+    z = torch.empty((B * t, h * w, Cc), device=xd.device, dtype=torch.float32)
+    L = _lib.load()
+    with torch.cuda.device(xd.device):
+        _lib.check(L.gtav_latents_to_tokens(xd.data_ptr(), z.data_ptr(), B * t, h * w, Cc, _lib.current_stream()))
+    img = vae.decode(z, 1.0 / scaling_factor, 0.5, 0.5)          # (decode(x / s) + 1) / 2
+    if not to_uint8:
+        return img.reshape(B, t, 3, vae.input_height, vae.input_width)
+    out = torch.empty((B * t, vae.input_height, vae.input_width, 3), device=img.device, dtype=torch.uint8)
+    with torch.cuda.device(img.device):
+        _lib.check(L.gtav_frames_to_u8(img.data_ptr(), out.data_ptr(), B * t, vae.input_height, vae.input_width,
+                                       _lib.current_stream()))
+    return out.reshape(B, t, vae.input_height, vae.input_width, 3)
+
+
+@torch.inference_mode()
+def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_steps: int, noise_chunks: torch.Tensor,
+                     actions: Optional[torch.Tensor] = None, stabilization_level: int = 15, noise_abs_max: float = 20.0,
+                     clamp_min: float = 1e-4, ctx_cache: bool = False) -> torch.Tensor:
+    """generate.py:186-220.  x_prompt (B, n_prompt, C, h, w) latents; noise_chunks (B, total-n_prompt, C, h, w)
+    standard-normal draws (clamped to +-noise_abs_max here, generate.py:201-202); actions (B, total, 25) or None.
+    ctx_cache=False re-runs the whole window on every noise step exactly like the reference;
+    ctx_cache=True runs the window once per generated frame and then only the frame being denoised,
+    taking the context K/V of the temporal layers from the cache (same result, ~4.8x less work).
+    Returns latents (B, total_frames, C, h, w) on the model's device."""
+    dev = model.device
+    B, n_prompt = x_prompt.shape[:2]
+    x = torch.empty((B, total_frames, *x_prompt.shape[2:]), device=dev, dtype=torch.float32)
+    x[:, :n_prompt] = x_prompt.to(dev, torch.float32)
+    x[:, n_prompt:] = noise_chunks.to(dev, torch.float32).clamp(-noise_abs_max, noise_abs_max)
+    act = actions.to(dev, torch.float32).contiguous() if actions is not None else None
+    model.set_schedule(_alphas_cumprod(clamp_min))
+    noise_range = torch.linspace(0, 999, noise_steps + 1)                      # generate.py:194 (float)
+    t_of = [int(v) for v in noise_range]                                       # long() truncation (train_dit.py:70)
+    for i in range(n_prompt, total_frames):
+        start = max(0, i + 1 - model.max_frames)                              # generate.py:204
+        for noise_idx in reversed(range(0, noise_steps + 1)):
+            cached = ctx_cache and noise_idx != noise_steps
+            model.denoise_step_(x, start, i, stabilization_level, t_of[noise_idx], t_of[max(0, noise_idx - 1)],
+                                noise_idx <= 0, act, cached=cached)
+    model.check()
+    return x
+
+
+def shard_batch(B: int, rank: int, world: int):
+    """Contiguous batch shard of rank `rank`: samples [lo, hi). Requires B % world == 0."""
+    assert B % world == 0, f"global batch {B} must be divisible by world size {world}"
+    per = B // world
+    return rank * per, (rank + 1) * per
+
+
+def all_gather_latents(x_local: torch.Tensor) -> torch.Tensor:
+    """One all-gather (RCCL over xGMI when the backend is nccl) of the per-rank latents along the batch dim."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x_local
+    out = torch.empty((dist.get_world_size() * x_local.shape[0], *x_local.shape[1:]), device=x_local.device, dtype=x_local.dtype)
+    dist.all_gather_into_tensor(out, x_local.contiguous())
+    return out

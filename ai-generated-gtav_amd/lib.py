@@ -1,0 +1,116 @@
+"""ctypes binding of libgtav_amd.so (the C-ABI declared in include/gtav_amd.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, import of this module
+raises.  `build()` compiles it in-tree with hipcc for gfx950 (a GPU is not needed to build).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgtav_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gtav_amd.h")
+
+
+class GtavError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip into libgtav_amd.so (hipcc --offload-arch=gfx950). Returns the library path."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [HEADER_PATH]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+            return LIB_PATH
+    subprocess.run(["bash", os.path.join(src_dir, "build.sh")], check=True)
+    return LIB_PATH
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_h", "input_w", "patch_size", "in_channels", "hidden_size", "depth", "num_heads")] + [
+        ("mlp_ratio", C.c_float), ("external_cond_dim", C.c_int32), ("max_frames", C.c_int32), ("max_batch", C.c_int32),
+        ("max_cond_rows", C.c_int32)]
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("latent_dim", "input_height", "input_width", "patch_size", "enc_dim", "enc_depth",
+                                          "enc_heads", "dec_dim", "dec_depth", "dec_heads")] + [
+        ("mlp_ratio", C.c_float), ("use_variational", C.c_int32), ("max_frames_per_call", C.c_int32)]
+
+
+_p, _i, _f, _l = C.c_void_p, C.c_int32, C.c_float, C.c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "gtav_last_error": [],
+    "gtav_abi_version": [],
+    "gtav_dit_create": [C.POINTER(DitConfig), C.POINTER(_p)],
+    "gtav_dit_destroy": [_p],
+    "gtav_dit_set_weight": [_p, C.c_char_p, _p, _l, _p],
+    "gtav_dit_finalize": [_p, _p],
+    "gtav_dit_get_weight": [_p, C.c_char_p, _p, _l, _p],
+    "gtav_dit_forward": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "gtav_dit_set_schedule": [_p, C.POINTER(C.c_float), _i],
+    "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
+    "gtav_dit_check": [_p, _p],
+    "gtav_vae_create": [C.POINTER(VaeConfig), C.POINTER(_p)],
+    "gtav_vae_destroy": [_p],
+    "gtav_vae_set_weight": [_p, C.c_char_p, _p, _l, _p],
+    "gtav_vae_finalize": [_p, _p],
+    "gtav_vae_get_weight": [_p, C.c_char_p, _p, _l, _p],
+    "gtav_vae_encode": [_p, _p, _f, _f, _p, _i, _p],
+    "gtav_vae_decode": [_p, _p, _f, _p, _f, _f, _i, _p],
+    "gtav_ddim_update": [_p, _p, _p, _i, _i, _p, _p, _i, _p],
+    "gtav_add_noise": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "gtav_vtarget": [_p, _p, _p, _p, _i, _i, _f, _p],
+    "gtav_mse": [_p, _l, _p, _l, _i, _i, _p, _p],
+    "gtav_frames_to_u8": [_p, _p, _i, _i, _i, _p],
+    "gtav_moments_to_latents": [_p, _p, _i, _i, _i, _i, _f, _p],
+    "gtav_latents_to_tokens": [_p, _p, _i, _i, _i, _p],
+    "gtav_op_gemm_f16": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
+    "gtav_op_gemm_qkv": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "gtav_op_skinny_f32": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "gtav_op_ln_modulate": [_p, _p, _i, _i, _p, _p, _i, _i, _p],
+    "gtav_op_ln_affine": [_p, _p, _i, _i, _p, _p, _p],
+    "gtav_op_attn_spatial": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "gtav_op_attn_temporal": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _p],
+}
+_RESTYPES = {"gtav_last_error": C.c_char_p, "gtav_dit_destroy": None, "gtav_vae_destroy": None}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the shared library (once) and binds every symbol of SIGNATURES; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GtavError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"(hipcc --offload-arch=gfx950). gtav_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise GtavError(load().gtav_last_error().decode() or f"gtav_amd call failed with code {rc}")
+
+
+def ptr(t) -> int:
+    """Device/host address of a torch tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

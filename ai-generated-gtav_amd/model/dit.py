@@ -1,0 +1,284 @@
+"""Drop-in mirror of the reference `model/dit.py` public surface (model/dit.py:228-392): `DiT`,
+`DiT_S_2`, `DiT_models` — same constructor signature, `forward(x, t, external_cond)` call shape,
+`max_frames` / `patch_size` attributes and state-dict names — with every FLOP executed by the HIP
+kernels of libgtav_amd.so through the C-ABI (`gtav_dit_*`, include/gtav_amd.h).  torch is used for
+storage (device tensors, the fp32 master copy of the weights) and host-side constant tables only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, Iterator, Optional
+
+import torch
+
+from .. import lib as _lib
+from .. import weights as _w
+
+
+def _rope_tables_axial(freqs: torch.Tensor, gh: int, gw: int):
+    """cos/sin tables (gh*gw, 64) of `RotaryEmbedding.get_axial_freqs(gh, gw)` for pixel freqs
+    (model/rotary_embedding_torch.py:290-345), identity beyond the rotated dims."""
+    def ang(n):
+        a = torch.linspace(-1, 1, steps=n)[:, None] * freqs[None, :]
+        return a.repeat_interleave(2, dim=-1)
+    ah, aw = ang(gh), ang(gw)
+    a = torch.cat([ah[:, None, :].expand(gh, gw, -1), aw[None, :, :].expand(gh, gw, -1)], dim=-1).reshape(gh * gw, -1)
+    cos, sin = torch.ones(gh * gw, 64), torch.zeros(gh * gw, 64)
+    cos[:, : a.shape[1]] = a.cos()
+    sin[:, : a.shape[1]] = a.sin()
+    return cos.contiguous(), sin.contiguous()
+
+
+def _rope_tables_temporal(freqs: torch.Tensor, T: int):
+    """`rotate_queries_or_keys` angles for positions 0..T-1 (rotary_embedding_torch.py:186-209)."""
+    a = (torch.arange(T, dtype=torch.float32)[:, None] * freqs[None, :]).repeat_interleave(2, dim=-1)
+    return a.cos().contiguous(), a.sin().contiguous()
+
+
+def _timestep_table() -> torch.Tensor:
+    """TimestepEmbedder.timestep_embedding for every t in [0, 999] (model/dit.py:96-118): (1000, 256)."""
+    half = 128
+    freqs = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = torch.arange(1000, dtype=torch.float32)[:, None] * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1).contiguous()
+
+
+class _HipModule:
+    """Shared plumbing of DiT / AutoencoderKL: fp32 master weights on the host, a C-ABI handle on the GPU."""
+
+    _prefix = ""  # gtav_dit / gtav_vae
+
+    def __init__(self):
+        self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._handle = C.c_void_p(None)
+        self._dirty = True
+        self.training = False
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda")
+
+    # --- nn.Module-like surface the reference callers use (SURVEY.md §8(b) "Attributes read") ---
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def to(self, *args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, (str, torch.device)) and torch.device(a).type == "cuda":
+                self.device = torch.device(a)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    def parameters(self) -> Iterator[torch.Tensor]:
+        return iter(self._sd.values())
+
+    def named_parameters(self):
+        return iter(self._sd.items())
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        sd = OrderedDict(self._sd)
+        sd.update(self._extra_state())
+        return sd
+
+    def _extra_state(self) -> Dict[str, torch.Tensor]:
+        return {}
+
+    def _shapes(self):
+        raise NotImplementedError
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        params, sf, tf = _w.split_freq_keys(dict(sd))
+        shapes = self._shapes()
+        missing = [k for k in shapes if k not in params]
+        unexpected = [k for k in params if k not in shapes]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing keys {missing[:5]}..., unexpected keys {unexpected[:5]}...")
+        for k, shp in shapes.items():
+            if k in params:
+                v = params[k].detach().to("cpu", torch.float32).contiguous()
+                if tuple(v.shape) != tuple(shp):
+                    raise RuntimeError(f"load_state_dict: {k} has shape {tuple(v.shape)}, expected {tuple(shp)}")
+                self._sd[k] = v
+        self._load_freqs(sf, tf)
+        self._dirty = True
+        return missing, unexpected
+
+    def _load_freqs(self, sf, tf):
+        pass
+
+    def _free(self):
+        if self._handle:
+            getattr(_lib.load(), self._prefix + "_destroy")(self._handle)
+            self._handle = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    def _upload(self, extra: Dict[str, torch.Tensor]):
+        L = _lib.load()
+        setw = getattr(L, self._prefix + "_set_weight")
+        stream = _lib.current_stream()
+        with torch.cuda.device(self.device):
+            for name, v in list(self._sd.items()) + list(extra.items()):
+                d = v.to(self.device, torch.float32, non_blocking=False).contiguous()
+                _lib.check(setw(self._handle, name.encode(), d.data_ptr(), d.numel(), stream))
+                del d
+            _lib.check(getattr(L, self._prefix + "_finalize")(self._handle, stream))
+            torch.cuda.synchronize()
+        self._dirty = False
+
+
+class DiT(_HipModule):
+    """model/dit.py:228-376.  `max_batch` (keyword-only, not in the reference) pre-sizes the HBM workspace;
+    it grows automatically when a larger batch arrives."""
+
+    _prefix = "gtav_dit"
+
+    def __init__(self, input_h=18, input_w=32, patch_size=2, in_channels=16, hidden_size=1024, depth=12, num_heads=16,
+                 mlp_ratio=4.0, external_cond_dim=25, max_frames=5, *, max_batch=1, init_weights=True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = in_channels
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self._max_frames = max_frames
+        self.input_h, self.input_w, self.hidden_size, self.depth = input_h, input_w, hidden_size, depth
+        self.mlp_ratio, self.external_cond_dim = mlp_ratio, external_cond_dim
+        self._cfg_kwargs = dict(input_h=input_h, input_w=input_w, patch_size=patch_size, in_channels=in_channels,
+                                hidden_size=hidden_size, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                                external_cond_dim=external_cond_dim)
+        self._capacity_b, self._capacity_t = max_batch, max(max_frames, 1)
+        hd = hidden_size // num_heads
+        self._spatial_freqs = _w.rope_freqs_pixel(hd // 2, 256)   # model/dit.py:259-261
+        self._temporal_freqs = _w.rope_freqs_lang(hd)             # model/dit.py:262
+        self._schedule = None
+        if init_weights:
+            self.initialize_weights()
+
+    # `max_frames` is read AND assigned by callers (generate.py:139,204)
+    @property
+    def max_frames(self):
+        return self._max_frames
+
+    @max_frames.setter
+    def max_frames(self, v):
+        self._max_frames = int(v)
+        if v > self._capacity_t:
+            self._capacity_t = int(v)
+            self._free()
+
+    def _shapes(self):
+        return _w.dit_param_shapes(**self._cfg_kwargs)
+
+    def _extra_state(self):
+        # same de-duplicated aliases the reference's own writer keeps (train_dit.py:758-762)
+        return {"spatial_rotary_emb.freqs": self._spatial_freqs, "temporal_rotary_emb.freqs": self._temporal_freqs}
+
+    def _load_freqs(self, sf, tf):
+        if sf is not None:
+            self._spatial_freqs = sf.detach().float().cpu()
+        if tf is not None:
+            self._temporal_freqs = tf.detach().float().cpu()
+
+    def initialize_weights(self):
+        """Distribution-identical restatement of model/dit.py:295-326 (N(0,.02) linears, zero biases,
+        t-MLP std .01, adaLN zeroed, final adaLN std .01, final linear std .001)."""
+        for k, shp in self._shapes().items():
+            if k.endswith(".bias"):
+                v = torch.zeros(shp)
+            elif "adaLN_modulation" in k and k.startswith("blocks."):
+                v = torch.zeros(shp)
+            elif k.startswith("t_embedder.mlp") or k.startswith("final_layer.adaLN_modulation"):
+                v = torch.randn(shp) * 0.01
+            elif k == "final_layer.linear.weight":
+                v = torch.randn(shp) * 0.001
+            else:
+                v = torch.randn(shp) * 0.02
+            self._sd[k] = v
+        self._dirty = True
+
+    # ------------------------------------------------------------------------------------------
+    def _ensure(self, B: int, T: int):
+        if T > self._capacity_t:
+            self._capacity_t = T
+            self._free()
+        if B > self._capacity_b:
+            self._capacity_b = B
+            self._free()
+        if not self._handle:
+            L = _lib.load()
+            cfg = _lib.DitConfig(max_frames=self._capacity_t, max_batch=self._capacity_b,
+                                 max_cond_rows=self._capacity_b * self._capacity_t, **self._cfg_kwargs)
+            with torch.cuda.device(self.device):
+                _lib.check(L.gtav_dit_create(C.byref(cfg), C.byref(self._handle)))
+            self._dirty = True
+        if self._dirty:
+            gh, gw = self.input_h // self.patch_size, self.input_w // self.patch_size
+            sc, ss = _rope_tables_axial(self._spatial_freqs, gh, gw)
+            tc, ts = _rope_tables_temporal(self._temporal_freqs, self._capacity_t)
+            extra = {"tables.timestep_sincos": _timestep_table(), "tables.rope_spatial_cos": sc, "tables.rope_spatial_sin": ss,
+                     "tables.rope_temporal_cos": tc, "tables.rope_temporal_sin": ts}
+            self._upload(extra)
+            if self._schedule is not None:
+                self.set_schedule(self._schedule)
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, external_cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """model/dit.py:343-376.  x (B,T,C,H,W), t (B,T) integer timesteps, external_cond (B,T,25) or None."""
+        B, T, Cc, H, W = x.shape
+        assert H == self.input_h and W == self.input_w, (
+            f"Input image size ({H}*{W}) doesn't match model ({self.input_h}*{self.input_w}).")  # model/dit.py:67-69
+        self._ensure(B, T)
+        dev = self.device
+        xd = x.to(dev, torch.float32).contiguous()
+        td = t.to(dev, torch.int64).contiguous()
+        ad = external_cond.to(dev, torch.float32).contiguous() if torch.is_tensor(external_cond) else None
+        out = torch.empty_like(xd)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().gtav_dit_forward(self._handle, xd.data_ptr(), td.data_ptr(), _lib.ptr(ad), out.data_ptr(),
+                                                    B, T, _lib.current_stream()))
+        return out
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------------------------------
+    # fused sampler entry (train_dit.denoise_step + generate.py:220), used by gtav_amd.generate
+    # ------------------------------------------------------------------------------------------
+    def set_schedule(self, alphas_cumprod: torch.Tensor):
+        ac = alphas_cumprod.detach().reshape(-1).float().cpu().contiguous()
+        assert ac.numel() == 1000
+        self._schedule = ac
+        if self._handle:
+            arr = (C.c_float * 1000).from_buffer_copy(ac.numpy().tobytes())
+            _lib.check(_lib.load().gtav_dit_set_schedule(self._handle, arr, 1000))
+
+    def denoise_step_(self, x: torch.Tensor, start: int, cur: int, t_ctx: int, t_cur: int, t_next: int, is_final: bool,
+                      actions: Optional[torch.Tensor] = None, cached: bool = False, v_out: Optional[torch.Tensor] = None):
+        """In-place fused step on latents x (B, F, C, H, W) fp32 contiguous on the model's device."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        B, F = x.shape[:2]
+        self._ensure(B, cur - start + 1)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_denoise_step(
+                self._handle, x.data_ptr(), B, F, start, cur, int(t_ctx), int(t_cur), int(t_next), int(bool(is_final)),
+                _lib.ptr(actions), 1 if cached else 0, _lib.ptr(v_out), _lib.current_stream()))
+
+    def check(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_check(self._handle, _lib.current_stream()))
+
+
+def DiT_S_2(**kwargs):
+    """model/dit.py:379-389."""
+    return DiT(input_h=18, input_w=32, patch_size=2, hidden_size=1024, depth=16, num_heads=16, max_frames=5, **kwargs)
+
+
+DiT_models = {"DiT-S/2": DiT_S_2}

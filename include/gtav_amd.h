@@ -1,0 +1,162 @@
+/* gtav_amd — C ABI of the MI355X (gfx950) implementation of the AI-Generated-GTAV hot path.
+ *
+ * The reference (ikergarcia1996/AI-Generated-GTAV) has no FFI layer: its boundary for this path is the
+ * Python class API of model/dit.py and model/vae.py plus train_dit.denoise_step.
+ * This header is the C-ABI a binding of that API sits on; each entry point cites the reference
+ * interface it replaces.  `ai-generated-gtav_amd/` holds the ctypes binding that mirrors the
+ * reference classes on top of it; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: every function returns 0 on success and a non-zero code on failure (message via
+ * gtav_last_error()); nothing throws across the ABI.  All pointers named *_dev are device (HBM)
+ * pointers owned by the caller (torch storage); handles own their weights and workspace.  `stream`
+ * is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work; they never
+ * synchronise, allocate or free, so they are hipGraph-capturable.  Handles are not thread-safe.
+ */
+#ifndef GTAV_AMD_H
+#define GTAV_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* gtav_last_error(void);
+/* Library/ABI version; bumped when a signature changes. */
+int gtav_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * DiT  — replaces model/dit.py:228-376 (class DiT) and its sub-modules
+ *        (model/attention.py:13-136, model/rotary_embedding_torch.py, timm Mlp).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gtav_dit_config {
+    /* DiT.__init__ arguments, model/dit.py:233-244 */
+    int32_t input_h, input_w, patch_size, in_channels, hidden_size, depth, num_heads;
+    float mlp_ratio;
+    int32_t external_cond_dim, max_frames;
+    /* capacity of the handle's workspace */
+    int32_t max_batch;      /* largest B of a forward / denoise call */
+    int32_t max_cond_rows;  /* rows of the conditioning (adaLN) table; >= max_batch * max_frames */
+} gtav_dit_config;
+
+typedef struct gtav_dit gtav_dit;
+
+int gtav_dit_create(const gtav_dit_config* cfg, gtav_dit** out);
+void gtav_dit_destroy(gtav_dit* h);
+/* One call per reference state-dict entry (names of SURVEY.md §8(b), e.g. "blocks.3.t_attn.to_qkv.weight");
+ * src_dev is the fp32 tensor in torch layout.  Replaces safetensors.torch.load_model(model, path)
+ * (generate.py:32).  Rotary `freqs` entries are passed under "spatial_rotary_emb.freqs" /
+ * "temporal_rotary_emb.freqs" (any alias is accepted). */
+int gtav_dit_set_weight(gtav_dit* h, const char* name, const float* src_dev, int64_t numel, void* stream);
+/* Builds derived tables (RoPE cos/sin, fused conditioning weights). Call after all set_weight calls;
+ * fails if a parameter is missing. */
+int gtav_dit_finalize(gtav_dit* h, void* stream);
+/* Copies the repacked value of one parameter back out as fp32 (for state_dict round trips / tests). */
+int gtav_dit_get_weight(gtav_dit* h, const char* name, float* dst_dev, int64_t numel, void* stream);
+
+/* DiT.forward(x, t, external_cond) — model/dit.py:343-376.
+ * x (B,T,C,H,W) f32, t (B,T) int64, actions (B,T,external_cond_dim) f32 or NULL, out like x. */
+int gtav_dit_forward(gtav_dit* h, const float* x_dev, const int64_t* t_dev, const float* actions_dev, float* out_dev,
+                     int32_t B, int32_t T, void* stream);
+
+/* Diffusion schedule used by the fused sampler step: alphas_cumprod (generate.py:195-198), 1000 floats (host). */
+int gtav_dit_set_schedule(gtav_dit* h, const float* alphas_cumprod_host, int32_t n);
+
+/* train_dit.denoise_step (train_dit.py:30-125) fused with generate.py:220 ("update only the last frame"):
+ * latents x (B, F, C, H, W) f32; the window is frames [start, cur]; context frames use timestep t_ctx,
+ * frame `cur` uses t_cur; frame `cur` of x is overwritten with x_pred (final step when is_final != 0).
+ * mode 0: recompute the whole window (what the reference does on every step).
+ * mode 1: context-cached step — only frame `cur` is pushed through the network, context K/V of every
+ *         temporal layer come from the cache left by the last mode-0 call on the same window
+ *         (exact: context activations do not depend on frame `cur`).
+ * actions (B, F, external_cond_dim) or NULL.  v_out (B, C, H, W) optional: v_pred of frame `cur`. */
+int gtav_dit_denoise_step(gtav_dit* h, float* x_dev, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
+                          int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions_dev, int32_t mode,
+                          float* v_out_dev, void* stream);
+
+/* Raises an error if any timestep seen since the last call was outside [0, 999] (synchronises). */
+int gtav_dit_check(gtav_dit* h, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ViT-VAE — replaces model/vae.py:160-361 (class AutoencoderKL)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gtav_vae_config {
+    /* AutoencoderKL.__init__ arguments, model/vae.py:161-176 */
+    int32_t latent_dim, input_height, input_width, patch_size;
+    int32_t enc_dim, enc_depth, enc_heads, dec_dim, dec_depth, dec_heads;
+    float mlp_ratio;
+    int32_t use_variational;
+    int32_t max_frames_per_call; /* workspace capacity: frames per encode/decode call */
+} gtav_vae_config;
+
+typedef struct gtav_vae gtav_vae;
+
+int gtav_vae_create(const gtav_vae_config* cfg, gtav_vae** out);
+void gtav_vae_destroy(gtav_vae* h);
+int gtav_vae_set_weight(gtav_vae* h, const char* name, const float* src_dev, int64_t numel, void* stream);
+int gtav_vae_finalize(gtav_vae* h, void* stream);
+int gtav_vae_get_weight(gtav_vae* h, const char* name, float* dst_dev, int64_t numel, void* stream);
+
+/* AutoencoderKL.encode (model/vae.py:306-322): img (N,3,H,W) f32; the network sees in_scale*img + in_shift
+ * (callers pass 2,-1 to fuse generate.py:56 `x * 2 - 1`; 1,0 for the plain method).
+ * moments_dev (N, seq_len, 2*latent) f32 = quant_conv output with logvar already clamped to [-30, 20]
+ * (DiagonalGaussianDistribution, model/vae.py:19-30). */
+int gtav_vae_encode(gtav_vae* h, const float* img_dev, float in_scale, float in_shift, float* moments_dev, int32_t N,
+                    void* stream);
+/* AutoencoderKL.decode (model/vae.py:324-338): z (N, seq_len, latent) f32, network input is z_scale*z;
+ * img (N,3,H,W) f32 = out_scale*decoded + out_shift (1,0 for the plain method). */
+int gtav_vae_decode(gtav_vae* h, const float* z_dev, float z_scale, float* img_dev, float out_scale, float out_shift,
+                    int32_t N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler / training elementwise math on caller-owned buffers
+ * ---------------------------------------------------------------------------------------------- */
+/* train_dit.py:110-125 for `rows` frames of n elements each, per-row alphas (device arrays). */
+int gtav_ddim_update(const float* x_dev, const float* v_dev, float* out_dev, int32_t rows, int32_t n,
+                     const float* alpha_t_dev, const float* alpha_next_dev, int32_t is_final, void* stream);
+/* train_dit.py:625-641: out = x*sqrt(a) + sqrt(1-a)*clamp(noise, +-clamp_abs), per-row alpha. */
+int gtav_add_noise(const float* x_dev, const float* noise_dev, const float* alpha_dev, float* out_dev, int32_t rows,
+                   int32_t n, float clamp_abs, void* stream);
+/* train_dit.py:643-645: v_target = sqrt(a)*clamp(noise) - sqrt(1-a)*x. */
+int gtav_vtarget(const float* x_dev, const float* noise_dev, const float* alpha_dev, float* vt_dev, int32_t rows,
+                 int32_t n, float clamp_abs, void* stream);
+/* train_dit.py:650 mse_loss: out[0] = mean((a-b)^2) over rows x n; a,b rows are a_stride / b_stride floats apart.
+ * out_dev must hold 1 + rows floats. */
+int gtav_mse(const float* a_dev, int64_t a_stride, const float* b_dev, int64_t b_stride, int32_t rows, int32_t n,
+             float* out_dev, void* stream);
+/* generate.py:238-244 tail: uint8 = clamp(img * 255, 0, 255) with img (N,3,H,W) f32 -> (N,H,W,3) u8. */
+int gtav_frames_to_u8(const float* img_dev, uint8_t* out_dev, int32_t N, int32_t H, int32_t W, void* stream);
+/* generate.py:56-65: latents (N,C,h,w) = scale * mean, from moments (N, h*w, 2*latent) (first `latent` channels). */
+int gtav_moments_to_latents(const float* moments_dev, float* lat_dev, int32_t N, int32_t hw, int32_t latent,
+                            int32_t mom_ch, float scale, void* stream);
+/* generate.py:238: (N,C,h,w) latents -> (N, h*w, C) decoder input. */
+int gtav_latents_to_tokens(const float* lat_dev, float* z_dev, int32_t N, int32_t hw, int32_t latent, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level entry points (used by the parity tests in tests/ and by bench.py's roofline probe)
+ * ---------------------------------------------------------------------------------------------- */
+/* epilogues: 0 f32, 1 f16, 2 gelu-tanh f16, 3 gelu-erf f16, 4 residual (+gate) f32 in place */
+int gtav_op_gemm_f16(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, void* out_dev,
+                     int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* gate_dev,
+                     int32_t gate_stride, int32_t rows_per_gate, void* stream);
+/* fused QKV projection + RoPE + attention-layout scatter. mode 0 spatial, 1 temporal (see csrc/gemm.h). */
+int gtav_op_gemm_qkv(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,
+                     int32_t D, int32_t mode, void* q_dev, void* k_dev, void* v_dev, int32_t S, int32_t Tq, int32_t t0,
+                     int32_t Tmax, const float* rope_cos_dev, const float* rope_sin_dev, void* stream);
+int gtav_op_skinny_f32(const float* x_dev, int32_t ldx, const float* w_dev, const float* bias_dev, float* y_dev,
+                       int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act_silu, void* stream);
+int gtav_op_ln_modulate(const float* x_dev, void* out_f16_dev, int32_t M, int32_t D, const float* shift_dev,
+                        const float* scale_dev, int32_t mod_stride, int32_t rows_per_mod, void* stream);
+int gtav_op_ln_affine(const float* x_dev, void* out_f16_dev, int32_t M, int32_t D, const float* gamma_dev,
+                      const float* beta_dev, void* stream);
+int gtav_op_attn_spatial(const void* q_dev, const void* k_dev, const void* vt_dev, void* o_dev, int32_t NB,
+                         int32_t heads, int32_t S, void* stream);
+int gtav_op_attn_temporal(const void* q_dev, const void* kv_dev, void* o_dev, int32_t B, int32_t P, int32_t D,
+                          int32_t Tq, int32_t t0, int32_t Tmax, void* stream);
+int gtav_op_convert_f16(const float* src_dev, int32_t lds, int32_t R, int32_t C, void* dst_f16_dev, int32_t Rp,
+                        int32_t Cp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTAV_AMD_H */

@@ -1,0 +1,220 @@
+"""Kernel-level parity (GPU): every HIP kernel against fp32 torch math on the SAME fp16-rounded operands,
+through the C-ABI (gtav_op_*).  Tolerances: fp32-accumulated GEMMs on identical inputs 2e-5 rel-L2; paths that
+round an intermediate to fp16 (GELU out, attention P) 1.5e-3."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import dev, gemm, pad_weight_f16, rel_l2, stream  # noqa: E402
+from gtav_amd import lib as L  # noqa: E402
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("M,N,K", [(720, 1024, 1024), (100, 256, 64), (144, 1200, 1024), (257, 64, 4096), (5760, 4096, 1024)])
+def test_gemm_f32_epilogue(M, N, K):
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    w16 = pad_weight_f16(w)
+    xd, bd = x.to(dev()), b.to(dev())
+    out = torch.full((M, N), float("nan"), device=dev())
+    gemm(xd, w16, bd, M, N, K, 0, out, N)
+    ref = x.float() @ w.half().float().t() + b
+    assert rel_l2(out, ref) < 2e-5
+    assert torch.isfinite(out).all()
+
+
+def test_gemm_f16_and_gelu_epilogues():
+    M, N, K = 300, 512, 256
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    w16 = pad_weight_f16(w)
+    xd, bd = x.to(dev()), b.to(dev())
+    pre = x.float() @ w.half().float().t() + b
+    for epi, fn in ((1, lambda z: z), (2, lambda z: torch.nn.functional.gelu(z, approximate="tanh")),
+                    (3, lambda z: torch.nn.functional.gelu(z))):
+        out = torch.zeros((M, N), device=dev(), dtype=torch.float16)
+        gemm(xd, w16, bd, M, N, K, epi, out, N)
+        assert rel_l2(out.float(), fn(pre)) < 6e-4, epi
+
+
+def test_gemm_residual_gate_epilogue():
+    M, N, K, P = 288, 256, 512, 48   # 6 frames of 48 tokens
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    resid = _rand(M, N, seed=4)
+    modw = 3 * N
+    mod = _rand(M // P, modw, seed=5)
+    w16 = pad_weight_f16(w)
+    r = resid.clone().to(dev())
+    md, xd, bd = mod.to(dev()), x.to(dev()), b.to(dev())
+    gate_view = md[:, N:]   # gate vector lives at column offset N of each mod row
+    L.check(L.load().gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), r.data_ptr(), N, M, N, K, 4,
+                                      gate_view.data_ptr(), modw, P, stream()))
+    y = x.float() @ w.half().float().t() + b
+    ref = resid + mod[:, N:2 * N].repeat_interleave(P, dim=0) * y
+    assert rel_l2(r, ref) < 2e-5
+    # plain residual (gate == NULL), VAE style
+    r2 = resid.clone().to(dev())
+    L.check(L.load().gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), r2.data_ptr(), N, M, N, K, 4,
+                                      0, 0, 1, stream()))
+    assert rel_l2(r2, resid + y) < 2e-5
+
+
+def _rope_ref(x, cos, sin):
+    """x (..., 64) with per-row cos/sin (..., 64): interleaved-pair rotation."""
+    x2 = x.reshape(*x.shape[:-1], 32, 2)
+    rot = torch.stack((-x2[..., 1], x2[..., 0]), dim=-1).reshape(x.shape)
+    return x * cos + rot * sin
+
+
+def test_gemm_qkv_spatial_layout_and_rope():
+    NB, S, D, heads = 3, 48, 256, 4
+    M = NB * S
+    x = _rand(M, D, seed=1).half()
+    w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
+    bias = _rand(3 * D, seed=7)
+    ang = _rand(S, 64, seed=3) * 3
+    cos, sin = ang.cos(), ang.sin()
+    w16 = pad_weight_f16(w)
+    q = torch.zeros(NB, heads, S, 64, device=dev(), dtype=torch.float16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(NB, heads, 64, S, device=dev(), dtype=torch.float16)
+    xd, bd, cd, sd_ = x.to(dev()), bias.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
+    L.check(L.load().gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), bd.data_ptr(), M, D, 0, q.data_ptr(),
+                                      k.data_ptr(), vt.data_ptr(), S, 0, 0, 0, cd.data_ptr(), sd_.data_ptr(), stream()))
+    y = (x.float() @ w.half().float().t() + bias).reshape(NB, S, 3, heads, 64)
+    qr = _rope_ref(y[:, :, 0].permute(0, 2, 1, 3), cos[None, None], sin[None, None])
+    kr = _rope_ref(y[:, :, 1].permute(0, 2, 1, 3), cos[None, None], sin[None, None])
+    vr = y[:, :, 2].permute(0, 2, 3, 1)  # (NB, heads, 64, S)
+    assert rel_l2(q.float(), qr) < 6e-4
+    assert rel_l2(k.float(), kr) < 6e-4
+    assert rel_l2(vt.float(), vr) < 6e-4
+
+
+def test_gemm_qkv_temporal_layout():
+    B, Tq, t0, Tmax, P, D = 2, 2, 1, 4, 16, 256
+    M = B * Tq * P
+    x = _rand(M, D, seed=1).half()
+    w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
+    ang = _rand(Tmax, 64, seed=3) * 3
+    cos, sin = ang.cos(), ang.sin()
+    w16 = pad_weight_f16(w)
+    q = torch.zeros(M, D, device=dev(), dtype=torch.float16)
+    kv = torch.zeros(B, Tmax, P, 2, D, device=dev(), dtype=torch.float16)
+    xd, cd, sd_ = x.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
+    L.check(L.load().gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), 0, M, D, 1, q.data_ptr(), kv.data_ptr(),
+                                      kv.data_ptr(), P, Tq, t0, Tmax, cd.data_ptr(), sd_.data_ptr(), stream()))
+    y = (x.float() @ w.half().float().t()).reshape(B, Tq, P, 3, D // 64, 64)
+    pos = torch.arange(t0, t0 + Tq)
+    c, s = cos[pos][None, :, None, None, :], sin[pos][None, :, None, None, :]
+    qr = _rope_ref(y[:, :, :, 0], c, s).reshape(M, D)
+    kr = _rope_ref(y[:, :, :, 1], c, s).reshape(B, Tq, P, D)
+    vr = y[:, :, :, 2].reshape(B, Tq, P, D)
+    assert rel_l2(q.float(), qr) < 6e-4
+    assert rel_l2(kv[:, t0:t0 + Tq, :, 0].float(), kr) < 6e-4
+    assert rel_l2(kv[:, t0:t0 + Tq, :, 1].float(), vr) < 6e-4
+    assert kv[:, :t0].abs().max().item() == 0  # untouched cache slots
+
+
+@pytest.mark.parametrize("M,N,K,act", [(5, 1024, 256, 1), (16, 6144, 1056, 0), (37, 192, 1024, 1)])
+def test_skinny_f32(M, N, K, act):
+    x, w, b = _rand(M, K, seed=1), _rand(N, K, scale=1 / math.sqrt(K), seed=2), _rand(N, seed=3)
+    y = torch.full((M, N), float("nan"), device=dev())
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    L.check(L.load().gtav_op_skinny_f32(xd.data_ptr(), K, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N, M, N, K, act, stream()))
+    ref = x.double() @ w.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.silu(ref)
+    assert rel_l2(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("D", [256, 1024])
+def test_layernorm_kernels(D):
+    M, P = 96, 32
+    x = _rand(M, D, seed=1) * 3 + 0.5
+    mod = _rand(M // P, 2 * D, seed=2)
+    out = torch.zeros(M, D, device=dev(), dtype=torch.float16)
+    md, xd = mod.to(dev()), x.to(dev())
+    L.check(L.load().gtav_op_ln_modulate(xd.data_ptr(), out.data_ptr(), M, D, md.data_ptr(), md[:, D:].data_ptr(), 2 * D, P,
+                                         stream()))
+    xh = torch.nn.functional.layer_norm(x, (D,), eps=1e-6)
+    shift, scale = mod[:, :D].repeat_interleave(P, 0), mod[:, D:].repeat_interleave(P, 0)
+    ref = xh * (1 + (scale + 1e-6)) + shift
+    assert rel_l2(out.float(), ref) < 5e-4
+    g, b = _rand(D, seed=3) * 0.1 + 1, _rand(D, seed=4) * 0.1
+    gd, bd = g.to(dev()), b.to(dev())
+    L.check(L.load().gtav_op_ln_affine(xd.data_ptr(), out.data_ptr(), M, D, gd.data_ptr(), bd.data_ptr(), stream()))
+    assert rel_l2(out.float(), torch.nn.functional.layer_norm(x, (D,), g, b, eps=1e-6)) < 5e-4
+
+
+@pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72)])
+def test_attention_spatial(NB, heads, S):
+    q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
+    q = q * 1.5
+    vt = v.transpose(-1, -2).contiguous()
+    o = torch.zeros(NB * S, heads * 64, device=dev(), dtype=torch.float16)
+    qd, kd, vd = q.to(dev()), k.to(dev()), vt.to(dev())
+    L.check(L.load().gtav_op_attn_spatial(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), NB, heads, S, stream()))
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    ref = ref.permute(0, 2, 1, 3).reshape(NB * S, heads * 64)
+    assert rel_l2(o.float(), ref) < 1.5e-3
+
+
+def test_attention_spatial_online_softmax_spike():
+    """Forces the running max to jump in a LATER key block (the rescale branch of the online softmax)."""
+    NB, heads, S = 1, 1, 144
+    q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
+    k[0, 0, 130] = q[0, 0, 7] * 4  # key 130 (third block) dominates query 7
+    vt = v.transpose(-1, -2).contiguous()
+    o = torch.zeros(NB * S, 64, device=dev(), dtype=torch.float16)
+    qd, kd, vd = q.to(dev()), k.to(dev()), vt.to(dev())
+    L.check(L.load().gtav_op_attn_spatial(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), NB, heads, S, stream()))
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())[0, 0]
+    assert rel_l2(o.float(), ref) < 1.5e-3
+    assert rel_l2(o[7].float(), ref[7]) < 2e-3
+
+
+@pytest.mark.parametrize("Tq,t0", [(5, 0), (1, 4), (2, 1), (1, 0)])
+def test_attention_temporal(Tq, t0):
+    B, P, D, Tmax = 2, 24, 256, 5
+    Tk = t0 + Tq
+    q = _rand(B, Tq, P, D, seed=1).half()
+    kv = _rand(B, Tmax, P, 2, D, seed=2).half()
+    o = torch.zeros(B * Tq * P, D, device=dev(), dtype=torch.float16)
+    qd, kvd = q.to(dev()), kv.to(dev())
+    L.check(L.load().gtav_op_attn_temporal(qd.data_ptr(), kvd.data_ptr(), o.data_ptr(), B, P, D, Tq, t0, Tmax, stream()))
+    h = D // 64
+    qf = q.float().reshape(B, Tq, P, h, 64).permute(0, 2, 3, 1, 4)             # B P h Tq d
+    kf = kv[:, :Tk, :, 0].float().reshape(B, Tk, P, h, 64).permute(0, 2, 3, 1, 4)
+    vf = kv[:, :Tk, :, 1].float().reshape(B, Tk, P, h, 64).permute(0, 2, 3, 1, 4)
+    s = qf @ kf.transpose(-1, -2) / 8.0
+    mask = torch.arange(Tk)[None, :] > (t0 + torch.arange(Tq))[:, None]
+    s = s.masked_fill(mask, float("-inf"))
+    ref = (s.softmax(-1) @ vf).permute(0, 3, 1, 2, 4).reshape(B * Tq * P, D)
+    assert rel_l2(o.float(), ref) < 6e-4
+
+
+def test_ddim_update_matches_reference_formula():
+    rows, n = 6, 1000
+    x, v = _rand(rows, n, seed=1), _rand(rows, n, seed=2)
+    at = torch.rand(rows, generator=torch.Generator().manual_seed(3)) * 0.98 + 0.01
+    an = torch.rand(rows, generator=torch.Generator().manual_seed(4)) * 0.98 + 0.01
+    an[:3] = 1.0
+    from gtav_amd.sampler import ddim_update
+    for final in (False, True):
+        out = ddim_update(x.to(dev()), v.to(dev()), at.to(dev()), an.to(dev()), final)
+        a_t, a_n = at[:, None], an[:, None]
+        x0 = a_t.sqrt() * x - (1 - a_t).sqrt() * v
+        eps = ((1 / a_t).sqrt() * x - x0) / (1 / a_t - 1).sqrt()
+        ref = x0 if final else a_n.sqrt() * x0 + (1 - a_n).sqrt() * eps
+        assert rel_l2(out, ref) < 1e-6

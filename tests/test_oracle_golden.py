@@ -1,0 +1,167 @@
+"""CPU: pins oracle/ref_cpu.py (and the product's host-side tables) against golden vectors captured from the ACTUAL
+reference (tools/make_golden.py -> tests/golden/*.safetensors).  fp32 vs fp32, so the bound is tight (2e-5 rel-L2;
+most cases are bit-exact because the oracle uses the same ATen CPU kernels)."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import ref_cpu as O
+import gtav_amd.weights as W
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL_DIT = dict(input_h=8, input_w=16, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+SMALL_VAE = dict(latent_dim=16, input_height=64, input_width=96, patch_size=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=256,
+                 dec_depth=2, dec_heads=4)
+TOL = 2e-5
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def gold(name):
+    return load_file(os.path.join(GOLD, name))
+
+
+def test_g0_schedule_and_known_answers():
+    g = gold("g0_constants.safetensors")
+    for tag, cm in (("gen", 1e-4), ("train", 1e-6)):
+        assert torch.equal(O.sigmoid_beta_schedule(1000, clamp_min=cm), g[f"betas64_{tag}"])
+        assert torch.equal(O.alphas_cumprod_table(cm), g[f"alphas_cumprod_{tag}"])
+    # known answers recorded in SURVEY.md §8(a) a20
+    ac = O.alphas_cumprod_table(1e-4)
+    for i, v in ((0, 0.99969977), (15, 0.99499559), (499, 0.50005001), (999, 1.0000775e-4)):
+        assert abs(ac[i].item() - v) / v < 2e-6
+    assert torch.equal(O.noise_range_generate(100), g["noise_range_gen100"])
+    assert [int(v) for v in O.noise_range_generate(100)] == g["noise_range_gen100_long"].tolist()
+    assert [int(v) for v in O.noise_range_generate(100)][:4] == [0, 9, 19, 29]
+    assert torch.equal(O.noise_range_train(50), g["noise_range_train50"])
+
+
+def test_g0_rope_tables_and_embeddings():
+    g = gold("g0_constants.safetensors")
+    assert torch.equal(O.rope_freqs_pixel(32, 256), g["rope_spatial_freqs"])
+    assert torch.equal(O.rope_angles_axial(9, 16, O.rope_freqs_pixel(32, 256)), g["rope_spatial_angles_9x16"])
+    assert torch.equal(O.rope_freqs_lang(64), g["rope_temporal_freqs"])
+    assert torch.equal(O.rope_angles_temporal(5, O.rope_freqs_lang(64)), g["rope_temporal_angles_T5"])
+    assert torch.equal(O.vae_rope_angles(O.vit_l_20_shallow_encoder(), 16, 1024), g["rope_vae_angles_18x32"])
+    assert torch.equal(O.timestep_embedding(torch.tensor([0, 15, 19, 500, 999])), g["timestep_embedding_rows"])
+    m = O.modulate(torch.ones(1, 1, 1, 1, 1), torch.full((1, 1, 1), 0.5), torch.full((1, 1, 1), 0.25))
+    assert torch.equal(m, g["modulate_known"]) and abs(m.item() - 1.75000095) < 1e-6
+    assert torch.allclose(O.dummy_clip().mean(dim=(2, 3)), g["dummy_clip_means"])
+    assert torch.equal(O.actions_to_one_hot([-1, 3, 0, 24, -1]), g["one_hot_example"])
+
+
+def test_product_host_tables_match_reference():
+    """The tables the product uploads (computed in gtav_amd.model.dit with torch CPU ops) equal the reference's."""
+    from gtav_amd.model.dit import _rope_tables_axial, _rope_tables_temporal, _timestep_table
+    from gtav_amd.utils import alphas_cumprod
+    from gtav_amd.dummy_dataset import ImageDataset, actions_to_one_hot
+    g = gold("g0_constants.safetensors")
+    c, s = _rope_tables_axial(W.rope_freqs_pixel(32, 256), 9, 16)
+    ang = g["rope_spatial_angles_9x16"].reshape(144, 64)
+    assert torch.equal(c, ang.cos()) and torch.equal(s, ang.sin())
+    c, s = _rope_tables_temporal(W.rope_freqs_lang(64), 5)
+    assert torch.equal(c, g["rope_temporal_angles_T5"].cos()) and torch.equal(s, g["rope_temporal_angles_T5"].sin())
+    c, s = _rope_tables_axial(W.rope_freqs_pixel(16, 576), 18, 32)
+    va = g["rope_vae_angles_18x32"].reshape(576, 32)
+    assert torch.equal(c[:, :32], va.cos()) and torch.equal(s[:, :32], va.sin())
+    assert torch.equal(c[:, 32:], torch.ones(576, 32)) and torch.equal(s[:, 32:], torch.zeros(576, 32))
+    tab = _timestep_table()
+    assert torch.equal(tab[[0, 15, 19, 500, 999]], g["timestep_embedding_rows"])
+    assert torch.equal(alphas_cumprod(1e-4), g["alphas_cumprod_gen"]) and torch.equal(alphas_cumprod(1e-6), g["alphas_cumprod_train"])
+    assert torch.allclose(ImageDataset("test").sequence_blue_red.mean(dim=(2, 3)), g["dummy_clip_means"])
+    assert torch.equal(actions_to_one_hot([-1, 3, 0, 24, -1]), g["one_hot_example"])
+
+
+def test_g2_small_dit():
+    g = gold("g2_small_dit.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=3)
+    cfg = O.DiTConfig(**SMALL_DIT)
+    taps = {}
+    with torch.no_grad():
+        assert rel(O.dit_forward(sd, cfg, g["x"], g["t"], g["actions"], taps), g["out_actions"]) < TOL
+        assert rel(O.dit_forward(sd, cfg, g["x"], g["t"], None), g["out_noactions"]) < TOL
+    for i in range(2):
+        assert rel(taps[f"block{i}"], g[f"block{i}_actions"]) < TOL
+
+
+def test_g2_small_vae():
+    g = gold("g2_small_vae.safetensors")
+    sd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE), seed=5)
+    cfg = O.VAEConfig(**SMALL_VAE)
+    with torch.no_grad():
+        mom = O.vae_encode_moments(sd, cfg, g["img"])
+        assert rel(mom[..., :16], g["mean"]) < TOL
+        assert rel(mom[..., 16:].clamp(-30, 20), g["logvar"]) < TOL
+        assert rel(O.vae_decode(sd, cfg, g["z"]), g["decoded"]) < TOL
+
+
+def test_g4_denoise_step():
+    g = gold("g4_denoise_step.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=4)
+    cfg = O.DiTConfig(**SMALL_DIT)
+    ac = O.alphas_cumprod_table(1e-4)[:, None, None, None]
+    nr = torch.linspace(0, 999, 11)
+    fn = lambda x, t, a: O.dit_forward(sd, cfg, x, t, a)
+    with torch.no_grad():
+        for idx in (10, 4, 0):
+            xp, vp = O.denoise_step(fn, g["x"], g["actions"], idx, 15, nr, ac, start_frame=1)
+            assert rel(xp, g[f"x_pred_{idx}"]) < TOL and rel(vp, g[f"v_pred_{idx}"]) < TOL
+
+
+def test_g5_rollout():
+    g = gold("g5_rollout.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=6)
+    cfg = O.DiTConfig(**SMALL_DIT)
+    fn = lambda x, t, a: O.dit_forward(sd, cfg, x, t, a)
+    with torch.no_grad():
+        out = O.generate_latents(fn, g["x_prompt"], 4, 10, g["noise"], g["actions"])
+    assert rel(out, g["latents"]) < 1e-4     # 33 chained fp32 forwards
+
+
+def test_g6_train_forward_loss():
+    g = gold("g6_train_forward.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=7)
+    cfg = O.DiTConfig(**SMALL_DIT)
+    fn = lambda x, t, a: O.dit_forward(sd, cfg, x, t, a)
+    with torch.no_grad():
+        loss, vp, vt, xn, t = O.train_forward_loss(fn, g["latents"], g["actions"], g["target_idx"], g["ctx_idx"], g["ctx_noise"], g["noise"])
+    assert torch.equal(t, g["t"])
+    assert rel(xn, g["x_noisy"]) < 1e-6 and rel(vt, g["v_target"]) < 1e-6
+    assert rel(vp, g["v_pred"]) < TOL and abs(loss.item() - g["loss"].item()) / g["loss"].item() < TOL
+
+
+@pytest.mark.slow
+def test_g3_full_dit():
+    g = gold("g3_full_dit.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    cfg = O.dit_s_2()
+    taps = {}
+    with torch.no_grad():
+        out = O.dit_forward(sd, cfg, g["x_b1t5"], g["t_b1t5"], g["a_b1t5"], taps)
+        assert rel(out, g["out_b1t5"]) < TOL
+        for i in (0, 7, 15):
+            tp = taps[f"block{i}"]
+            st = torch.stack([tp.mean(), tp.abs().max(), tp.abs().mean()])
+            assert torch.allclose(st, g[f"block{i}_stats"], rtol=1e-4)
+            assert torch.allclose(tp.reshape(-1)[:: max(1, tp.numel() // 8)][:8], g[f"block{i}_samples"], rtol=1e-4, atol=1e-4)
+        assert rel(O.dit_forward(sd, cfg, g["x_b2t3"], g["t_b2t3"], None), g["out_b2t3"]) < TOL
+
+
+@pytest.mark.slow
+def test_g3_full_vae():
+    g = gold("g3_full_vae.safetensors")
+    sd = W.synth_state_dict(W.vae_param_shapes(), seed=1)
+    cfg = O.vit_l_20_shallow_encoder()
+    gen = torch.Generator().manual_seed(3)
+    img = torch.rand(2, 3, 360, 640, generator=gen) * 2 - 1
+    z = torch.randn(2, 576, 16, generator=gen)
+    assert torch.equal(z, g["z"])
+    with torch.no_grad():
+        mom = O.vae_encode_moments(sd, cfg, img)
+        assert rel(mom[..., :16], g["mean"]) < TOL
+        dec = O.vae_decode(sd, cfg, z)
+        assert rel(dec[:, :, ::4, ::4], g["decoded_stride4"]) < TOL and rel(dec[:, :, 100], g["decoded_row100"]) < TOL

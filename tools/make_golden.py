@@ -1,0 +1,210 @@
+"""Generates tests/golden/*.safetensors by running the ACTUAL reference (/root/reference) on CPU.
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+The reference is imported through tools/ref_shim.py (stubs for the absent third-party packages); its
+modules are loaded with this repo's deterministic synthetic weights (gtav_amd.weights.synth_state_dict, every
+matrix non-zero — the reference's own init zeroes the adaLN gates, which would make every block the identity).
+Only inputs and reference OUTPUTS are stored (data, not source).  Loops that live inside un-importable scripts
+(generate.py:main needs CUDA; DiffusionTrainer needs accelerate state) are driven here with the reference's own
+`denoise_step`, `sigmoid_beta_schedule` and model classes, following generate.py:186-220 / train_dit.py:554-650.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+
+import ref_shim  # noqa: E402
+import gtav_amd.weights as W  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SMALL_DIT = dict(input_h=8, input_w=16, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+SMALL_VAE = dict(latent_dim=16, input_height=64, input_width=96, patch_size=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=256,
+                 dec_depth=2, dec_heads=4)
+
+
+def load_into(model, sd):
+    msd = model.state_dict()
+    for k in msd:
+        if k in sd:
+            assert msd[k].shape == sd[k].shape, k
+            msd[k] = sd[k]
+    model.load_state_dict(msd)
+    return model.eval()
+
+
+def save(name, tensors):
+    tensors = {k: (v.detach().contiguous() if torch.is_tensor(v) else torch.tensor(v)) for k, v in tensors.items()}
+    path = os.path.join(OUT, name)
+    save_file(tensors, path)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(tensors)} tensors")
+
+
+def one_hot_actions(B, T, g):
+    a = torch.zeros(B, T, 25)
+    a[torch.arange(B)[:, None], torch.arange(T)[None], torch.randint(0, 25, (B, T), generator=g)] = 1
+    return a
+
+
+@torch.no_grad()
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rd, rv, ref_denoise_step, ref_schedule = ref_shim.import_reference()
+    from model.rotary_embedding_torch import RotaryEmbedding
+    from dummy_dataset import ImageDataset as RefDummy
+    from web_dataset import actions_to_one_hot as ref_one_hot
+
+    # ---------------- G0: constants / tables -------------------------------------------------
+    g0 = {}
+    for tag, cm in (("gen", 1e-4), ("train", 1e-6)):
+        betas = ref_schedule(1000, clamp_min=cm)
+        g0[f"betas64_{tag}"] = betas
+        g0[f"alphas_cumprod_{tag}"] = torch.cumprod(1.0 - betas.float(), dim=0)
+    g0["noise_range_gen100"] = torch.linspace(0, 999, 101)
+    g0["noise_range_gen100_long"] = torch.tensor([int(torch.full((1,), v, dtype=torch.long)) for v in torch.linspace(0, 999, 101)])
+    g0["noise_range_train50"] = torch.linspace(0, 999, 51).long()
+    sp = RotaryEmbedding(dim=32, freqs_for="pixel", max_freq=256)
+    g0["rope_spatial_freqs"] = sp.freqs.detach()
+    g0["rope_spatial_angles_9x16"] = sp.get_axial_freqs(9, 16)
+    tp = RotaryEmbedding(dim=64)
+    g0["rope_temporal_freqs"] = tp.freqs.detach()
+    g0["rope_temporal_angles_T5"] = tp.forward(torch.arange(5).float(), tp.freqs, seq_len=5).clone()
+    g0["rope_vae_angles_18x32"] = RotaryEmbedding(dim=16, freqs_for="pixel", max_freq=18 * 32).get_axial_freqs(18, 32)
+    g0["timestep_embedding_rows"] = rd.TimestepEmbedder.timestep_embedding(torch.tensor([0, 15, 19, 500, 999]), 256)
+    g0["modulate_known"] = rd.modulate(torch.ones(1, 1, 1, 1, 1), torch.full((1, 1, 1), 0.5), torch.full((1, 1, 1), 0.25))
+    ds = RefDummy(split="test")
+    g0["dummy_clip_means"] = ds.sequence_blue_red.mean(dim=(2, 3))            # (5, 3) colours
+    g0["one_hot_example"] = ref_one_hot([-1, 3, 0, 24, -1])
+    save("g0_constants.safetensors", g0)
+
+    # ---------------- G2: small DiT / VAE end to end -----------------------------------------
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=3)
+    m = load_into(rd.DiT(**SMALL_DIT), sd)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 3, 16, 8, 16, generator=g)
+    t = torch.randint(0, 1000, (2, 3), generator=g)
+    a = one_hot_actions(2, 3, g)
+    taps = {}
+    hooks = [m.blocks[i].register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, out.clone())) for i in range(2)]
+    out_a = m(x, t, a)
+    blk = {f"block{i}_actions": taps[i] for i in range(2)}
+    out_n = m(x, t, None)
+    for h in hooks:
+        h.remove()
+    save("g2_small_dit.safetensors", {"x": x, "t": t, "actions": a, "out_actions": out_a, "out_noactions": out_n, **blk})
+
+    vsd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE), seed=5)
+    v = load_into(rv.AutoencoderKL(**SMALL_VAE), vsd)
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(3, 3, 64, 96, generator=g) * 2 - 1
+    post = v.encode(img)
+    z = torch.randn(3, v.seq_len, 16, generator=g)
+    save("g2_small_vae.safetensors", {"img": img, "mean": post.mean, "logvar": post.logvar, "z": z, "decoded": v.decode(z)})
+
+    # ---------------- G4: denoise_step (reference function, small DiT) -----------------------
+    sd4 = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=4)
+    m4 = load_into(rd.DiT(**SMALL_DIT), sd4)
+    g = torch.Generator().manual_seed(2)
+    x4 = torch.randn(2, 6, 16, 8, 16, generator=g)
+    a4 = torch.zeros(2, 6, 25)
+    a4[:, :, 3] = 1
+    ac = torch.cumprod(1.0 - ref_schedule(1000).float(), dim=0)[:, None, None, None]
+    nr = torch.linspace(0, 999, 11)
+    g4 = {"x": x4, "actions": a4}
+    for idx in (10, 4, 0):
+        xp, vp = ref_denoise_step(m4, x4, a4, idx, 15, nr, ac, start_frame=1, dtype=torch.bfloat16)
+        g4[f"x_pred_{idx}"], g4[f"v_pred_{idx}"] = xp, vp
+    save("g4_denoise_step.safetensors", g4)
+
+    # ---------------- G5: config-1-shaped mini rollout (generate.py:186-220) ------------------
+    sd5 = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=6)
+    m5 = load_into(rd.DiT(**SMALL_DIT), sd5)
+    g = torch.Generator().manual_seed(9)
+    B, total, steps = 2, 4, 10
+    x0 = torch.randn(B, 1, 16, 8, 16, generator=g) * 0.5
+    noise = torch.randn(B, 3, 16, 8, 16, generator=g)
+    a5 = torch.zeros(B, total, 25)
+    a5[:, :, 3] = 1
+    xx = x0.clone()
+    nr5 = torch.linspace(0, 999, steps + 1)
+    for i in range(1, total):
+        chunk = torch.clamp(noise[:, i - 1: i], -20, 20)
+        xx = torch.cat([xx, chunk], dim=1)
+        start = max(0, i + 1 - 5)
+        for noise_idx in reversed(range(0, steps + 1)):
+            xp, _ = ref_denoise_step(m5, xx, a5, noise_idx, 15, nr5, ac, start_frame=start, dtype=torch.bfloat16)
+            xx[:, -1:] = xp[:, -1:]
+    save("g5_rollout.safetensors", {"x_prompt": x0, "noise": noise, "actions": a5, "latents": xx})
+
+    # ---------------- G6: training forward + loss (train_dit.py:574-650) ----------------------
+    sd6 = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=7)
+    m6 = load_into(rd.DiT(**SMALL_DIT), sd6)
+    g = torch.Generator().manual_seed(4)
+    B = 3
+    lat = torch.randn(B, 5, 16, 8, 16, generator=g) * 0.5
+    a6 = torch.zeros(B, 5, 25)
+    a6[:, -1, 1] = 1
+    tgt, ctx = torch.tensor([50, 1, 23]), torch.tensor([40, 7, 30])
+    ctx_noise = torch.randn(B, 4, 16, 8, 16, generator=g) * 8
+    nz = torch.randn(B, 1, 16, 8, 16, generator=g) * 8
+    ac_t = torch.cumprod(1.0 - ref_schedule(1000, clamp_min=0.000001).float(), dim=0)[:, None, None, None]
+    noise_range = torch.linspace(0, 999, 51).long()
+    ctx_i = torch.minimum(ctx, tgt)
+    tt = torch.zeros((B, 5), dtype=torch.long)
+    tt[:, :-1] = noise_range[ctx_i].unsqueeze(1)
+    tt[:, -1] = noise_range[tgt]
+    cn, n1 = ctx_noise.clamp(-20, 20), nz.clamp(-20, 20)
+    x_noisy = lat.clone()
+    al = ac_t[tt[:, :-1]]
+    x_noisy[:, :-1].mul_(al.sqrt()).add_((1 - al).sqrt() * cn)
+    al = ac_t[tt[:, -1:]]
+    x_noisy[:, -1:].mul_(al.sqrt()).add_((1 - al).sqrt() * n1)
+    v_target = al.sqrt() * n1 - (1 - al).sqrt() * lat[:, -1:]
+    v_pred = m6(x_noisy, tt, a6)
+    loss = torch.nn.functional.mse_loss(v_pred[:, -1:], v_target)
+    save("g6_train_forward.safetensors", {"latents": lat, "actions": a6, "target_idx": tgt, "ctx_idx": ctx, "ctx_noise": ctx_noise,
+                                          "noise": nz, "x_noisy": x_noisy, "t": tt, "v_target": v_target, "v_pred": v_pred,
+                                          "loss": loss.reshape(1)})
+
+    # ---------------- G3: full-size models (weights regenerated from the hash generator in tests) ----
+    fsd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    fm = load_into(rd.DiT_models["DiT-S/2"](), fsd)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 5, 16, 18, 32, generator=g)
+    t = torch.tensor([[15, 15, 15, 15, 500]])
+    a = torch.zeros(1, 5, 25)
+    a[:, :, 3] = 1
+    taps = {}
+    hooks = [fm.blocks[i].register_forward_hook(lambda mod, inp, out, i=i: taps.__setitem__(i, out.clone())) for i in (0, 7, 15)]
+    out1 = fm(x, t, a)
+    for h in hooks:
+        h.remove()
+    g3 = {"x_b1t5": x, "t_b1t5": t, "a_b1t5": a, "out_b1t5": out1}
+    for i in (0, 7, 15):
+        g3[f"block{i}_stats"] = torch.stack([taps[i].mean(), taps[i].abs().max(), taps[i].abs().mean()])
+        g3[f"block{i}_samples"] = taps[i].reshape(-1)[:: max(1, taps[i].numel() // 8)][:8].clone()
+    g2_ = torch.Generator().manual_seed(5)
+    x2 = torch.randn(2, 3, 16, 18, 32, generator=g2_)
+    t2 = torch.randint(0, 1000, (2, 3), generator=g2_)
+    g3.update({"x_b2t3": x2, "t_b2t3": t2, "out_b2t3": fm(x2, t2, None)})
+    save("g3_full_dit.safetensors", g3)
+    del fm, fsd
+
+    fvsd = W.synth_state_dict(W.vae_param_shapes(), seed=1)
+    fv = load_into(rv.VAE_models["vit-l-20-shallow-encoder"](), fvsd)
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(2, 3, 360, 640, generator=g) * 2 - 1       # regenerated from the seed in the tests
+    post = fv.encode(img)
+    z = torch.randn(2, 576, 16, generator=g)
+    dec = fv.decode(z)
+    save("g3_full_vae.safetensors", {"mean": post.mean, "logvar": post.logvar, "z": z, "decoded_stride4": dec[:, :, ::4, ::4].clone(),
+                                     "decoded_row100": dec[:, :, 100].clone()})
+
+
+if __name__ == "__main__":
+    main()
