@@ -141,10 +141,64 @@ static void build_axial_table(const std::vector<float>& freqs, int gh, int gw, s
 
 }  // namespace
 
+// In-situ kernel timing (opt-in): HIP events on the launch stream around every kernel of a forward,
+// accumulated per kernel class.  Used by bench.py for the roofline line; off in normal operation.
+enum ProfClass { PC_LN = 0, PC_QKV, PC_ATTN_S, PC_ATTN_T, PC_OUT, PC_FC1, PC_FC2, PC_OTHER, PC_COUNT };
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> cls;
+    size_t used = 0;
+    double ms[PC_COUNT] = {0};
+    long long n[PC_COUNT] = {0};
+    int begin(int c, hipStream_t s) {
+        if (!on) return 0;
+        if (used + 2 > ev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t e;
+                GTAV_CHECK_HIP(hipEventCreate(&e));
+                ev.push_back(e);
+            }
+        }
+        cls.resize(ev.size() / 2);
+        cls[used / 2] = c;
+        GTAV_CHECK_HIP(hipEventRecord(ev[used], s));
+        return 0;
+    }
+    int end(hipStream_t s) {
+        if (!on) return 0;
+        GTAV_CHECK_HIP(hipEventRecord(ev[used + 1], s));
+        used += 2;
+        return 0;
+    }
+    int collect(hipStream_t s) {
+        if (!on || used == 0) return 0;
+        GTAV_CHECK_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < used; i += 2) {
+            float t = 0.f;
+            GTAV_CHECK_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            ms[cls[i / 2]] += t;
+            n[cls[i / 2]] += 1;
+        }
+        used = 0;
+        return 0;
+    }
+    ~Profiler() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    }
+};
+#define PROF(h, c, s, expr)            \
+    do {                               \
+        RET_IF((h)->prof.begin(c, s)); \
+        RET_IF(expr);                  \
+        RET_IF((h)->prof.end(s));      \
+    } while (0)
+
 // ================================================================================================
 // DiT
 // ================================================================================================
 struct gtav_dit {
+    Profiler prof;
     gtav_dit_config cfg;
     int D, L, heads, P, gh, gw, C, p, H, W, Hm, Hm_pad, A, Apad, MODW, Kpe, Nfin, maxB, maxT, Mmax, max_rows;
     Arena arena;
@@ -189,16 +243,16 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                             const float* mod, const int* mod_rows, float* v_out, hipStream_t s) {
     const int D = h->D, P = h->P, NB = B * Tq, M = NB * P;
     GTAV_REQUIRE(M <= h->Mmax, "forward: %d tokens exceed workspace (%d)", M, h->Mmax);
-    RET_IF(launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, s));
+    PROF(h, PC_OTHER, s, launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kpe; g.W = h->w_pe; g.M = M; g.N = D; g.K = h->Kpe; g.bias = h->b_pe; g.out = h->resid; g.ldo = D;
-    RET_IF(launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
     for (int l = 0; l < h->L; ++l) {
         for (int hf = 0; hf < 2; ++hf) {
             const gtav_dit::Half& w = h->halves[l * 2 + hf];
             const float* mb = mod + (size_t)(l * 2 + hf) * 6 * D;
-            RET_IF(launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, s));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, s));
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
             if (hf == 0) {
@@ -209,30 +263,30 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
                 g.rope_cos = h->rope_t.cos_dev; g.rope_sin = h->rope_t.sin_dev;
             }
-            RET_IF(launch_gemm(g, EPI_QKV, s));
-            if (hf == 0) RET_IF(launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
-            else RET_IF(launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
+            PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
+            if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
+            else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             memset(&g, 0, sizeof(g));
             g.X = h->ao; g.ldx = D; g.W = w.w_out; g.M = M; g.N = D; g.K = D; g.bias = w.b_out; g.out = h->resid; g.ldo = D;
             g.gate = mb + 2 * D; g.gate_stride = h->MODW; g.gate_rows = mod_rows; g.rows_per_gate = P;
-            RET_IF(launch_gemm(g, EPI_RESID, s));
-            RET_IF(launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, s));
+            PROF(h, PC_OUT, s, launch_gemm(g, EPI_RESID, s));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, s));
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad;
-            RET_IF(launch_gemm(g, EPI_GELU_TANH, s));
+            PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
             memset(&g, 0, sizeof(g));
             g.X = h->hbuf; g.ldx = h->Hm_pad; g.W = w.w_fc2; g.M = M; g.N = D; g.K = h->Hm_pad; g.bias = w.b_fc2; g.out = h->resid; g.ldo = D;
             g.gate = mb + 5 * D; g.gate_stride = h->MODW; g.gate_rows = mod_rows; g.rows_per_gate = P;
-            RET_IF(launch_gemm(g, EPI_RESID, s));
+            PROF(h, PC_FC2, s, launch_gemm(g, EPI_RESID, s));
         }
     }
     const float* mf = mod + (size_t)h->L * 12 * D;
-    RET_IF(launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, s));
+    PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
-    RET_IF(launch_gemm(g, EPI_F32, s));
-    RET_IF(launch_unpatchify(h->fo, h->Nfin, v_out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
-    return 0;
+    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, launch_unpatchify(h->fo, h->Nfin, v_out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
+    return h->prof.collect(s);
 }
 
 extern "C" {
@@ -444,6 +498,19 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
     RET_IF(launch_ddim_update(x + (size_t)cur * fsz, (size_t)F * fsz, vlast, (size_t)Tq * fsz, x + (size_t)cur * fsz, (size_t)F * fsz,
                               B, (int)fsz, nullptr, nullptr, h->ac_host[t_cur], h->ac_host[t_next], is_final, s));
     if (v_out) RET_IF(launch_copy_rows_f32(vlast, (size_t)Tq * fsz, v_out, fsz, B, fsz, s));
+    return 0;
+}
+
+int gtav_dit_profile(gtav_dit* h, int32_t enable) {
+    GTAV_REQUIRE(h, "dit_profile: null handle");
+    h->prof.on = enable != 0;
+    h->prof.used = 0;
+    for (int i = 0; i < PC_COUNT; ++i) { h->prof.ms[i] = 0; h->prof.n[i] = 0; }
+    return 0;
+}
+int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class) {
+    GTAV_REQUIRE(h && ms_by_class && launches_by_class, "dit_profile_read: null argument");
+    for (int i = 0; i < PC_COUNT; ++i) { ms_by_class[i] = h->prof.ms[i]; launches_by_class[i] = h->prof.n[i]; }
     return 0;
 }
 

@@ -12,7 +12,7 @@ namespace {
 // MODE 0: adaLN modulate  y = xhat * (1 + (scale + 1e-6)) + shift     (model/dit.py:19-27)
 // MODE 1: affine          y = xhat * gamma + beta                     (nn.LayerNorm, model/vae.py:174)
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int NV>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, int ldx, f16* __restrict__ out, int ldo,
                                                  int M, int D, const float* __restrict__ p0, const float* __restrict__ p1,
                                                  int mod_stride, const int* __restrict__ rows, int rows_per_mod) {
@@ -20,10 +20,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, in
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const float* xr = x + (size_t)m * ldx;
-    f32x4 v[8];
+    f32x4 v[NV];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < D) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, in
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         if (c < D) {
 #pragma unroll
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, in
     }
     f16* orow = out + (size_t)m * ldo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         if (c < D) {
             const f32x4 av = *(const f32x4*)(a + c);
@@ -301,8 +301,14 @@ inline int grid_for(size_t total, int block = 256) {
 int launch_ln_modulate(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
                        int mod_stride, const int* rows, int rows_per_mod, hipStream_t stream) {
     GTAV_REQUIRE(D % 4 == 0 && D <= 2048 && rows_per_mod > 0, "ln_modulate: D=%d must be %%4 and <= 2048", D);
-    hipLaunchKernelGGL(ln_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, ldo, M, D, shift, scale,
-                       mod_stride, rows, rows_per_mod);
+#define LN_LAUNCH(NV)                                                                                            \
+    hipLaunchKernelGGL((ln_kernel<0, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, ldo, M, D, shift, scale, \
+                       mod_stride, rows, rows_per_mod)
+    if (D <= 256) LN_LAUNCH(1);
+    else if (D <= 512) LN_LAUNCH(2);
+    else if (D <= 1024) LN_LAUNCH(4);
+    else LN_LAUNCH(8);
+#undef LN_LAUNCH
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -310,8 +316,14 @@ int launch_ln_modulate(const float* x, int ldx, f16* out, int ldo, int M, int D,
 int launch_ln_affine(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
                      hipStream_t stream) {
     GTAV_REQUIRE(D % 4 == 0 && D <= 2048, "ln_affine: D=%d must be %%4 and <= 2048", D);
-    hipLaunchKernelGGL(ln_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, ldo, M, D, gamma, beta, 0,
-                       (const int*)nullptr, 1);
+#define LN_LAUNCH(NV)                                                                                           \
+    hipLaunchKernelGGL((ln_kernel<1, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, ldo, M, D, gamma, beta, 0, \
+                       (const int*)nullptr, 1)
+    if (D <= 256) LN_LAUNCH(1);
+    else if (D <= 512) LN_LAUNCH(2);
+    else if (D <= 1024) LN_LAUNCH(4);
+    else LN_LAUNCH(8);
+#undef LN_LAUNCH
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -56,6 +56,8 @@ SIGNATURES = {
     "gtav_dit_set_schedule": [_p, C.POINTER(C.c_float), _i],
     "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     "gtav_dit_check": [_p, _p],
+    "gtav_dit_profile": [_p, _i],
+    "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_vae_create": [C.POINTER(VaeConfig), C.POINTER(_p)],
     "gtav_vae_destroy": [_p],
     "gtav_vae_set_weight": [_p, C.c_char_p, _p, _l, _p],

@@ -74,6 +74,14 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x_dev, int32_t B, int32_t F, int32
                           int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions_dev, int32_t mode,
                           float* v_out_dev, void* stream);
 
+/* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
+ * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).
+ * Classes: 0 LN+modulate, 1 QKV GEMM, 2 spatial attention, 3 temporal attention, 4 out-proj GEMM, 5 fc1 GEMM,
+ * 6 fc2 GEMM, 7 other (patchify, embed, final, unpatchify).  Conditioning kernels are not included. */
+#define GTAV_PROFILE_CLASSES 8
+int gtav_dit_profile(gtav_dit* h, int32_t enable);
+int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class);
+
 /* Raises an error if any timestep seen since the last call was outside [0, 999] (synchronises). */
 int gtav_dit_check(gtav_dit* h, void* stream);
 
