@@ -6,9 +6,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace gtav {
@@ -76,7 +78,7 @@ struct WeightTable {
         Slot& sl = it->second;
         GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "set_weight: '%s' has %lld elements, expected %d x %d", name,
                      (long long)numel, sl.R, sl.C);
-        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_convert_pad_f16(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, s));
+        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_convert_pad_f16(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, 1, s));
         else RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, (float*)sl.dst, sl.Cp, sl.c0, s));
         sl.set = true;
         return 0;
@@ -86,7 +88,7 @@ struct WeightTable {
         GTAV_REQUIRE(it != slots.end(), "get_weight: unknown key '%s'", name);
         Slot& sl = it->second;
         GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "get_weight: '%s' size mismatch", name);
-        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_unpad_f16_to_f32((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, s));
+        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_unpad_f16_to_f32((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, 1, s));
         else RET_IF(launch_copy_f32_strided((const float*)sl.dst + sl.c0, sl.Cp, sl.R, sl.C, dst, sl.C, s));
         return 0;
     }
@@ -218,19 +220,37 @@ struct gtav_dit {
     // workspace
     f16 *xp, *xn, *qs, *ks, *vts, *qt, *ao, *hbuf;
     std::vector<f16*> kvcache;  // [L]
-    float *resid, *fo, *vout, *E, *HC, *Sc, *mod;
+    float *resid, *fo, *vout, *E, *HC, *Sc, *mod, *parts;
+    size_t parts_rows = 0;
     int* err_flag = nullptr;
     int* frame_idx = nullptr;   // [maxB * maxT]
+    StepParams* step_dev = nullptr;
+    // captured hipGraphs of the fused sampler step, keyed by (shape, mode, buffers)
+    struct GraphKey {
+        int B, F, T, mode;
+        const void *x, *actions, *vout;
+        bool operator<(const GraphKey& o) const {
+            return std::tie(B, F, T, mode, x, actions, vout) < std::tie(o.B, o.F, o.T, o.mode, o.x, o.actions, o.vout);
+        }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;   // nullptr value = shape seen once (eager warm-up done), not yet captured
+    bool use_graph = true;
+    hipStream_t cap_stream = nullptr;            // private stream the step is captured on (the caller's may be the null stream)
+    ~gtav_dit() {
+        for (auto& kv : graphs)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
     float* ac_table = nullptr;  // alphas_cumprod [1000]
     std::vector<float> ac_host;
     bool finalized = false;
 };
 
-static int dit_cond(gtav_dit* h, const int64_t* t64, int rows, int Tq, int t_ctx, int t_cur, const float* actions,
+static int dit_cond(gtav_dit* h, const int64_t* t64, int rows, int Tq, const StepParams* sp, int use_cur, const float* actions,
                     int64_t act_outer, int64_t act_inner, hipStream_t s) {
     GTAV_REQUIRE(rows <= h->max_rows, "conditioning rows %d exceed max_cond_rows %d", rows, h->max_rows);
     const int ldhc = h->D + h->Apad;
-    RET_IF(launch_cond_inputs(t64, rows, Tq, t_ctx, t_cur, h->sincos, h->E, actions, act_outer, act_inner, h->A, h->HC, ldhc,
+    RET_IF(launch_cond_inputs(t64, rows, Tq, sp, use_cur, h->sincos, h->E, actions, act_outer, act_inner, h->A, h->HC, ldhc,
                               h->D, h->Apad, h->err_flag, s));
     RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, h->HC, ldhc, rows, h->D, 256, 1, s));
     RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, h->Sc, h->D, rows, h->D, ldhc, 1, s));
@@ -248,11 +268,30 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kpe; g.W = h->w_pe; g.M = M; g.N = D; g.K = h->Kpe; g.bias = h->b_pe; g.out = h->resid; g.ldo = D;
     PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    // Residual GEMMs (out-proj, fc2) write split-K partial slabs; the LayerNorm that always follows reduces them and
+    // applies bias + gate + residual (LnPending), so the GEMM epilogue has no read-modify-write and small-M
+    // launches can spread their K loop over all CUs.
+    LnPending pend;
+    bool have_pend = false;
+    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate) -> int {
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
+        q.splitk = gemm_choose_splitk(M, D, K);
+        GTAV_REQUIRE((size_t)q.splitk * M <= h->parts_rows, "split-K slabs exceed workspace");
+        PROF(h, cls, s, launch_gemm(q, EPI_PARTIAL, s));
+        memset(&pend, 0, sizeof(pend));
+        pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * D; pend.ld = D; pend.bias = bias;
+        pend.gate = gate; pend.gate_stride = h->MODW; pend.gate_rows = mod_rows; pend.rows_per_gate = P;
+        have_pend = true;
+        return 0;
+    };
     for (int l = 0; l < h->L; ++l) {
         for (int hf = 0; hf < 2; ++hf) {
             const gtav_dit::Half& w = h->halves[l * 2 + hf];
             const float* mb = mod + (size_t)(l * 2 + hf) * 6 * D;
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, s));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, s));
+            have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
             if (hf == 0) {
@@ -266,22 +305,17 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
             if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
             else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
-            memset(&g, 0, sizeof(g));
-            g.X = h->ao; g.ldx = D; g.W = w.w_out; g.M = M; g.N = D; g.K = D; g.bias = w.b_out; g.out = h->resid; g.ldo = D;
-            g.gate = mb + 2 * D; g.gate_stride = h->MODW; g.gate_rows = mod_rows; g.rows_per_gate = P;
-            PROF(h, PC_OUT, s, launch_gemm(g, EPI_RESID, s));
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, s));
+            RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, &pend, s));
+            have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad;
             PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
-            memset(&g, 0, sizeof(g));
-            g.X = h->hbuf; g.ldx = h->Hm_pad; g.W = w.w_fc2; g.M = M; g.N = D; g.K = h->Hm_pad; g.bias = w.b_fc2; g.out = h->resid; g.ldo = D;
-            g.gate = mb + 5 * D; g.gate_stride = h->MODW; g.gate_rows = mod_rows; g.rows_per_gate = P;
-            PROF(h, PC_FC2, s, launch_gemm(g, EPI_RESID, s));
+            RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D));
         }
     }
     const float* mf = mod + (size_t)h->L * 12 * D;
-    PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, s));
+    PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
     PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
@@ -375,16 +409,20 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->freqs_s_dev, 16)); wt.add_f32("spatial_rotary_emb.freqs", 1, 16, h->freqs_s_dev, 16, 0, false);
     A_(a.alloc_t(&h->freqs_t_dev, 32)); wt.add_f32("temporal_rotary_emb.freqs", 1, 32, h->freqs_t_dev, 32, 0, false);
     // workspace
-    const size_t Mx = h->Mmax;
+    const size_t Mx = round_up(h->Mmax, 128);   // tile-major A-operands: rows padded to the 128-row tile
     A_(a.alloc_t(&h->xp, Mx * h->Kpe)); A_(a.alloc_t(&h->xn, Mx * D)); A_(a.alloc_t(&h->qs, Mx * D)); A_(a.alloc_t(&h->ks, Mx * D));
     A_(a.alloc_t(&h->vts, Mx * D)); A_(a.alloc_t(&h->qt, Mx * D)); A_(a.alloc_t(&h->ao, Mx * D)); A_(a.alloc_t(&h->hbuf, Mx * h->Hm_pad));
     h->kvcache.resize(h->L);
     for (int l = 0; l < h->L; ++l) A_(a.alloc_t(&h->kvcache[l], Mx * 2 * D));
     A_(a.alloc_t(&h->resid, Mx * D)); A_(a.alloc_t(&h->fo, Mx * h->Nfin));
     A_(a.alloc_t(&h->vout, Mx / h->P * h->C * h->H * h->W));
+    h->parts_rows = Mx > 8192 ? Mx : 8192;   // split-K slabs: splitk * M rows (splitk * M <= ~6.2 K rows when splitk > 1)
+    A_(a.alloc_t(&h->parts, h->parts_rows * D));
     const size_t R = h->max_rows;
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
     A_(a.alloc_t(&h->err_flag, 4)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
+    A_(a.alloc_t(&h->step_dev, 4));
+    if (const char* e = getenv("GTAV_GRAPH")) h->use_graph = atoi(e) != 0;
 #undef A_
     if (rc) {
         delete h;
@@ -465,7 +503,7 @@ int gtav_dit_forward(gtav_dit* h, const float* x, const int64_t* t, const float*
     GTAV_REQUIRE(B >= 1 && B <= h->maxB && T >= 1 && T <= h->maxT, "dit_forward: B=%d T=%d outside capacity (%d, %d)", B, T, h->maxB, h->maxT);
     GTAV_REQUIRE(!actions || h->A > 0, "dit_forward: model has no external_cond");
     hipStream_t s = (hipStream_t)stream;
-    RET_IF(dit_cond(h, t, B * T, 1, 0, 0, actions, h->A, 0, s));
+    RET_IF(dit_cond(h, t, B * T, 1, nullptr, 0, actions, h->A, 0, s));
     return dit_forward_core(h, x, nullptr, B, T, 0, h->mod, nullptr, out, s);
 }
 
@@ -473,6 +511,21 @@ int gtav_dit_set_schedule(gtav_dit* h, const float* ac, int32_t n) {
     GTAV_REQUIRE(h && ac && n == 1000, "dit_set_schedule: expected 1000 alphas_cumprod values");
     h->ac_host.assign(ac, ac + n);
     GTAV_CHECK_HIP(hipMemcpy(h->ac_table, ac, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// the kernel sequence of one fused sampler step; every step-varying scalar is read from h->step_dev
+static int denoise_step_body(gtav_dit* h, float* x, int B, int F, int T, const float* actions, int mode, float* v_out,
+                             hipStream_t s) {
+    const size_t fsz = (size_t)h->C * h->H * h->W;
+    const int Tq = mode == 1 ? 1 : T, t0 = mode == 1 ? T - 1 : 0;
+    RET_IF(launch_frame_index(h->frame_idx, B, Tq, F, h->step_dev, mode == 1, s));
+    RET_IF(dit_cond(h, nullptr, B * Tq, Tq, h->step_dev, mode == 1, actions, (int64_t)F * h->A, h->A, s));
+    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, h->mod, nullptr, h->vout, s));
+    // DDIM update of frame `cur` (train_dit.py:110-125, generate.py:220)
+    const float* vlast = h->vout + (size_t)(Tq - 1) * fsz;
+    RET_IF(launch_ddim_update_step(x, F, vlast, (size_t)Tq * fsz, B, (int)fsz, h->step_dev, s));
+    if (v_out) RET_IF(launch_copy_rows_f32(vlast, (size_t)Tq * fsz, v_out, fsz, B, fsz, s));
     return 0;
 }
 
@@ -485,19 +538,64 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
     GTAV_REQUIRE(start >= 0 && cur < F && T >= 1 && T <= h->maxT && B >= 1 && B <= h->maxB, "denoise_step: bad window [%d, %d] of %d frames", start, cur, F);
     GTAV_REQUIRE(t_cur >= 0 && t_cur < 1000 && t_next >= 0 && t_next < 1000 && t_ctx >= 0 && t_ctx < 1000, "denoise_step: timestep out of range");
     GTAV_REQUIRE(!actions || h->A > 0, "denoise_step: model has no external_cond");
+    GTAV_REQUIRE(mode == 0 || mode == 1, "denoise_step: mode %d", mode);
     hipStream_t s = (hipStream_t)stream;
-    const size_t fsz = (size_t)h->C * h->H * h->W;
-    const int Tq = mode == 1 ? 1 : T, t0 = mode == 1 ? T - 1 : 0;
-    // frame indices of the processed frames inside x (B, F, ...)
-    RET_IF(launch_frame_index(h->frame_idx, B, Tq, F, mode == 1 ? cur : start, s));
-    const float* act = actions ? actions + (size_t)(mode == 1 ? cur : start) * h->A : nullptr;
-    RET_IF(dit_cond(h, nullptr, B * Tq, Tq, t_ctx, t_cur, act, (int64_t)F * h->A, h->A, s));
-    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, h->mod, nullptr, h->vout, s));
-    // DDIM update of frame `cur` (train_dit.py:110-125, generate.py:220)
-    const float* vlast = h->vout + (size_t)(Tq - 1) * fsz;
-    RET_IF(launch_ddim_update(x + (size_t)cur * fsz, (size_t)F * fsz, vlast, (size_t)Tq * fsz, x + (size_t)cur * fsz, (size_t)F * fsz,
-                              B, (int)fsz, nullptr, nullptr, h->ac_host[t_cur], h->ac_host[t_next], is_final, s));
-    if (v_out) RET_IF(launch_copy_rows_f32(vlast, (size_t)Tq * fsz, v_out, fsz, B, fsz, s));
+    StepParams sp;
+    sp.first = start; sp.cur = cur; sp.t_ctx = t_ctx; sp.t_cur = t_cur; sp.is_final = is_final != 0;
+    sp.alpha_t = h->ac_host[t_cur]; sp.alpha_next = h->ac_host[t_next]; sp.pad = 0;
+    RET_IF(launch_set_step(h->step_dev, sp, s));
+    if (!h->use_graph || h->prof.on) return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+
+    // hipGraph path: the first step of a new (shape, buffers) key runs eagerly (warm-up: lazy module load, function
+    // attributes), the second one is captured, later ones replay the captured graph (~240 kernel nodes, one launch).
+    gtav_dit::GraphKey key{B, F, T, mode, x, actions, v_out};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        if (h->graphs.size() > 64) {
+            for (auto& kv : h->graphs)
+                if (kv.second) (void)hipGraphExecDestroy(kv.second);
+            h->graphs.clear();
+        }
+        h->graphs[key] = nullptr;
+        return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+    }
+    if (!it->second) {
+        // capture on a private non-blocking stream (stream capture is not permitted on the legacy null stream, which is
+        // what torch hands out by default); nothing executes during capture, the graph is launched on the caller's stream
+        if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+            h->use_graph = false;
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+        }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            h->use_graph = false;
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+        }
+        const int rc = denoise_step_body(h, x, B, F, T, actions, mode, v_out, h->cap_stream);
+        const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+        if (rc || ce != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            h->use_graph = false;  // capture is not available here: fall back to eager launches for good
+            if (rc) return rc;
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess || !exec) {
+            h->use_graph = false;
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+        }
+        it->second = exec;
+    }
+    GTAV_CHECK_HIP(hipGraphLaunch(it->second, s));
+    return 0;
+}
+
+int gtav_dit_set_graph(gtav_dit* h, int32_t enable) {
+    GTAV_REQUIRE(h, "dit_set_graph: null handle");
+    h->use_graph = enable != 0;
     return 0;
 }
 
@@ -540,33 +638,48 @@ struct gtav_vae {
     float *b_patch, *b_quant, *b_post, *b_pred, *g_enc, *be_enc, *g_dec, *be_dec;
     RopeTable rope_e, rope_d;
     f16 *xp, *xn, *q, *k, *vt, *ao, *hbuf, *zin;
-    float *resid, *po;
+    float *resid, *po, *parts;
+    size_t parts_rows = 0;
     bool finalized = false;
 };
 
 static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim, int heads, const RopeTable& rope, int N,
-                      hipStream_t s) {
+                      const float* g_last, const float* b_last, hipStream_t s) {
+    // pre-LN blocks (model/vae.py:154-157); residual GEMMs are deferred into the next LayerNorm (see dit_forward_core),
+    // the trailing enc_norm / dec_norm (g_last, b_last) consumes the last one and leaves LN(x) in h->xn.
     const int M = N * h->S, Hm = (int)(dim * h->cfg.mlp_ratio), Hm_pad = round_up(Hm, 128);
     GemmParams g;
+    LnPending pend;
+    bool have_pend = false;
+    auto resid_gemm = [&](const f16* X, int ldx, const f16* Wt, int K, const float* bias) -> int {
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = dim; q.K = K; q.out = h->parts; q.ldo = dim;
+        q.splitk = gemm_choose_splitk(M, dim, K);
+        GTAV_REQUIRE((size_t)q.splitk * M <= h->parts_rows, "split-K slabs exceed workspace");
+        RET_IF(launch_gemm(q, EPI_PARTIAL, s));
+        memset(&pend, 0, sizeof(pend));
+        pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * dim; pend.ld = dim; pend.bias = bias;
+        have_pend = true;
+        return 0;
+    };
     for (auto& b : blocks) {
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, s));
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, s));
+        have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_qkv; g.M = M; g.N = 3 * dim; g.K = dim; g.bias = b.b_qkv; g.D = dim; g.S = h->S;
         g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cos = rope.cos_dev; g.rope_sin = rope.sin_dev;
         RET_IF(launch_gemm(g, EPI_QKV, s));
         RET_IF(launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s));
-        memset(&g, 0, sizeof(g));
-        g.X = h->ao; g.ldx = dim; g.W = b.w_proj; g.M = M; g.N = dim; g.K = dim; g.bias = b.b_proj; g.out = h->resid; g.ldo = dim;
-        RET_IF(launch_gemm(g, EPI_RESID, s));
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, s));
+        RET_IF(resid_gemm(h->ao, dim, b.w_proj, dim, b.b_proj));
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, &pend, s));
+        have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad;
         RET_IF(launch_gemm(g, EPI_GELU_ERF, s));
-        memset(&g, 0, sizeof(g));
-        g.X = h->hbuf; g.ldx = Hm_pad; g.W = b.w_fc2; g.M = M; g.N = dim; g.K = Hm_pad; g.bias = b.b_fc2; g.out = h->resid; g.ldo = dim;
-        RET_IF(launch_gemm(g, EPI_RESID, s));
+        RET_IF(resid_gemm(h->hbuf, Hm_pad, b.w_fc2, Hm_pad, b.b_fc2));
     }
-    return 0;
+    return launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, s);
 }
 
 extern "C" {
@@ -635,10 +748,12 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->rope_e.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_enc_sin", h->S, 64, h->rope_e.sin_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_d.cos_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_cos", h->S, 64, h->rope_d.cos_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_d.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_sin", h->S, 64, h->rope_d.sin_dev, 64, 0, false);
-    const size_t Mx = h->Mmax, Dm = h->Dmax;
+    const size_t Mx = round_up(h->Mmax, 128), Dm = h->Dmax;
     A_(a.alloc_t(&h->xp, Mx * h->Kp)); A_(a.alloc_t(&h->xn, Mx * Dm)); A_(a.alloc_t(&h->q, Mx * Dm)); A_(a.alloc_t(&h->k, Mx * Dm));
     A_(a.alloc_t(&h->vt, Mx * Dm)); A_(a.alloc_t(&h->ao, Mx * Dm)); A_(a.alloc_t(&h->hbuf, Mx * h->Hmax)); A_(a.alloc_t(&h->zin, Mx * 64));
     A_(a.alloc_t(&h->resid, Mx * Dm)); A_(a.alloc_t(&h->po, Mx * h->Npred));
+    h->parts_rows = Mx > 8192 ? Mx : 8192;
+    A_(a.alloc_t(&h->parts, h->parts_rows * Dm));
 #undef A_
     if (rc) {
         delete h;
@@ -690,8 +805,7 @@ int gtav_vae_encode(gtav_vae* h, const float* img, float in_scale, float in_shif
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kp; g.W = h->w_patch; g.M = M; g.N = De; g.K = h->Kp; g.bias = h->b_patch; g.out = h->resid; g.ldo = De;
     RET_IF(launch_gemm(g, EPI_F32, s));
-    RET_IF(vae_blocks(h, h->enc, De, h->cfg.enc_heads, h->rope_e, N, s));
-    RET_IF(launch_ln_affine(h->resid, De, h->xn, De, M, De, h->g_enc, h->be_enc, s));
+    RET_IF(vae_blocks(h, h->enc, De, h->cfg.enc_heads, h->rope_e, N, h->g_enc, h->be_enc, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = De; g.W = h->w_quant; g.M = M; g.N = h->Mom; g.K = De; g.bias = h->b_quant; g.out = moments; g.ldo = h->Mom;
     RET_IF(launch_gemm(g, EPI_F32, s));
@@ -706,13 +820,12 @@ int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, floa
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_decode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int Dd = h->cfg.dec_dim, M = N * h->S;
-    RET_IF(launch_convert_pad_f16(z, h->Lat, M, h->Lat, h->zin, M, 64, z_scale, s));
+    RET_IF(launch_convert_pad_f16(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->zin; g.ldx = 64; g.W = h->w_post; g.M = M; g.N = Dd; g.K = 64; g.bias = h->b_post; g.out = h->resid; g.ldo = Dd;
     RET_IF(launch_gemm(g, EPI_F32, s));
-    RET_IF(vae_blocks(h, h->dec, Dd, h->cfg.dec_heads, h->rope_d, N, s));
-    RET_IF(launch_ln_affine(h->resid, Dd, h->xn, Dd, M, Dd, h->g_dec, h->be_dec, s));
+    RET_IF(vae_blocks(h, h->dec, Dd, h->cfg.dec_heads, h->rope_d, N, h->g_dec, h->be_dec, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = Dd; g.W = h->w_pred; g.M = M; g.N = h->Npred; g.K = Dd; g.bias = h->b_pred; g.out = h->po; g.ldo = h->Npred;
     RET_IF(launch_gemm(g, EPI_F32, s));
@@ -726,7 +839,7 @@ int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, floa
 int gtav_ddim_update(const float* x, const float* v, float* out, int32_t rows, int32_t n, const float* alpha_t,
                      const float* alpha_next, int32_t is_final, void* stream) {
     GTAV_REQUIRE(x && v && out && alpha_t && (alpha_next || is_final), "ddim_update: null argument");
-    return launch_ddim_update(x, n, v, n, out, n, rows, n, alpha_t, alpha_next, 0.f, 0.f, is_final, (hipStream_t)stream);
+    return launch_ddim_update(x, n, v, n, out, n, rows, n, alpha_t, alpha_next, is_final, (hipStream_t)stream);
 }
 int gtav_add_noise(const float* x, const float* noise, const float* alpha, float* out, int32_t rows, int32_t n, float clamp_abs,
                    void* stream) {
@@ -755,9 +868,10 @@ int gtav_latents_to_tokens(const float* lat, float* z, int32_t N, int32_t hw, in
 // ------------------------------------------------------------------------------------------------
 int gtav_op_gemm_f16(const void* x, int32_t ldx, const void* w, const float* bias, void* out, int32_t ldo, int32_t M, int32_t N,
                      int32_t K, int32_t epilogue, const float* gate, int32_t gate_stride, int32_t rows_per_gate, void* stream) {
-    GTAV_REQUIRE(epilogue >= 0 && epilogue <= 4, "op_gemm_f16: epilogue %d", epilogue);
+    GTAV_REQUIRE((epilogue >= 0 && epilogue <= 4) || epilogue == EPI_PARTIAL, "op_gemm_f16: epilogue %d", epilogue);
     GemmParams g;
     memset(&g, 0, sizeof(g));
+    if (epilogue == EPI_PARTIAL) g.splitk = gate_stride > 0 ? gate_stride : 1;  // split-K factor travels in gate_stride
     g.X = (const f16*)x; g.ldx = ldx; g.W = (const f16*)w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.gate = gate; g.gate_stride = gate_stride; g.rows_per_gate = rows_per_gate;
     return launch_gemm(g, epilogue, (hipStream_t)stream);
@@ -779,10 +893,10 @@ int gtav_op_skinny_f32(const float* x, int32_t ldx, const float* w, const float*
 }
 int gtav_op_ln_modulate(const float* x, void* out, int32_t M, int32_t D, const float* shift, const float* scale,
                         int32_t mod_stride, int32_t rows_per_mod, void* stream) {
-    return launch_ln_modulate(x, D, (f16*)out, D, M, D, shift, scale, mod_stride, nullptr, rows_per_mod, (hipStream_t)stream);
+    return launch_ln_modulate((float*)x, D, (f16*)out, D, M, D, shift, scale, mod_stride, nullptr, rows_per_mod, nullptr, (hipStream_t)stream);
 }
 int gtav_op_ln_affine(const float* x, void* out, int32_t M, int32_t D, const float* gamma, const float* beta, void* stream) {
-    return launch_ln_affine(x, D, (f16*)out, D, M, D, gamma, beta, (hipStream_t)stream);
+    return launch_ln_affine((float*)x, D, (f16*)out, D, M, D, gamma, beta, nullptr, (hipStream_t)stream);
 }
 int gtav_op_attn_spatial(const void* q, const void* k, const void* vt, void* o, int32_t NB, int32_t heads, int32_t S, void* stream) {
     return launch_attn_spatial((const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, NB, heads, S, (hipStream_t)stream);
@@ -791,8 +905,28 @@ int gtav_op_attn_temporal(const void* q, const void* kv, void* o, int32_t B, int
                           int32_t Tmax, void* stream) {
     return launch_attn_temporal((const f16*)q, (const f16*)kv, (f16*)o, B, P, D, Tq, t0, Tmax, (hipStream_t)stream);
 }
-int gtav_op_convert_f16(const float* src, int32_t lds, int32_t R, int32_t C, void* dst, int32_t Rp, int32_t Cp, void* stream) {
-    return launch_convert_pad_f16(src, lds, R, C, (f16*)dst, Rp, Cp, 1.0f, (hipStream_t)stream);
+int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t N, int32_t K,
+                           int32_t splitk, float* parts, float* resid, const float* gate, int32_t gate_stride,
+                           int32_t rows_per_gate, void* out_f16, const float* shift, const float* scale, int32_t mod_stride,
+                           void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)x; g.ldx = ldx; g.W = (const f16*)w; g.M = M; g.N = N; g.K = K; g.out = parts; g.ldo = N;
+    g.splitk = splitk > 0 ? splitk : gemm_choose_splitk(M, N, K);
+    RET_IF(launch_gemm(g, EPI_PARTIAL, (hipStream_t)stream));
+    LnPending pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.parts = parts; pd.nsplit = g.splitk; pd.slab_stride = (size_t)M * N; pd.ld = N; pd.bias = bias; pd.gate = gate;
+    pd.gate_stride = gate_stride; pd.rows_per_gate = rows_per_gate;
+    return launch_ln_modulate(resid, N, (f16*)out_f16, N, M, N, shift, scale, mod_stride, nullptr, rows_per_gate, &pd, (hipStream_t)stream);
+}
+int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K) { return gemm_choose_splitk(M, N, K); }
+void gtav_op_gemm_set_stages(int32_t ns) { gemm_set_stages(ns); }
+void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }
+
+int gtav_op_convert_f16(const float* src, int32_t lds, int32_t R, int32_t C, void* dst, int32_t Rp, int32_t Cp, int32_t tiled,
+                        void* stream) {
+    return launch_convert_pad_f16(src, lds, R, C, (f16*)dst, Rp, Cp, 1.0f, tiled, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -138,13 +138,13 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
         lt = lt + __shfl_xor(lt, 32, 64);
         const float inv = 1.0f / lt;
         if (q0 + li < S) {
-            f16* orow = O + ((size_t)nb * S + q0 + li) * Dm + head * 64;
+            const int mrow = nb * S + q0 + li;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 f16x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = (f16)(o[dt][r] * inv);
-                *(f16x4*)(orow + dt * 16 + 4 * g) = h;
+                *(f16x4*)(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm)) = h;
             }
         }
     }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restric
         f16x4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = (f16)(acc[e] * inv);
-        *(f16x4*)(O + row * D + c) = o4;
+        *(f16x4*)(O + tiled_off((int)row, c, D)) = o4;
     }
 }
 

@@ -39,6 +39,18 @@ const char* last_error();
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
+// ---- tile-major fp16 operand layout of the GEMM ---------------------------------------------
+// A [rows][K] fp16 GEMM operand (activations X or weights W) is stored as contiguous 16 KiB tiles of
+// 128 rows x 64 k, tile (r / 128, k / 64) at ((r / 128) * (K / 64) + k / 64) * 8192 halves, and INSIDE a tile in
+// the exact LDS image the kernel wants: row-major 128-byte rows whose 16-byte chunk c sits at c ^ (row & 7)
+// (the ds_read_b128 bank swizzle).  Every direct-to-LDS instruction then copies 1 KiB of contiguous memory
+// (no power-of-two row stride -> no L2-channel hot spots) and a K-panel of a tile row is one linear stream.
+// rows are padded to 128, K to 64.  Offset in halves of element (r, k):
+__host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
+    return ((size_t)(r >> 7) * (size_t)(K >> 6) + (size_t)(k >> 6)) * 8192 + (size_t)((r & 127) * 64) +
+           (size_t)(((((k >> 3) & 7) ^ (r & 7)) << 3) + (k & 7));
+}
+
 // ---- small device math ------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 

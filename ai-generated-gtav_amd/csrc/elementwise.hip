@@ -3,49 +3,63 @@
 // All are HBM-bound; every global access is 8-16 B per lane, rows are walked by whole waves.
 #include "ops.h"
 
+#include <cstring>
+
 namespace gtav {
 
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm (eps 1e-6) over D, one wave per row, row kept in registers (D <= 2048, D % 4 == 0).
+// LayerNorm (eps 1e-6) over D, ONE BLOCK PER ROW (D/4 threads, one float4 each; D % 256 == 0 or D < 256), two-pass
+// fp32 statistics through LDS.  Optional deferred residual update first (LnPending): all slab/bias/gate loads of a
+// thread are independent and issued together, so the kernel is bandwidth- not latency-bound at small M.
 // MODE 0: adaLN modulate  y = xhat * (1 + (scale + 1e-6)) + shift     (model/dit.py:19-27)
 // MODE 1: affine          y = xhat * gamma + beta                     (nn.LayerNorm, model/vae.py:174)
+// Output: fp16, tile-major (GEMM A-operand).
 // ------------------------------------------------------------------------------------------
-template <int MODE, int NV>
-__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, int ldx, f16* __restrict__ out, int ldo,
-                                                 int M, int D, const float* __restrict__ p0, const float* __restrict__ p1,
-                                                 int mod_stride, const int* __restrict__ rows, int rows_per_mod) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const float* xr = x + (size_t)m * ldx;
-    f32x4 v[NV];
-    float sum = 0.f;
+template <int MODE, bool PEND>
+__global__ __launch_bounds__(512) void ln_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
+                                                 const float* __restrict__ p0, const float* __restrict__ p1, int mod_stride,
+                                                 const int* __restrict__ rows, int rows_per_mod, LnPending pd) {
+    __shared__ float red[16];
+    const int m = blockIdx.x;
+    const int c = threadIdx.x * 4;
+    const int nw = (blockDim.x + 63) >> 6, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* xr = x + (size_t)m * ldx;
+    const bool act = c < D;   // blocks are padded to whole waves (D / 4 may be < 64): idle lanes carry zeros
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (act) v = *(const f32x4*)(xr + c);
+    if (PEND && act) {
+        f32x4 part[8];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < D) {
-            v[i] = *(const f32x4*)(xr + c);
-            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        for (int sp = 0; sp < 8; ++sp)
+            if (sp < pd.nsplit) part[sp] = *(const f32x4*)(pd.parts + (size_t)sp * pd.slab_stride + (size_t)m * pd.ld + c);
+        f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 gt = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (pd.gate) {
+            int gr = m / pd.rows_per_gate;
+            if (pd.gate_rows) gr = pd.gate_rows[gr];
+            gt = *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
         }
-    }
-    const float mean = wave_sum(sum) / (float)D;
-    float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
-            }
-        }
+        for (int sp = 0; sp < 8; ++sp)
+            if (sp < pd.nsplit) y = y + part[sp];
+        v = v + gt * y;
+        *(f32x4*)(xr + c) = v;
     }
-    const float var = wave_sum(sq) / (float)D;
-    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    float s = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += red[i];
+    const float mean = tot / (float)D;
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    float q = wave_sum(act ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f);
+    if (lane == 0) red[8 + wid] = q;
+    __syncthreads();
+    float tq = 0.f;
+    for (int i = 0; i < nw; ++i) tq += red[8 + i];
+    const float rstd = 1.0f / sqrtf(tq / (float)D + 1e-6f);
     const float *a, *b;  // MODE 0: a = scale row, b = shift row; MODE 1: a = gamma, b = beta
     if (MODE == 0) {
         int row = m / rows_per_mod;
@@ -56,29 +70,24 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, in
         a = p0;
         b = p1;
     }
-    f16* orow = out + (size_t)m * ldo;
+    if (!act) return;
+    const f32x4 av = *(const f32x4*)(a + c);
+    const f32x4 bv = *(const f32x4*)(b + c);
+    const float dd[4] = {d0, d1, d2, d3};
+    f16x4 o;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-            const f32x4 av = *(const f32x4*)(a + c);
-            const f32x4 bv = *(const f32x4*)(b + c);
-            f16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (v[i][e] - mean) * rstd;
-                float y;
-                if (MODE == 0) {
-                    const float sc = av[e] + 1e-6f;
-                    y = xh * (1.0f + sc) + bv[e];
-                } else {
-                    y = xh * av[e] + bv[e];
-                }
-                o[e] = (f16)y;
-            }
-            *(f16x4*)(orow + c) = o;
+    for (int e = 0; e < 4; ++e) {
+        const float xh = dd[e] * rstd;
+        float y;
+        if (MODE == 0) {
+            const float sc = av[e] + 1e-6f;
+            y = xh * (1.0f + sc) + bv[e];
+        } else {
+            y = xh * av[e] + bv[e];
         }
+        o[e] = (f16)y;
     }
+    *(f16x4*)(out + tiled_off(m, c, D)) = o;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -96,7 +105,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, const int* __rest
             const int f = frame_index ? frame_index[nb] : nb;
             val = a * img[(((size_t)f * C + c) * H + (y * p + ph)) * W + (x * p + pw)] + b;
         }
-        out[idx] = (f16)val;
+        out[tiled_off((int)m, k, ldo)] = (f16)val;
     }
 }
 
@@ -115,14 +124,14 @@ __global__ void unpatchify_kernel(const float* __restrict__ y, int ldy, float* _
 }
 
 __global__ void convert_pad_f16_kernel(const float* __restrict__ src, int lds, int R, int C, f16* __restrict__ dst, int Rp,
-                                       int Cp, float scale) {
+                                       int Cp, float scale, int tiled) {
     const size_t total = (size_t)Rp * Cp;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % Cp);
         const size_t r = idx / Cp;
         float v = 0.f;
         if (r < (size_t)R && c < C) v = src[r * lds + c] * scale;
-        dst[idx] = (f16)v;
+        dst[tiled ? tiled_off((int)r, c, Cp) : idx] = (f16)v;
     }
 }
 
@@ -144,42 +153,59 @@ __global__ void add_f32_kernel(const float* a, const float* b, float* out, size_
         out[idx] = a[idx] + b[idx];
 }
 
-__global__ void cond_inputs_kernel(const int64_t* __restrict__ t64, int rows, int Tq, int t_ctx, int t_cur,
+__global__ void set_step_kernel(StepParams* dst, StepParams v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+
+__global__ void cond_inputs_kernel(const int64_t* __restrict__ t64, int rows, int Tq, const StepParams* __restrict__ sp, int use_cur,
                                    const float* __restrict__ sincos, float* __restrict__ E, const float* __restrict__ actions,
                                    long long act_outer, long long act_inner, int A, float* __restrict__ HC, int ldhc, int D,
                                    int Apad, int* err_flag) {
     const int r = blockIdx.x;
     if (r >= rows) return;
     const int ro = r / Tq, ri = r - ro * Tq;
-    long long t = t64 ? (long long)t64[r] : (long long)(ri == Tq - 1 ? t_cur : t_ctx);
+    long long t;
+    int frame0 = 0;
+    if (t64) {
+        t = (long long)t64[r];
+    } else {
+        t = ri == Tq - 1 ? sp->t_cur : sp->t_ctx;
+        frame0 = use_cur ? sp->cur : sp->first;
+    }
     if (t < 0 || t > 999) {
         if (threadIdx.x == 0 && err_flag) atomicOr(err_flag, 1);
         t = t < 0 ? 0 : 999;
     }
     for (int j = threadIdx.x; j < 256; j += blockDim.x) E[(size_t)r * 256 + j] = sincos[(size_t)t * 256 + j];
-    const float* arow = actions ? actions + ro * act_outer + ri * act_inner : nullptr;
+    const float* arow = actions ? actions + ro * act_outer + (frame0 + ri) * act_inner : nullptr;
     for (int j = threadIdx.x; j < Apad; j += blockDim.x) HC[(size_t)r * ldhc + D + j] = (arow && j < A) ? arow[j] : 0.f;
+}
+
+__device__ __forceinline__ float ddim_one(float xc, float vp, float at, float an, int is_final) {
+    const float x0 = sqrtf(at) * xc - sqrtf(1.0f - at) * vp;
+    if (is_final) return x0;
+    const float eps = (sqrtf(1.0f / at) * xc - x0) / sqrtf(1.0f / at - 1.0f);
+    return sqrtf(an) * x0 + sqrtf(1.0f - an) * eps;
 }
 
 __global__ void ddim_update_kernel(const float* __restrict__ x, size_t x_stride, const float* __restrict__ v, size_t v_stride,
                                    float* __restrict__ out, size_t out_stride, int n, const float* __restrict__ alpha_t,
-                                   const float* __restrict__ alpha_next, float at_s, float an_s, int is_final) {
+                                   const float* __restrict__ alpha_next, int is_final) {
     const int b = blockIdx.y;
-    const float at = alpha_t ? alpha_t[b] : at_s;
-    const float an = alpha_t ? (alpha_next ? alpha_next[b] : 1.f) : an_s;
-    const float s_at = sqrtf(at), s_1at = sqrtf(1.0f - at);
-    const float s_rat = sqrtf(1.0f / at), s_den = sqrtf(1.0f / at - 1.0f);
-    const float s_an = sqrtf(an), s_1an = sqrtf(1.0f - an);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float xc = x[b * x_stride + i], vp = v[b * v_stride + i];
-        const float x0 = s_at * xc - s_1at * vp;
-        float r = x0;
-        if (!is_final) {
-            const float eps = (s_rat * xc - x0) / s_den;
-            r = s_an * x0 + s_1an * eps;
-        }
-        out[b * out_stride + i] = r;
-    }
+    const float at = alpha_t[b];
+    const float an = alpha_next ? alpha_next[b] : 1.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[b * out_stride + i] = ddim_one(x[b * x_stride + i], v[b * v_stride + i], at, an, is_final);
+}
+
+__global__ void ddim_update_step_kernel(float* __restrict__ x, size_t frames_per_sample, const float* __restrict__ v,
+                                        size_t v_stride, int n, const StepParams* __restrict__ sp) {
+    const int b = blockIdx.y;
+    const float at = sp->alpha_t, an = sp->alpha_next;
+    const int fin = sp->is_final;
+    float* xf = x + ((size_t)b * frames_per_sample + sp->cur) * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        xf[i] = ddim_one(xf[i], v[b * v_stride + i], at, an, fin);
 }
 
 __global__ void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ alpha,
@@ -229,12 +255,12 @@ __global__ void mse_final_kernel(const float* partial, int rows, float inv_count
     }
 }
 
-__global__ void unpad_f16_kernel(const f16* __restrict__ src, int lds, int R, int C, float* __restrict__ dst) {
+__global__ void unpad_f16_kernel(const f16* __restrict__ src, int lds, int R, int C, float* __restrict__ dst, int tiled) {
     const size_t total = (size_t)R * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
         const size_t r = idx / C;
-        dst[idx] = (float)src[r * lds + c];
+        dst[idx] = (float)src[tiled ? tiled_off((int)r, c, lds) : r * lds + c];
     }
 }
 __global__ void copy_rows_kernel(const float* __restrict__ src, size_t ss, float* __restrict__ dst, size_t ds, size_t n) {
@@ -252,8 +278,9 @@ __global__ void clamp_cols_kernel(float* buf, int M, int ld, int c0, int c1, flo
         buf[m * ld + c] = fminf(fmaxf(v, lo), hi);
     }
 }
-__global__ void frame_index_kernel(int* idx, int B, int Tq, int F, int first) {
+__global__ void frame_index_kernel(int* idx, int B, int Tq, int F, const StepParams* __restrict__ sp, int use_cur) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int first = use_cur ? sp->cur : sp->first;
     if (i < B * Tq) idx[i] = (i / Tq) * F + first + (i % Tq);
 }
 // (N,3,H,W) f32 -> (N,H,W,3) u8 = clamp(img*255, 0, 255) truncated (torch .byte())
@@ -298,35 +325,36 @@ inline int grid_for(size_t total, int block = 256) {
 
 }  // namespace
 
-int launch_ln_modulate(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
-                       int mod_stride, const int* rows, int rows_per_mod, hipStream_t stream) {
-    GTAV_REQUIRE(D % 4 == 0 && D <= 2048 && rows_per_mod > 0, "ln_modulate: D=%d must be %%4 and <= 2048", D);
-#define LN_LAUNCH(NV)                                                                                            \
-    hipLaunchKernelGGL((ln_kernel<0, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, ldo, M, D, shift, scale, \
-                       mod_stride, rows, rows_per_mod)
-    if (D <= 256) LN_LAUNCH(1);
-    else if (D <= 512) LN_LAUNCH(2);
-    else if (D <= 1024) LN_LAUNCH(4);
-    else LN_LAUNCH(8);
-#undef LN_LAUNCH
+#define LN_DISPATCH(MODE, P0, P1, STRIDE, ROWS, RPM)                                                                      \
+    do {                                                                                                               \
+        LnPending pd_;                                                                                                 \
+        memset(&pd_, 0, sizeof(pd_));                                                                                  \
+        if (pend) pd_ = *pend;                                                                                         \
+        const dim3 grid_(M), block_(round_up(D / 4, 64));                                                              \
+        if (pend) hipLaunchKernelGGL((ln_kernel<MODE, true>), grid_, block_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
+        else hipLaunchKernelGGL((ln_kernel<MODE, false>), grid_, block_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
+    } while (0)
+
+int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
+                       int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, hipStream_t stream) {
+    GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && rows_per_mod > 0 && ldo == D, "ln_modulate: D=%d must be %%64, <= 2048, ldo == D", D);
+    GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
+                 "ln_modulate: bad pending update");
+    LN_DISPATCH(0, shift, scale, mod_stride, rows, rows_per_mod);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_ln_affine(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
-                     hipStream_t stream) {
-    GTAV_REQUIRE(D % 4 == 0 && D <= 2048, "ln_affine: D=%d must be %%4 and <= 2048", D);
-#define LN_LAUNCH(NV)                                                                                           \
-    hipLaunchKernelGGL((ln_kernel<1, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, ldo, M, D, gamma, beta, 0, \
-                       (const int*)nullptr, 1)
-    if (D <= 256) LN_LAUNCH(1);
-    else if (D <= 512) LN_LAUNCH(2);
-    else if (D <= 1024) LN_LAUNCH(4);
-    else LN_LAUNCH(8);
-#undef LN_LAUNCH
+int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
+                     const LnPending* pend, hipStream_t stream) {
+    GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && ldo == D, "ln_affine: D=%d must be %%64, <= 2048, ldo == D", D);
+    GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
+                 "ln_affine: bad pending update");
+    LN_DISPATCH(1, gamma, beta, 0, (const int*)nullptr, 1);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
+#undef LN_DISPATCH
 
 int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo,
                     float a, float b, hipStream_t stream) {
@@ -348,10 +376,12 @@ int launch_unpatchify(const float* y, int ldy, float* img, int NB, int C, int H,
     return 0;
 }
 
-int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, hipStream_t stream) {
+int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled,
+                           hipStream_t stream) {
     GTAV_REQUIRE(Rp >= R && Cp >= C, "convert_pad: padded shape smaller than source");
+    GTAV_REQUIRE(!tiled || (Rp % 128 == 0 && Cp % 64 == 0), "convert_pad: tile-major needs Rp %% 128 == 0 and Cp %% 64 == 0");
     hipLaunchKernelGGL(convert_pad_f16_kernel, dim3(grid_for((size_t)Rp * Cp)), dim3(256), 0, stream, src, lds, R, C, dst,
-                       Rp, Cp, scale);
+                       Rp, Cp, scale, tiled);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -374,21 +404,34 @@ int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStre
     return 0;
 }
 
-int launch_cond_inputs(const int64_t* t64, int rows, int Tq, int t_ctx, int t_cur, const float* sincos, float* E,
+int launch_set_step(StepParams* dst, const StepParams& v, hipStream_t stream) {
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, stream, dst, v);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cond_inputs(const int64_t* t64, int rows, int Tq, const StepParams* sp, int use_cur, const float* sincos, float* E,
                        const float* actions, int64_t act_outer, int64_t act_inner, int A, float* HC, int ldhc, int D, int Apad,
                        int* err_flag, hipStream_t stream) {
-    GTAV_REQUIRE(rows > 0 && Tq > 0, "cond_inputs: bad rows/Tq");
-    hipLaunchKernelGGL(cond_inputs_kernel, dim3(rows), dim3(256), 0, stream, t64, rows, Tq, t_ctx, t_cur, sincos, E, actions,
+    GTAV_REQUIRE(rows > 0 && Tq > 0 && (t64 || sp), "cond_inputs: bad rows/Tq/timesteps");
+    hipLaunchKernelGGL(cond_inputs_kernel, dim3(rows), dim3(256), 0, stream, t64, rows, Tq, sp, use_cur, sincos, E, actions,
                        (long long)act_outer, (long long)act_inner, A, HC, ldhc, D, Apad, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_ddim_update(const float* x, size_t x_stride, const float* v, size_t v_stride, float* out, size_t out_stride,
-                       int B, int n, const float* alpha_t, const float* alpha_next, float alpha_t_s, float alpha_next_s,
-                       int is_final, hipStream_t stream) {
+                       int B, int n, const float* alpha_t, const float* alpha_next, int is_final, hipStream_t stream) {
     hipLaunchKernelGGL(ddim_update_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, stream, x, x_stride, v, v_stride, out,
-                       out_stride, n, alpha_t, alpha_next, alpha_t_s, alpha_next_s, is_final);
+                       out_stride, n, alpha_t, alpha_next, is_final);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ddim_update_step(float* x, size_t frames_per_sample, const float* v, size_t v_stride, int B, int n,
+                            const StepParams* sp, hipStream_t stream) {
+    hipLaunchKernelGGL(ddim_update_step_kernel, dim3(cdiv(n, 256), B), dim3(256), 0, stream, x, frames_per_sample, v, v_stride,
+                       n, sp);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -417,8 +460,8 @@ int launch_mse(const float* a, size_t a_stride, const float* b, size_t b_stride,
     return 0;
 }
 
-int launch_unpad_f16_to_f32(const f16* src, int lds, int R, int C, float* dst, hipStream_t stream) {
-    hipLaunchKernelGGL(unpad_f16_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, src, lds, R, C, dst);
+int launch_unpad_f16_to_f32(const f16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t stream) {
+    hipLaunchKernelGGL(unpad_f16_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, src, lds, R, C, dst, tiled);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -435,8 +478,8 @@ int launch_clamp_cols(float* buf, int M, int ld, int c0, int c1, float lo, float
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_frame_index(int* idx, int B, int Tq, int F, int first, hipStream_t stream) {
-    hipLaunchKernelGGL(frame_index_kernel, dim3(cdiv(B * Tq, 256)), dim3(256), 0, stream, idx, B, Tq, F, first);
+int launch_frame_index(int* idx, int B, int Tq, int F, const StepParams* sp, int use_cur, hipStream_t stream) {
+    hipLaunchKernelGGL(frame_index_kernel, dim3(cdiv(B * Tq, 256)), dim3(256), 0, stream, idx, B, Tq, F, sp, use_cur);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -1,5 +1,6 @@
 // Big-M fp16 MFMA GEMM with fused epilogues:  Y[m][n] = sum_k X[m][k] * W[n][k]  (+ epilogue)
-// X: activations [M][ldx] fp16 (K contiguous), W: torch-Linear layout [N][K] fp16 (K contiguous).
+// X (activations, logical [M][K]) and W (torch-Linear [N][K]) are both fp16 in the TILE-MAJOR layout of
+// common.h `tiled_off` (rows padded to 128, K to 64).  fp16 outputs that feed another GEMM are written tile-major too.
 #pragma once
 #include "common.h"
 
@@ -12,6 +13,8 @@ enum GemmEpi : int {
     EPI_GELU_ERF = 3,   // out_f16[m][n] = gelu_erf(acc + bias)    (VAE Mlp, model/vae.py:128)
     EPI_RESID = 4,      // resid_f32[m][n] += gate[row(m)][n] * (acc + bias)   (model/dit.py:207-223)
     EPI_QKV = 5,        // bias, RoPE on q/k, scatter to attention layouts (model/attention.py:50-58,109-118)
+    EPI_PARTIAL = 6,    // split-K: out_f32[ks][m][n] = raw partial sums (no bias); the following LayerNorm kernel
+                        // reduces the slabs and applies bias + gate + residual (ops.h: LnPending)
 };
 
 enum QkvMode : int {
@@ -20,12 +23,15 @@ enum QkvMode : int {
 };
 
 struct GemmParams {
-    const f16* X;
-    int ldx;
-    const f16* W;  // [round_up(N,128)][K]
+    const f16* X;  // tile-major [round_up(M,128)][K]
+    int ldx;       // unused (kept for ABI stability of the struct users): K is the logical row length
+    const f16* W;  // tile-major [round_up(N,128)][K]
     int M, N, K;   // K % 64 == 0
+    int debug;     // experiments only: bit 0 = skip the LDS fills after the prologue, bit 1 = skip LDS reads + MFMA
+    int splitk;    // EPI_PARTIAL only: number of K slices (grid = tiles * splitk); (K / 64) % splitk == 0
     const float* bias;  // [N] or nullptr
-    void* out;          // EPI_F32/F16/GELU/RESID target, [M][ldo]
+    void* out;          // EPI_F32/RESID/PARTIAL: f32 row-major [M][ldo]; EPI_F16: f16 row-major [M][ldo];
+                        // EPI_GELU_*: f16 TILE-MAJOR with logical row length ldo (the next GEMM's K)
     int ldo;
     // EPI_RESID
     const float* gate;     // nullptr => gate = 1
@@ -48,5 +54,10 @@ struct GemmParams {
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+// Split-K factor used for a residual GEMM of this shape (1 = no split): fills the 256 CUs when M is small.
+int gemm_choose_splitk(int M, int N, int K);
+// Pipeline depth override for experiments (0 = heuristic, else 2 or 4 LDS stages).
+void gemm_set_stages(int ns);
+void gemm_set_debug(int bits);
 
 }  // namespace gtav

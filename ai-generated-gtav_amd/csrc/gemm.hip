@@ -33,32 +33,32 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     return cv.u;
 }
 
-template <bool TR>
-__device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0, int m0, f32x4 (&acc)[4][4]) {
+// NS-stage LDS ring.  Tile t lives in stage t % NS.  Steady state: NS-1 tiles are in flight when iteration t starts;
+// the wave waits (counted vmcnt, never 0 in the main loop) until ITS OWN share of tile t has landed, the raw
+// s_barrier then (a) makes every wave's share of tile t visible and (b) proves every wave has finished reading
+// tile t-1, whose stage is refilled right after the barrier with tile t+NS-1.  One barrier per K-step; the
+// HBM/L2 -> LDS latency (~1.1 us under load) is covered by NS-2 further tiles in flight.
+template <bool TR, int NS>
+__device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                         f32x4 (&acc)[4][4]) {
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w >> 1, wm = w & 1;
-    const int nk = p.K / TK;
 
-    // ---- staging: wave w issues instructions q = 4w .. 4w+3 of each 16-instruction tile ----
-    const int srow = lane >> 3, sc = lane & 7;
-    const int gc = sc ^ srow;  // source chunk for the linear LDS slot (row & 7 == srow)
-    const char* wsrc[4];
-    const char* xsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 8 * (4 * w + i) + srow;
-        wsrc[i] = (const char*)(p.W + (size_t)(n0 + r) * p.K + gc * 8);
-        int xr = m0 + r;
-        xr = xr < p.M ? xr : p.M - 1;  // ragged last M tile: clamp (results are masked in the epilogue)
-        xsrc[i] = (const char*)(p.X + (size_t)xr * p.ldx + gc * 8);
-    }
-    auto stage = [&](int buf, int t) {
-        char* base = smem + buf * 2 * TILE_BYTES + (4 * w) * 1024;
+    // ---- staging: operands are tile-major (common.h tiled_off): the 16 KiB tile (row-tile, k-tile) is contiguous and
+    // already in LDS-image order, so wave w copies bytes [4w KiB, 4w+4 KiB) of each tile with 4 linear 1 KiB pieces ----
+    const int nktot = p.K / TK;
+    const char* wsrc = (const char*)p.W + ((size_t)(n0 >> 7) * nktot + kt0) * TILE_BYTES + (4 * w) * 1024 + lane * 16;
+    const char* xsrc = (const char*)p.X + ((size_t)(m0 >> 7) * nktot + kt0) * TILE_BYTES + (4 * w) * 1024 + lane * 16;
+    auto stage = [&](int t) {
+        char* base = smem + (t % NS) * STAGE_BYTES + (4 * w) * 1024;
+        const char* ws = wsrc + (size_t)t * TILE_BYTES;
+        const char* xs = xsrc + (size_t)t * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(wsrc[i] + (size_t)t * (TK * 2), base + i * 1024);
-            glds16(xsrc[i] + (size_t)t * (TK * 2), base + TILE_BYTES + i * 1024);
+            glds16(ws + i * 1024, base + i * 1024);
+            glds16(xs + i * 1024, base + TILE_BYTES + i * 1024);
         }
     };
 
@@ -72,13 +72,17 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
         xoff[s] = TILE_BYTES + (64 * wm + li) * 128 + ch;
     }
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(cur ^ 1, t + 1);
-        const char* b = smem + cur * 2 * TILE_BYTES;
+    const int npro = nkt < NS - 1 ? nkt : NS - 1;
+    for (int t = 0; t < npro; ++t) stage(t);
+    for (int t = 0; t < nkt; ++t) {
+        // tiles newer than t already issued: min(NS - 2, nkt - 1 - t), 8 loads each
+        const int rem = nkt - 1 - t;
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (t + NS - 1 < nkt && !(p.debug & 1)) stage(t + NS - 1);
+        const char* b = smem + (t % NS) * STAGE_BYTES;
+        if (p.debug & 2) continue;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 wf[4], xf[4];
@@ -97,14 +101,12 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+template <int EPI, int NS>
+__global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * 2 * TILE_BYTES];
     const int tiles_m = (p.M + TM - 1) / TM;
 
     // XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous
@@ -112,7 +114,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int tile_n = swz / tiles_m, tile_m = swz - tile_n * tiles_m;
+    int tile_id = swz, ks = 0, kt0 = 0, nkt = p.K / TK;
+    if constexpr (EPI == EPI_PARTIAL) {
+        const int tiles = tiles_m * ((p.N + TN - 1) / TN);
+        ks = swz / tiles;  // K slice is the slowest index: the slices of one W panel stay on one XCD
+        tile_id = swz - ks * tiles;
+        nkt = nkt / p.splitk;
+        kt0 = ks * nkt;
+    }
+    const int tile_n = tile_id / tiles_m, tile_m = tile_id - tile_n * tiles_m;
     const int n0 = tile_n * TN, m0 = tile_m * TM;
 
     f32x4 acc[4][4];
@@ -124,10 +134,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     bool tr = false;
     if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
     if constexpr (EPI == EPI_QKV) {
-        if (tr) mainloop<true>(p, smem, n0, m0, acc);
-        else mainloop<false>(p, smem, n0, m0, acc);
+        if (tr) mainloop<true, NS>(p, smem, n0, m0, kt0, nkt, acc);
+        else mainloop<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
     } else {
-        mainloop<false>(p, smem, n0, m0, acc);
+        mainloop<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
     }
 
     // ------------------------------------ epilogue ------------------------------------
@@ -163,21 +173,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const int n = n0 + 64 * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
         if (n >= p.N) continue;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+        if (EPI != EPI_PARTIAL && p.bias) bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + 64 * wm + 16 * j + li;
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + bv;
-            if constexpr (EPI == EPI_F32) {
+            if constexpr (EPI == EPI_PARTIAL) {
+                *(f32x4*)((float*)p.out + ((size_t)ks * p.M + m) * p.ldo + n) = v;
+            } else if constexpr (EPI == EPI_F32) {
                 *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
             } else if constexpr (EPI == EPI_F16) {
                 *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
             } else if constexpr (EPI == EPI_GELU_TANH) {
-                *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) =
+                *(uint2*)((f16*)p.out + tiled_off(m, n, p.ldo)) =
                     pack4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
             } else if constexpr (EPI == EPI_GELU_ERF) {
-                *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) =
+                *(uint2*)((f16*)p.out + tiled_off(m, n, p.ldo)) =
                     pack4(gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
             } else if constexpr (EPI == EPI_RESID) {
                 float* dst = (float*)p.out + (size_t)m * p.ldo + n;
@@ -237,11 +249,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
 }  // namespace
 
-int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
+static int g_force_stages = 0, g_debug = 0;
+void gemm_set_stages(int ns) { g_force_stages = ns; }
+void gemm_set_debug(int bits) { g_debug = bits; }
+
+int gemm_choose_splitk(int M, int N, int K) {
+    const int tiles = cdiv(M, TM) * cdiv(N, TN);
+    int s = 1;
+    while (tiles * s < 192 && s < 8 && (K / TK) % (s * 2) == 0 && K / (s * 2) >= 256) s *= 2;
+    return s;
+}
+
+template <int EPI>
+static void launch_epi(const GemmParams& p, int ns, dim3 grid, hipStream_t stream) {
+    if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_kernel<EPI, 4>), grid, dim3(256), 0, stream, p);
+}
+
+int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.debug = g_debug;
     GTAV_REQUIRE(p.K > 0 && p.K % TK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, TK);
     GTAV_REQUIRE(p.M > 0 && p.N > 0 && p.N % 4 == 0, "gemm: bad M=%d N=%d", p.M, p.N);
-    GTAV_REQUIRE(p.ldx >= p.K && p.ldx % 8 == 0, "gemm: ldx=%d must be >= K and a multiple of 8", p.ldx);
     GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    int splitk = 1;
     if (epi == EPI_QKV) {
         GTAV_REQUIRE(p.N == 3 * p.D && p.D % 128 == 0, "gemm/qkv: N=%d must equal 3*D, D=%d %% 128 == 0", p.N, p.D);
         GTAV_REQUIRE(p.S > 0 && p.q && p.k && p.rope_cos && p.rope_sin, "gemm/qkv: missing buffers");
@@ -252,17 +283,25 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
         }
     } else {
         GTAV_REQUIRE(p.out && p.ldo >= p.N && p.ldo % 4 == 0, "gemm: bad output ldo=%d", p.ldo);
+        if (epi == EPI_GELU_TANH || epi == EPI_GELU_ERF) GTAV_REQUIRE(p.ldo % 64 == 0, "gemm/gelu: tile-major output needs ldo %% 64 == 0");
         if (epi == EPI_RESID && p.gate) GTAV_REQUIRE(p.rows_per_gate > 0, "gemm/resid: rows_per_gate");
+        if (epi == EPI_PARTIAL) {
+            splitk = p.splitk;
+            GTAV_REQUIRE(splitk >= 1 && (p.K / TK) % splitk == 0, "gemm/partial: splitk=%d must divide K/64=%d", splitk, p.K / TK);
+        }
     }
     const int tiles = cdiv(p.M, TM) * cdiv(p.N, TN);
-    dim3 grid(tiles), block(256);
+    // pipeline depth: 4 stages (128 KB LDS, 1 block per CU) when the grid cannot put two blocks on every CU anyway
+    int ns = g_force_stages ? g_force_stages : (tiles * splitk < 2 * 256 ? 4 : 2);
+    dim3 grid(tiles * splitk);
     switch (epi) {
-        case EPI_F32: hipLaunchKernelGGL(gemm_kernel<EPI_F32>, grid, block, 0, stream, p); break;
-        case EPI_F16: hipLaunchKernelGGL(gemm_kernel<EPI_F16>, grid, block, 0, stream, p); break;
-        case EPI_GELU_TANH: hipLaunchKernelGGL(gemm_kernel<EPI_GELU_TANH>, grid, block, 0, stream, p); break;
-        case EPI_GELU_ERF: hipLaunchKernelGGL(gemm_kernel<EPI_GELU_ERF>, grid, block, 0, stream, p); break;
-        case EPI_RESID: hipLaunchKernelGGL(gemm_kernel<EPI_RESID>, grid, block, 0, stream, p); break;
-        case EPI_QKV: hipLaunchKernelGGL(gemm_kernel<EPI_QKV>, grid, block, 0, stream, p); break;
+        case EPI_F32: launch_epi<EPI_F32>(p, ns, grid, stream); break;
+        case EPI_F16: launch_epi<EPI_F16>(p, ns, grid, stream); break;
+        case EPI_GELU_TANH: launch_epi<EPI_GELU_TANH>(p, ns, grid, stream); break;
+        case EPI_GELU_ERF: launch_epi<EPI_GELU_ERF>(p, ns, grid, stream); break;
+        case EPI_RESID: launch_epi<EPI_RESID>(p, ns, grid, stream); break;
+        case EPI_QKV: launch_epi<EPI_QKV>(p, ns, grid, stream); break;
+        case EPI_PARTIAL: launch_epi<EPI_PARTIAL>(p, ns, grid, stream); break;
         default: GTAV_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
     GTAV_CHECK_HIP(hipGetLastError());

@@ -11,15 +11,44 @@ int launch_skinny_f32(const float* X, int ldx, const float* W, const float* bias
 int skinny_init();  // raises the dynamic-LDS limit of the skinny kernels (call once per process)
 
 // ---- elementwise.hip ---------------------------------------------------------------------
+// Per-noise-step scalars of the fused sampler step, kept in device memory so that a captured hipGraph of the
+// step can be replayed with new values (written by a one-thread kernel ahead of the graph launch).
+struct StepParams {
+    int first;      // first frame of the window inside the latent buffer
+    int cur;        // frame being denoised
+    int t_ctx;      // timestep of the context frames (stabilization level)
+    int t_cur;      // timestep of frame `cur`
+    int is_final;   // noise_idx == 0: return x_start (train_dit.py:119-120)
+    float alpha_t, alpha_next;
+    int pad;
+};
+int launch_set_step(StepParams* dst, const StepParams& v, hipStream_t stream);
+
+// Deferred residual update executed by the LayerNorm that follows a residual GEMM (model/dit.py:207-223):
+//   x[m] += gate[row(m)] * (sum_s parts[s][m] + bias)      (gate == nullptr -> 1, i.e. the VAE's plain residual)
+// `parts` are the split-K slabs written by gemm EPI_PARTIAL: slab s at parts + s * slab_stride, rows of ld floats.
+struct LnPending {
+    const float* parts;
+    int nsplit;
+    size_t slab_stride;
+    int ld;
+    const float* bias;
+    const float* gate;
+    int gate_stride;
+    const int* gate_rows;
+    int rows_per_gate;
+};
+
+// LayerNorm outputs are GEMM A-operands: fp16 TILE-MAJOR with logical row length D (buffer rows padded to 128).
 // LayerNorm(eps=1e-6, no affine) + adaLN modulate -> fp16  (model/dit.py:19-27,163-181)
 //   out[m] = LN(x[m]) * (1 + (scale[row] + 1e-6)) + shift[row],  row = rows ? rows[m / rows_per_mod] : m / rows_per_mod
-int launch_ln_modulate(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
-                       int mod_stride, const int* rows, int rows_per_mod, hipStream_t stream);
+int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
+                       int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, hipStream_t stream);
 // LayerNorm(eps=1e-6) with affine weight/bias -> fp16   (model/vae.py:139,146,174)
-int launch_ln_affine(const float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
-                     hipStream_t stream);
+int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
+                     const LnPending* pend, hipStream_t stream);
 
-// Non-overlapping patch gather (im2col of a k = s = p conv):  img (NB, C, H, W) f32 with strides -> A [M][ldo] fp16,
+// Non-overlapping patch gather (im2col of a k = s = p conv):  img (NB, C, H, W) f32 -> A fp16 TILE-MAJOR, logical [M][ldo],
 // token m = (nb, gh, gw), column k = (c, ph, pw); value = a * img + b.  Columns [C p p, ldo) are zeroed.
 // `frame_index` (optional, length NB) picks frame f = frame_index[nb] out of the source buffer (frame stride =
 // C*H*W floats), which is how the sampler reads its sliding window in place.
@@ -31,15 +60,17 @@ int launch_unpatchify(const float* y, int ldy, float* img, int NB, int C, int H,
                       float b, hipStream_t stream);
 
 // fp32 -> fp16 with zero padding: src [R][C] (ld = lds) -> dst [Rp][Cp]
-int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, hipStream_t stream);
+// tiled != 0: dst is tile-major (common.h tiled_off) with Rp % 128 == 0, Cp % 64 == 0
+int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled,
+                           hipStream_t stream);
 // inverse of the above without padding (state_dict round trip): dst[r][c] = (float)src[r][c]
-int launch_unpad_f16_to_f32(const f16* src, int lds, int R, int C, float* dst, hipStream_t stream);
+int launch_unpad_f16_to_f32(const f16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t stream);
 int launch_copy_f32_strided(const float* src, int lds, int R, int C, float* dst, int ldd, hipStream_t stream);
 int launch_copy_rows_f32(const float* src, size_t src_stride, float* dst, size_t dst_stride, int rows, size_t n, hipStream_t stream);
 // buf[m][c] = clamp(buf[m][c], lo, hi) for c in [c0, c1)
 int launch_clamp_cols(float* buf, int M, int ld, int c0, int c1, float lo, float hi, hipStream_t stream);
-// idx[b * Tq + tl] = b * F + first + tl
-int launch_frame_index(int* idx, int B, int Tq, int F, int first, hipStream_t stream);
+// idx[b * Tq + tl] = b * F + first + tl, first = use_cur ? sp->cur : sp->first
+int launch_frame_index(int* idx, int B, int Tq, int F, const StepParams* sp, int use_cur, hipStream_t stream);
 int launch_frames_to_u8(const float* img, uint8_t* out, int N, int H, int W, hipStream_t stream);
 int launch_moments_to_latents(const float* mom, float* lat, int N, int hw, int latent, int mom_ch, float scale, hipStream_t stream);
 int launch_latents_to_tokens(const float* lat, float* z, int N, int hw, int latent, hipStream_t stream);
@@ -51,7 +82,9 @@ int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStre
 // Conditioning inputs (model/dit.py:96-118,359-364) for `rows` (b, frame) pairs, row r = (r / Tq, r % Tq):
 //   E[r][0:256] = sincos_table[t_r],  t_r = t64 ? t64[r] : (r % Tq == Tq - 1 ? t_cur : t_ctx)   (train_dit.py:64-91)
 //   HC[r][D : D+Apad] = actions[(r / Tq) * act_outer + (r % Tq) * act_inner + 0:A]  (zeros when actions == nullptr)
-int launch_cond_inputs(const int64_t* t64, int rows, int Tq, int t_ctx, int t_cur, const float* sincos /*[1000][256]*/,
+// With `sp` (sampler step): t_ctx / t_cur come from *sp and the action row of (b, tl) is
+// actions[b * act_outer + ((use_cur ? sp->cur : sp->first) + tl) * act_inner].
+int launch_cond_inputs(const int64_t* t64, int rows, int Tq, const StepParams* sp, int use_cur, const float* sincos /*[1000][256]*/,
                        float* E, const float* actions, int64_t act_outer, int64_t act_inner, int A, float* HC, int ldhc,
                        int D, int Apad, int* err_flag, hipStream_t stream);
 
@@ -60,8 +93,10 @@ int launch_cond_inputs(const int64_t* t64, int rows, int Tq, int t_ctx, int t_cu
 //   out = final ? x0 : sqrt(a_n) x0 + sqrt(1 - a_n) eps
 // x, v, out: n elements per sample with given sample strides (floats).
 int launch_ddim_update(const float* x, size_t x_stride, const float* v, size_t v_stride, float* out, size_t out_stride,
-                       int B, int n, const float* alpha_t, const float* alpha_next, float alpha_t_s, float alpha_next_s,
-                       int is_final, hipStream_t stream);  // per-row device alphas, or the two scalars when alpha_t == nullptr
+                       int B, int n, const float* alpha_t, const float* alpha_next, int is_final, hipStream_t stream);
+// sampler form: frame sp->cur of x (B, F, n) is updated in place from v (row stride v_stride); alphas / is_final from *sp
+int launch_ddim_update_step(float* x, size_t frames_per_sample, const float* v, size_t v_stride, int B, int n,
+                            const StepParams* sp, hipStream_t stream);
 
 // Training-side noising, v-target and squared-error partial sums (train_dit.py:621-650).
 int launch_add_noise(const float* x, const float* noise, const float* alpha /*[rows]*/, float* out, int rows, int n,
@@ -74,10 +109,10 @@ int launch_mse(const float* a, size_t a_stride, const float* b, size_t b_stride,
 // ---- attention.hip -----------------------------------------------------------------------
 // Full (non-causal) attention over S tokens per (nb, head), head_dim 64 (model/attention.py:127-129, model/vae.py:101).
 // Q,K [nb][heads][S][64], Vt [nb][heads][64][S] fp16 (layouts written by the QKV GEMM epilogue);
-// O [nb*S][heads*64] fp16 token-major.
+// O logical [nb*S][heads*64] fp16, TILE-MAJOR (A-operand of the out-projection GEMM).
 int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream);
 // Causal attention over the frames of a window per (b, p, head) (model/attention.py:62-64).
-// q [B*Tq*P][D] for frames t0 .. t0+Tq-1; kv cache [B][Tmax][P][2][D]; O like q.
+// q [B*Tq*P][D] row-major for frames t0 .. t0+Tq-1; kv cache [B][Tmax][P][2][D]; O logical like q but TILE-MAJOR.
 int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax,
                          hipStream_t stream);
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "gtav_dit_set_schedule": [_p, C.POINTER(C.c_float), _i],
     "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     "gtav_dit_check": [_p, _p],
+    "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_vae_create": [C.POINTER(VaeConfig), C.POINTER(_p)],
@@ -79,9 +80,14 @@ SIGNATURES = {
     "gtav_op_ln_affine": [_p, _p, _i, _i, _p, _p, _p],
     "gtav_op_attn_spatial": [_p, _p, _p, _p, _i, _i, _i, _p],
     "gtav_op_attn_temporal": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _p],
+    "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _i, _p],
+    "gtav_op_gemm_splitk_ln": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
+    "gtav_op_gemm_choose_splitk": [_i, _i, _i],
+    "gtav_op_gemm_set_stages": [_i],
+    "gtav_op_gemm_set_debug": [_i],
 }
-_RESTYPES = {"gtav_last_error": C.c_char_p, "gtav_dit_destroy": None, "gtav_vae_destroy": None}
+_RESTYPES = {"gtav_last_error": C.c_char_p, "gtav_dit_destroy": None, "gtav_vae_destroy": None, "gtav_op_gemm_set_stages": None,
+             "gtav_op_gemm_set_debug": None}
 
 _lib = None
 

@@ -283,6 +283,10 @@ class DiT(_HipModule):
         _lib.check(_lib.load().gtav_dit_profile_read(self._handle, ms, n))
         return {k: (ms[i], n[i]) for i, k in enumerate(self.PROFILE_CLASSES)}
 
+    def set_graph(self, enable: bool):
+        """hipGraph replay of the fused sampler step on/off (on by default)."""
+        _lib.check(_lib.load().gtav_dit_set_graph(self._handle, int(bool(enable))))
+
     def check(self):
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().gtav_dit_check(self._handle, _lib.current_stream()))

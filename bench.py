@@ -50,6 +50,19 @@ def clip_flops(B, n_prompt, total, steps, max_frames, cached):
     return fl
 
 
+def host_cores():
+    """Threads for the CPU baseline: the cgroup CPU quota if there is one, else the affinity mask, capped at 32
+    (torch's intra-op pool oversubscribes badly when handed every logical CPU of a shared host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,17 +200,19 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_cpu as O
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         torch.set_num_threads(cores)
         sd = dit.state_dict()
         cfg = O.dit_s_2()
         xc = xw[:1].cpu()
         tc = tw[:1]
         with torch.no_grad():
-            O.dit_forward(sd, cfg, xc, tc, None)
+            t0 = time.perf_counter()
+            O.dit_forward(sd, cfg, xc, tc, None)          # warm-up, also bounds the sample on a slow host
+            warm = time.perf_counter() - t0
             t0 = time.perf_counter()
             nf = 0
-            while nf < 4 or (time.perf_counter() - t0 < 12 and nf < 40):
+            while nf < 1 or (time.perf_counter() - t0 < 10 and nf < 40 and warm < 10):
                 O.dit_forward(sd, cfg, xc, tc, None)
                 nf += 1
             t_fwd = (time.perf_counter() - t0) / nf

@@ -74,6 +74,10 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x_dev, int32_t B, int32_t F, int32
                           int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions_dev, int32_t mode,
                           float* v_out_dev, void* stream);
 
+/* The fused step replays a captured hipGraph per (shape, buffers) key by default (env GTAV_GRAPH=0 or this call
+ * switch to plain launches; results are identical). */
+int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
+
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
  * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).
  * Classes: 0 LN+modulate, 1 QKV GEMM, 2 spatial attention, 3 temporal attention, 4 out-proj GEMM, 5 fc1 GEMM,
@@ -143,7 +147,8 @@ int gtav_latents_to_tokens(const float* lat_dev, float* z_dev, int32_t N, int32_
 /* ------------------------------------------------------------------------------------------------
  * Kernel-level entry points (used by the parity tests in tests/ and by bench.py's roofline probe)
  * ---------------------------------------------------------------------------------------------- */
-/* epilogues: 0 f32, 1 f16, 2 gelu-tanh f16, 3 gelu-erf f16, 4 residual (+gate) f32 in place */
+/* epilogues: 0 f32, 1 f16, 2 gelu-tanh f16, 3 gelu-erf f16, 4 residual (+gate) f32 in place,
+ * 6 split-K partial slabs out[ks][M][N] f32 (the split factor is passed in gate_stride) */
 int gtav_op_gemm_f16(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, void* out_dev,
                      int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* gate_dev,
                      int32_t gate_stride, int32_t rows_per_gate, void* stream);
@@ -161,8 +166,22 @@ int gtav_op_attn_spatial(const void* q_dev, const void* k_dev, const void* vt_de
                          int32_t heads, int32_t S, void* stream);
 int gtav_op_attn_temporal(const void* q_dev, const void* kv_dev, void* o_dev, int32_t B, int32_t P, int32_t D,
                           int32_t Tq, int32_t t0, int32_t Tmax, void* stream);
+/* Residual GEMM as the model runs it: split-K partial slabs (parts: splitk*M*N floats; splitk 0 = heuristic) followed by
+ * the LayerNorm kernel that reduces them: resid += gate * (sum parts + bias); out = LN(resid) * (1 + scale + 1e-6) + shift. */
+int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,
+                           int32_t N, int32_t K, int32_t splitk, float* parts_dev, float* resid_dev, const float* gate_dev,
+                           int32_t gate_stride, int32_t rows_per_gate, void* out_f16_dev, const float* shift_dev,
+                           const float* scale_dev, int32_t mod_stride, void* stream);
+int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K);
+/* Experiments: force the GEMM pipeline depth (0 = heuristic, 2 or 4 LDS stages). */
+void gtav_op_gemm_set_stages(int32_t ns);
+/* Experiments (results become WRONG): bit 0 skips the LDS fills after the prologue, bit 1 skips LDS reads + MFMA. */
+void gtav_op_gemm_set_debug(int32_t bits);
+/* fp32 [R][C] -> fp16 [Rp][Cp] zero padded; tiled != 0 writes the GEMM's tile-major operand layout (128 x 64 tiles,
+ * csrc/common.h tiled_off; Rp % 128 == 0, Cp % 64 == 0).  All fp16 GEMM operands (x_f16_dev, w_f16_dev) and the fp16
+ * outputs of gtav_op_ln_*, gtav_op_attn_* and the GELU epilogues use that layout. */
 int gtav_op_convert_f16(const float* src_dev, int32_t lds, int32_t R, int32_t C, void* dst_f16_dev, int32_t Rp,
-                        int32_t Cp, void* stream);
+                        int32_t Cp, int32_t tiled, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,17 +17,33 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def pad_weight_f16(w):
-    """fp32 (N, K) -> fp16 (round_up(N,128), round_up(K,64)) zero padded, on the GPU (via the convert kernel)."""
-    N, K = w.shape
-    Np, Kp = (N + 127) // 128 * 128, (K + 63) // 64 * 64
-    out = torch.empty((Np, Kp), device=dev(), dtype=torch.float16)
-    src = w.to(dev(), torch.float32).contiguous()
-    L.check(L.load().gtav_op_convert_f16(src.data_ptr(), K, N, K, out.data_ptr(), Np, Kp, stream()))
+def tiled_index(R, K):
+    """Offsets (in halves) of element (r, k) in the GEMM's tile-major operand layout (csrc/common.h tiled_off)."""
+    r = torch.arange(R)[:, None]
+    k = torch.arange(K)[None, :]
+    return ((r >> 7) * (K >> 6) + (k >> 6)) * 8192 + (r & 127) * 64 + ((((k >> 3) & 7) ^ (r & 7)) << 3) + (k & 7)
+
+
+def untile(buf, R, K):
+    """tile-major fp16 device buffer -> row-major (R, K) CPU tensor."""
+    flat = buf.reshape(-1).cpu()
+    return flat[tiled_index(R, K).reshape(-1)].reshape(R, K)
+
+
+def to_tiled_f16(x):
+    """fp32/fp16 (R, K) -> tile-major fp16 (round_up(R,128) * round_up(K,64) halves, zero padded) on the GPU."""
+    R, K = x.shape
+    Rp, Kp = (R + 127) // 128 * 128, (K + 63) // 64 * 64
+    out = torch.empty((Rp, Kp), device=dev(), dtype=torch.float16)
+    src = x.to(dev(), torch.float32).contiguous()
+    L.check(L.load().gtav_op_convert_f16(src.data_ptr(), K, R, K, out.data_ptr(), Rp, Kp, 1, stream()))
     return out
 
 
+pad_weight_f16 = to_tiled_f16
+
+
 def gemm(x16, w16, bias, M, N, K, epi, out, ldo, gate=None, gate_stride=0, rows_per_gate=1):
-    L.check(L.load().gtav_op_gemm_f16(x16.data_ptr(), x16.shape[1], w16.data_ptr(), L.ptr(bias), out.data_ptr(), ldo, M, N, K,
+    L.check(L.load().gtav_op_gemm_f16(x16.data_ptr(), K, w16.data_ptr(), L.ptr(bias), out.data_ptr(), ldo, M, N, K,
                                       epi, L.ptr(gate), gate_stride, rows_per_gate, stream()))
     return out

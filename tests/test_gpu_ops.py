@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import dev, gemm, pad_weight_f16, rel_l2, stream  # noqa: E402
+from helpers import dev, gemm, pad_weight_f16, rel_l2, stream, to_tiled_f16, untile  # noqa: E402
 from gtav_amd import lib as L  # noqa: E402
 
 
@@ -23,7 +23,7 @@ def test_gemm_f32_epilogue(M, N, K):
     w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
     b = _rand(N, seed=3)
     w16 = pad_weight_f16(w)
-    xd, bd = x.to(dev()), b.to(dev())
+    xd, bd = to_tiled_f16(x), b.to(dev())
     out = torch.full((M, N), float("nan"), device=dev())
     gemm(xd, w16, bd, M, N, K, 0, out, N)
     ref = x.float() @ w.half().float().t() + b
@@ -37,13 +37,14 @@ def test_gemm_f16_and_gelu_epilogues():
     w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
     b = _rand(N, seed=3)
     w16 = pad_weight_f16(w)
-    xd, bd = x.to(dev()), b.to(dev())
+    xd, bd = to_tiled_f16(x), b.to(dev())
     pre = x.float() @ w.half().float().t() + b
     for epi, fn in ((1, lambda z: z), (2, lambda z: torch.nn.functional.gelu(z, approximate="tanh")),
                     (3, lambda z: torch.nn.functional.gelu(z))):
-        out = torch.zeros((M, N), device=dev(), dtype=torch.float16)
+        out = torch.zeros(((M + 127) // 128 * 128, N), device=dev(), dtype=torch.float16)
         gemm(xd, w16, bd, M, N, K, epi, out, N)
-        assert rel_l2(out.float(), fn(pre)) < 6e-4, epi
+        got = out[:M].float().cpu() if epi == 1 else untile(out, M, N).float()   # GELU outputs are tile-major (next GEMM's A)
+        assert rel_l2(got, fn(pre)) < 6e-4, epi
 
 
 def test_gemm_residual_gate_epilogue():
@@ -56,7 +57,7 @@ def test_gemm_residual_gate_epilogue():
     mod = _rand(M // P, modw, seed=5)
     w16 = pad_weight_f16(w)
     r = resid.clone().to(dev())
-    md, xd, bd = mod.to(dev()), x.to(dev()), b.to(dev())
+    md, xd, bd = mod.to(dev()), to_tiled_f16(x), b.to(dev())
     gate_view = md[:, N:]   # gate vector lives at column offset N of each mod row
     L.check(L.load().gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), r.data_ptr(), N, M, N, K, 4,
                                       gate_view.data_ptr(), modw, P, stream()))
@@ -89,7 +90,7 @@ def test_gemm_qkv_spatial_layout_and_rope():
     q = torch.zeros(NB, heads, S, 64, device=dev(), dtype=torch.float16)
     k = torch.zeros_like(q)
     vt = torch.zeros(NB, heads, 64, S, device=dev(), dtype=torch.float16)
-    xd, bd, cd, sd_ = x.to(dev()), bias.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
+    xd, bd, cd, sd_ = to_tiled_f16(x), bias.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
     L.check(L.load().gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), bd.data_ptr(), M, D, 0, q.data_ptr(),
                                       k.data_ptr(), vt.data_ptr(), S, 0, 0, 0, cd.data_ptr(), sd_.data_ptr(), stream()))
     y = (x.float() @ w.half().float().t() + bias).reshape(NB, S, 3, heads, 64)
@@ -111,7 +112,7 @@ def test_gemm_qkv_temporal_layout():
     w16 = pad_weight_f16(w)
     q = torch.zeros(M, D, device=dev(), dtype=torch.float16)
     kv = torch.zeros(B, Tmax, P, 2, D, device=dev(), dtype=torch.float16)
-    xd, cd, sd_ = x.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
+    xd, cd, sd_ = to_tiled_f16(x), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
     L.check(L.load().gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), 0, M, D, 1, q.data_ptr(), kv.data_ptr(),
                                       kv.data_ptr(), P, Tq, t0, Tmax, cd.data_ptr(), sd_.data_ptr(), stream()))
     y = (x.float() @ w.half().float().t()).reshape(B, Tq, P, 3, D // 64, 64)
@@ -138,23 +139,23 @@ def test_skinny_f32(M, N, K, act):
     assert rel_l2(y, ref) < 2e-6
 
 
-@pytest.mark.parametrize("D", [256, 1024])
+@pytest.mark.parametrize("D", [128, 256, 1024])
 def test_layernorm_kernels(D):
     M, P = 96, 32
     x = _rand(M, D, seed=1) * 3 + 0.5
     mod = _rand(M // P, 2 * D, seed=2)
-    out = torch.zeros(M, D, device=dev(), dtype=torch.float16)
+    out = torch.zeros(128, D, device=dev(), dtype=torch.float16)
     md, xd = mod.to(dev()), x.to(dev())
     L.check(L.load().gtav_op_ln_modulate(xd.data_ptr(), out.data_ptr(), M, D, md.data_ptr(), md[:, D:].data_ptr(), 2 * D, P,
                                          stream()))
     xh = torch.nn.functional.layer_norm(x, (D,), eps=1e-6)
     shift, scale = mod[:, :D].repeat_interleave(P, 0), mod[:, D:].repeat_interleave(P, 0)
     ref = xh * (1 + (scale + 1e-6)) + shift
-    assert rel_l2(out.float(), ref) < 5e-4
+    assert rel_l2(untile(out, M, D).float(), ref) < 5e-4
     g, b = _rand(D, seed=3) * 0.1 + 1, _rand(D, seed=4) * 0.1
     gd, bd = g.to(dev()), b.to(dev())
     L.check(L.load().gtav_op_ln_affine(xd.data_ptr(), out.data_ptr(), M, D, gd.data_ptr(), bd.data_ptr(), stream()))
-    assert rel_l2(out.float(), torch.nn.functional.layer_norm(x, (D,), g, b, eps=1e-6)) < 5e-4
+    assert rel_l2(untile(out, M, D).float(), torch.nn.functional.layer_norm(x, (D,), g, b, eps=1e-6)) < 5e-4
 
 
 @pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72)])
@@ -162,12 +163,12 @@ def test_attention_spatial(NB, heads, S):
     q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
     q = q * 1.5
     vt = v.transpose(-1, -2).contiguous()
-    o = torch.zeros(NB * S, heads * 64, device=dev(), dtype=torch.float16)
+    o = torch.zeros((NB * S + 127) // 128 * 128, heads * 64, device=dev(), dtype=torch.float16)
     qd, kd, vd = q.to(dev()), k.to(dev()), vt.to(dev())
     L.check(L.load().gtav_op_attn_spatial(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), NB, heads, S, stream()))
     ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
     ref = ref.permute(0, 2, 1, 3).reshape(NB * S, heads * 64)
-    assert rel_l2(o.float(), ref) < 1.5e-3
+    assert rel_l2(untile(o, NB * S, heads * 64).float(), ref) < 1.5e-3
 
 
 def test_attention_spatial_online_softmax_spike():
@@ -176,12 +177,13 @@ def test_attention_spatial_online_softmax_spike():
     q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
     k[0, 0, 130] = q[0, 0, 7] * 4  # key 130 (third block) dominates query 7
     vt = v.transpose(-1, -2).contiguous()
-    o = torch.zeros(NB * S, 64, device=dev(), dtype=torch.float16)
+    o = torch.zeros(256, 64, device=dev(), dtype=torch.float16)   # tile-major output, rows padded to 128
     qd, kd, vd = q.to(dev()), k.to(dev()), vt.to(dev())
     L.check(L.load().gtav_op_attn_spatial(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), NB, heads, S, stream()))
     ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())[0, 0]
-    assert rel_l2(o.float(), ref) < 1.5e-3
-    assert rel_l2(o[7].float(), ref[7]) < 2e-3
+    got = untile(o, S, 64).float()
+    assert rel_l2(got, ref) < 1.5e-3
+    assert rel_l2(got[7], ref[7]) < 2e-3
 
 
 @pytest.mark.parametrize("Tq,t0", [(5, 0), (1, 4), (2, 1), (1, 0)])
@@ -190,7 +192,7 @@ def test_attention_temporal(Tq, t0):
     Tk = t0 + Tq
     q = _rand(B, Tq, P, D, seed=1).half()
     kv = _rand(B, Tmax, P, 2, D, seed=2).half()
-    o = torch.zeros(B * Tq * P, D, device=dev(), dtype=torch.float16)
+    o = torch.zeros((B * Tq * P + 127) // 128 * 128, D, device=dev(), dtype=torch.float16)
     qd, kvd = q.to(dev()), kv.to(dev())
     L.check(L.load().gtav_op_attn_temporal(qd.data_ptr(), kvd.data_ptr(), o.data_ptr(), B, P, D, Tq, t0, Tmax, stream()))
     h = D // 64
@@ -201,7 +203,7 @@ def test_attention_temporal(Tq, t0):
     mask = torch.arange(Tk)[None, :] > (t0 + torch.arange(Tq))[:, None]
     s = s.masked_fill(mask, float("-inf"))
     ref = (s.softmax(-1) @ vf).permute(0, 3, 1, 2, 4).reshape(B * Tq * P, D)
-    assert rel_l2(o.float(), ref) < 6e-4
+    assert rel_l2(untile(o, B * Tq * P, D).float(), ref) < 6e-4
 
 
 def test_ddim_update_matches_reference_formula():
@@ -218,3 +220,48 @@ def test_ddim_update_matches_reference_formula():
         eps = ((1 / a_t).sqrt() * x - x0) / (1 / a_t - 1).sqrt()
         ref = x0 if final else a_n.sqrt() * x0 + (1 - a_n).sqrt() * eps
         assert rel_l2(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(720, 1024, 4096, 0), (720, 1024, 1024, 4), (144, 1024, 4096, 8), (300, 256, 512, 1), (5760, 1024, 1024, 0)])
+def test_gemm_splitk_partials_reduced_by_layernorm(M, N, K, splitk):
+    """The residual path as the model runs it: EPI_PARTIAL slabs + the LN kernel's deferred
+    `resid += gate * (sum parts + bias)` (model/dit.py:207-223) followed by LN + modulate."""
+    P = 36 if M % 36 == 0 else M
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    resid = _rand(M, N, seed=4)
+    mod = _rand(M // P, 3 * N, seed=5)      # [gate | shift | scale]
+    w16 = pad_weight_f16(w)
+    sk = splitk or L.load().gtav_op_gemm_choose_splitk(M, N, K)
+    assert 1 <= sk <= 8
+    xd, bd, rd, md = to_tiled_f16(x), b.to(dev()), resid.clone().to(dev()), mod.to(dev())
+    parts = torch.full((sk, M, N), float("nan"), device=dev())
+    out = torch.zeros((M + 127) // 128 * 128, N, device=dev(), dtype=torch.float16)
+    L.check(L.load().gtav_op_gemm_splitk_ln(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), M, N, K, splitk, parts.data_ptr(),
+                                            rd.data_ptr(), md.data_ptr(), 3 * N, P, out.data_ptr(), md[:, N:].data_ptr(),
+                                            md[:, 2 * N:].data_ptr(), 3 * N, stream()))
+    y = x.float() @ w.half().float().t() + b
+    gate, shift, scale = (mod[:, i * N:(i + 1) * N].repeat_interleave(P, 0) for i in range(3))
+    new_resid = resid + gate * y
+    assert rel_l2(rd, new_resid) < 2e-5
+    ref = torch.nn.functional.layer_norm(new_resid, (N,), eps=1e-6) * (1 + (scale + 1e-6)) + shift
+    assert rel_l2(untile(out, M, N).float(), ref) < 5e-4
+
+
+@pytest.mark.parametrize("ns", [2, 4])
+def test_gemm_pipeline_depths_agree(ns):
+    """Both LDS ring depths (2 and 4 stages) of the GEMM give the same result, incl. K as short as one tile."""
+    lib = L.load()
+    try:
+        lib.gtav_op_gemm_set_stages(ns)
+        for (M, N, K) in ((720, 1024, 1024), (130, 128, 64), (257, 384, 192)):
+            x = _rand(M, K, seed=1).half()
+            w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+            w16 = pad_weight_f16(w)
+            xd = to_tiled_f16(x)
+            out = torch.full((M, N), float("nan"), device=dev())
+            gemm(xd, w16, None, M, N, K, 0, out, N)
+            assert rel_l2(out, x.float() @ w.half().float().t()) < 2e-5, (ns, M, N, K)
+    finally:
+        lib.gtav_op_gemm_set_stages(0)

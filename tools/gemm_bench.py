@@ -1,0 +1,73 @@
+"""GPU micro-benchmark of the fp16 MFMA GEMM (through the C-ABI) on the shapes of the DiT at several M.
+Weights rotate over `--copies` distinct buffers so that a launch does not find its W panel in the caches.
+Usage (GPU box): python tools/gemm_bench.py [--stages 0|2|4]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from gtav_amd import lib as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stages", type=int, nargs="+", default=[2, 4])
+    ap.add_argument("--copies", type=int, default=24)
+    ap.add_argument("--iters", type=int, default=96)
+    ap.add_argument("--ms", type=int, nargs="+", default=[144, 720, 1152, 5760, 11520])
+    ap.add_argument("--debug", type=int, nargs="+", default=[0], help="gemm debug bits to sweep (1 = no fills, 2 = no MFMA)")
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    lib = L.load()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [("qkv", 3072, 1024, 5), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]
+    print(f"{'shape':>5} {'M':>6} {'N':>5} {'K':>5} {'ns':>3} {'split':>5} {'us':>9} {'TFLOP/s':>9}")
+    for M in a.ms:
+        for name, N, K, epi in shapes:
+            if a.only and name not in a.only.split(","):
+                continue
+            # operands are tile-major; for timing any data of the padded size will do
+            x = (torch.randn((M + 127) // 128 * 128, K, device=dev) * 0.5).half()
+            ws = [(torch.randn((N + 127) // 128 * 128, K, device=dev) * 0.03).half() for _ in range(a.copies)]
+            bias = torch.randn(N, device=dev)
+            sk = lib.gtav_op_gemm_choose_splitk(M, N, K) if epi == 6 else 1
+            out = torch.empty((max(sk, 1) * (M + 127) // 128 * 128, N), device=dev, dtype=torch.float32 if epi == 6 else torch.float16)
+            q = torch.empty(3, M, 1024, device=dev, dtype=torch.float16)
+            cs = torch.ones(144, 64, device=dev)
+            sn = torch.zeros(144, 64, device=dev)
+            for ns, dbg in [(n_, d_) for n_ in a.stages for d_ in a.debug]:
+                lib.gtav_op_gemm_set_stages(ns)
+                lib.gtav_op_gemm_set_debug(dbg)
+
+                def run(i):
+                    w = ws[i % a.copies]
+                    if epi == 5:
+                        Mq = (M // 144) * 144
+                        L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Mq, 1024, 0, q[0].data_ptr(), q[1].data_ptr(),
+                                                     q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), sn.data_ptr(), st))
+                    elif epi == 6:
+                        g = lib.gtav_op_gemm_splitk_ln  # noqa: F841  (partial GEMM only: use the raw op below)
+                        L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), 0, out.data_ptr(), N, M, N, K, 6, 0, sk, 1, st))
+                    else:
+                        L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, 0, 0,
+                                                     1, st))
+                for i in range(8):
+                    run(i)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for i in range(a.iters):
+                    run(i)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / a.iters
+                print(f"{name:>5} {M:6d} {N:5d} {K:5d} {ns:3d} {sk:5d} {us:9.2f} {2.0 * M * N * K / us / 1e6:9.1f}  dbg={dbg}")
+    lib.gtav_op_gemm_set_stages(0)
+    lib.gtav_op_gemm_set_debug(0)
+
+
+if __name__ == "__main__":
+    main()
