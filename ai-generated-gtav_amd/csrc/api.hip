@@ -115,6 +115,7 @@ static std::vector<float> linspace_f32(float start, float end, int steps) {
 struct RopeTable {
     float* cos_dev = nullptr;
     float* sin_dev = nullptr;
+    float* cs_dev = nullptr;   // interleaved (cos, sin) table consumed by the QKV epilogue
     int npos = 0;
     bool set_cos = false, set_sin = false;
 };
@@ -225,6 +226,9 @@ struct gtav_dit {
     int* err_flag = nullptr;
     int* frame_idx = nullptr;   // [maxB * maxT]
     StepParams* step_dev = nullptr;
+    int* mod_rows_dev = nullptr;   // [maxB * maxT] rows of the per-frame conditioning table used by the current step
+    int* t_steps_dev = nullptr;    // [1024]
+    struct { bool valid = false; int B = 0, F = 0, start = 0, cur = 0, n_steps = 0; const float* actions = nullptr; } prepared;
     // captured hipGraphs of the fused sampler step, keyed by (shape, mode, buffers)
     struct GraphKey {
         int B, F, T, mode;
@@ -296,11 +300,11 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
             if (hf == 0) {
                 g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
-                g.rope_cos = h->rope_s.cos_dev; g.rope_sin = h->rope_s.sin_dev;
+                g.rope_cs = h->rope_s.cs_dev;
             } else {
                 g.qkv_mode = QKV_TEMPORAL; g.q = h->qt; g.k = h->kvcache[l]; g.v = h->kvcache[l];
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
-                g.rope_cos = h->rope_t.cos_dev; g.rope_sin = h->rope_t.sin_dev;
+                g.rope_cs = h->rope_t.cs_dev;
             }
             PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
             if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
@@ -406,6 +410,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->rope_s.sin_dev, (size_t)h->P * 64)); wt.add_f32("tables.rope_spatial_sin", h->P, 64, h->rope_s.sin_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_t.cos_dev, (size_t)h->maxT * 64)); wt.add_f32("tables.rope_temporal_cos", h->maxT, 64, h->rope_t.cos_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_t.sin_dev, (size_t)h->maxT * 64)); wt.add_f32("tables.rope_temporal_sin", h->maxT, 64, h->rope_t.sin_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_s.cs_dev, (size_t)h->P * 64)); A_(a.alloc_t(&h->rope_t.cs_dev, (size_t)h->maxT * 64));
     A_(a.alloc_t(&h->freqs_s_dev, 16)); wt.add_f32("spatial_rotary_emb.freqs", 1, 16, h->freqs_s_dev, 16, 0, false);
     A_(a.alloc_t(&h->freqs_t_dev, 32)); wt.add_f32("temporal_rotary_emb.freqs", 1, 32, h->freqs_t_dev, 32, 0, false);
     // workspace
@@ -421,7 +426,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     const size_t R = h->max_rows;
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
     A_(a.alloc_t(&h->err_flag, 4)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
-    A_(a.alloc_t(&h->step_dev, 4));
+    A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
     if (const char* e = getenv("GTAV_GRAPH")) h->use_graph = atoi(e) != 0;
 #undef A_
     if (rc) {
@@ -491,6 +496,8 @@ int gtav_dit_finalize(gtav_dit* h, void* stream) {
         }
         RET_IF(upload(h->sincos, tab));
     }
+    RET_IF(launch_rope_interleave(h->rope_s.cos_dev, h->rope_s.sin_dev, h->rope_s.cs_dev, h->P, s));
+    RET_IF(launch_rope_interleave(h->rope_t.cos_dev, h->rope_t.sin_dev, h->rope_t.cs_dev, h->maxT, s));
     GTAV_CHECK_HIP(hipStreamSynchronize(s));
     h->finalized = true;
     return 0;
@@ -516,12 +523,11 @@ int gtav_dit_set_schedule(gtav_dit* h, const float* ac, int32_t n) {
 
 // the kernel sequence of one fused sampler step; every step-varying scalar is read from h->step_dev
 static int denoise_step_body(gtav_dit* h, float* x, int B, int F, int T, const float* actions, int mode, float* v_out,
-                             hipStream_t s) {
+                             bool prepared, hipStream_t s) {
     const size_t fsz = (size_t)h->C * h->H * h->W;
     const int Tq = mode == 1 ? 1 : T, t0 = mode == 1 ? T - 1 : 0;
-    RET_IF(launch_frame_index(h->frame_idx, B, Tq, F, h->step_dev, mode == 1, s));
-    RET_IF(dit_cond(h, nullptr, B * Tq, Tq, h->step_dev, mode == 1, actions, (int64_t)F * h->A, h->A, s));
-    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, h->mod, nullptr, h->vout, s));
+    if (!prepared) RET_IF(dit_cond(h, nullptr, B * Tq, Tq, h->step_dev, mode == 1, actions, (int64_t)F * h->A, h->A, s));
+    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, h->mod, prepared ? h->mod_rows_dev : nullptr, h->vout, s));
     // DDIM update of frame `cur` (train_dit.py:110-125, generate.py:220)
     const float* vlast = h->vout + (size_t)(Tq - 1) * fsz;
     RET_IF(launch_ddim_update_step(x, F, vlast, (size_t)Tq * fsz, B, (int)fsz, h->step_dev, s));
@@ -529,9 +535,34 @@ static int denoise_step_body(gtav_dit* h, float* x, int B, int F, int T, const f
     return 0;
 }
 
+int gtav_dit_prepare_frame(gtav_dit* h, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
+                           const int32_t* t_steps_host, int32_t n_steps, const float* actions, void* stream) {
+    GTAV_REQUIRE(h && t_steps_host, "prepare_frame: null argument");
+    GTAV_REQUIRE(h->finalized, "prepare_frame: finalize the model first");
+    const int T = cur - start + 1;
+    GTAV_REQUIRE(start >= 0 && cur < F && T >= 1 && T <= h->maxT && B >= 1 && B <= h->maxB && n_steps >= 1 && n_steps <= 1024,
+                 "prepare_frame: bad window [%d, %d] / steps %d", start, cur, n_steps);
+    GTAV_REQUIRE(!actions || h->A > 0, "prepare_frame: model has no external_cond");
+    const int rows = B * (T - 1) + n_steps * B;
+    GTAV_REQUIRE(rows <= h->max_rows, "prepare_frame: %d conditioning rows exceed max_cond_rows %d", rows, h->max_rows);
+    hipStream_t s = (hipStream_t)stream;
+    // the host array may be freed by the caller after this call returns: synchronous copy (once per generated frame)
+    GTAV_CHECK_HIP(hipStreamSynchronize(s));
+    GTAV_CHECK_HIP(hipMemcpy(h->t_steps_dev, t_steps_host, n_steps * sizeof(int), hipMemcpyHostToDevice));
+    const int ldhc = h->D + h->Apad;
+    RET_IF(launch_cond_inputs_frame(rows, B, T, F, start, cur, t_ctx, h->t_steps_dev, h->sincos, h->E, actions, h->A, h->HC, ldhc,
+                                    h->D, h->Apad, h->err_flag, s));
+    RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, h->HC, ldhc, rows, h->D, 256, 1, s));
+    RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, h->Sc, h->D, rows, h->D, ldhc, 1, s));
+    RET_IF(launch_skinny_f32(h->Sc, h->D, h->w_ada, h->b_ada, h->mod, h->MODW, rows, h->MODW, h->D, 0, s));
+    h->prepared.valid = true; h->prepared.B = B; h->prepared.F = F; h->prepared.start = start; h->prepared.cur = cur;
+    h->prepared.n_steps = n_steps; h->prepared.actions = actions;
+    return 0;
+}
+
 int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
-                          int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions, int32_t mode, float* v_out,
-                          void* stream) {
+                          int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions, int32_t mode,
+                          int32_t cond_step, float* v_out, void* stream) {
     GTAV_REQUIRE(h && x, "denoise_step: null argument");
     GTAV_REQUIRE(h->finalized && !h->ac_host.empty(), "denoise_step: finalize the model and set the schedule first");
     const int T = cur - start + 1;
@@ -539,16 +570,23 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
     GTAV_REQUIRE(t_cur >= 0 && t_cur < 1000 && t_next >= 0 && t_next < 1000 && t_ctx >= 0 && t_ctx < 1000, "denoise_step: timestep out of range");
     GTAV_REQUIRE(!actions || h->A > 0, "denoise_step: model has no external_cond");
     GTAV_REQUIRE(mode == 0 || mode == 1, "denoise_step: mode %d", mode);
+    const bool prepared = cond_step >= 0;
+    if (prepared)
+        GTAV_REQUIRE(h->prepared.valid && h->prepared.B == B && h->prepared.F == F && h->prepared.start == start &&
+                         h->prepared.cur == cur && cond_step < h->prepared.n_steps && h->prepared.actions == actions,
+                     "denoise_step: cond_step=%d but gtav_dit_prepare_frame was not called for this window", cond_step);
+    else
+        h->prepared.valid = false;  // the inline path overwrites the conditioning table
     hipStream_t s = (hipStream_t)stream;
     StepParams sp;
     sp.first = start; sp.cur = cur; sp.t_ctx = t_ctx; sp.t_cur = t_cur; sp.is_final = is_final != 0;
-    sp.alpha_t = h->ac_host[t_cur]; sp.alpha_next = h->ac_host[t_next]; sp.pad = 0;
-    RET_IF(launch_set_step(h->step_dev, sp, s));
-    if (!h->use_graph || h->prof.on) return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+    sp.alpha_t = h->ac_host[t_cur]; sp.alpha_next = h->ac_host[t_next]; sp.cond_step = cond_step;
+    RET_IF(launch_step_setup(h->step_dev, sp, h->frame_idx, h->mod_rows_dev, B, mode == 1 ? 1 : T, T, F, mode == 1, s));
+    if (!h->use_graph || h->prof.on) return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
 
     // hipGraph path: the first step of a new (shape, buffers) key runs eagerly (warm-up: lazy module load, function
     // attributes), the second one is captured, later ones replay the captured graph (~240 kernel nodes, one launch).
-    gtav_dit::GraphKey key{B, F, T, mode, x, actions, v_out};
+    gtav_dit::GraphKey key{B, F, T, mode * 2 + (prepared ? 1 : 0), x, actions, v_out};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
         if (h->graphs.size() > 64) {
@@ -557,35 +595,35 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
             h->graphs.clear();
         }
         h->graphs[key] = nullptr;
-        return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+        return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
     }
     if (!it->second) {
         // capture on a private non-blocking stream (stream capture is not permitted on the legacy null stream, which is
         // what torch hands out by default); nothing executes during capture, the graph is launched on the caller's stream
         if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
             h->use_graph = false;
-            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
         }
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
             h->use_graph = false;
-            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
         }
-        const int rc = denoise_step_body(h, x, B, F, T, actions, mode, v_out, h->cap_stream);
+        const int rc = denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, h->cap_stream);
         const hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
         if (rc || ce != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
             h->use_graph = false;  // capture is not available here: fall back to eager launches for good
             if (rc) return rc;
-            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
         }
         hipGraphExec_t exec = nullptr;
         const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (ie != hipSuccess || !exec) {
             h->use_graph = false;
-            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, s);
+            return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
         }
         it->second = exec;
     }
@@ -668,7 +706,7 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_qkv; g.M = M; g.N = 3 * dim; g.K = dim; g.bias = b.b_qkv; g.D = dim; g.S = h->S;
-        g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cos = rope.cos_dev; g.rope_sin = rope.sin_dev;
+        g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cs = rope.cs_dev;
         RET_IF(launch_gemm(g, EPI_QKV, s));
         RET_IF(launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s));
         RET_IF(resid_gemm(h->ao, dim, b.w_proj, dim, b.b_proj));
@@ -748,6 +786,7 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->rope_e.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_enc_sin", h->S, 64, h->rope_e.sin_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_d.cos_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_cos", h->S, 64, h->rope_d.cos_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_d.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_sin", h->S, 64, h->rope_d.sin_dev, 64, 0, false);
+    A_(a.alloc_t(&h->rope_e.cs_dev, (size_t)h->S * 64)); A_(a.alloc_t(&h->rope_d.cs_dev, (size_t)h->S * 64));
     const size_t Mx = round_up(h->Mmax, 128), Dm = h->Dmax;
     A_(a.alloc_t(&h->xp, Mx * h->Kp)); A_(a.alloc_t(&h->xn, Mx * Dm)); A_(a.alloc_t(&h->q, Mx * Dm)); A_(a.alloc_t(&h->k, Mx * Dm));
     A_(a.alloc_t(&h->vt, Mx * Dm)); A_(a.alloc_t(&h->ao, Mx * Dm)); A_(a.alloc_t(&h->hbuf, Mx * h->Hmax)); A_(a.alloc_t(&h->zin, Mx * 64));
@@ -790,6 +829,9 @@ int gtav_vae_finalize(gtav_vae* h, void* stream) {
     };
     RET_IF(build(h->rope_e, "tables.rope_enc_cos", "tables.rope_enc_sin"));
     RET_IF(build(h->rope_d, "tables.rope_dec_cos", "tables.rope_dec_sin"));
+    RET_IF(launch_rope_interleave(h->rope_e.cos_dev, h->rope_e.sin_dev, h->rope_e.cs_dev, h->S, (hipStream_t)stream));
+    RET_IF(launch_rope_interleave(h->rope_d.cos_dev, h->rope_d.sin_dev, h->rope_d.cs_dev, h->S, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     h->finalized = true;
     return 0;
 }
@@ -877,13 +919,12 @@ int gtav_op_gemm_f16(const void* x, int32_t ldx, const void* w, const float* bia
     return launch_gemm(g, epilogue, (hipStream_t)stream);
 }
 int gtav_op_gemm_qkv(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t D, int32_t mode, void* q,
-                     void* k, void* v, int32_t S, int32_t Tq, int32_t t0, int32_t Tmax, const float* rope_cos,
-                     const float* rope_sin, void* stream) {
+                     void* k, void* v, int32_t S, int32_t Tq, int32_t t0, int32_t Tmax, const float* rope_cs, void* stream) {
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = (const f16*)x; g.ldx = ldx; g.W = (const f16*)w; g.M = M; g.N = 3 * D; g.K = D; g.bias = bias; g.D = D; g.S = S;
     g.qkv_mode = mode; g.q = (f16*)q; g.k = (f16*)k; g.v = (f16*)v; g.Tq = Tq; g.t0 = t0; g.Tmax = Tmax;
-    g.rope_cos = rope_cos; g.rope_sin = rope_sin;
+    g.rope_cs = rope_cs;
     return launch_gemm(g, EPI_QKV, (hipStream_t)stream);
 }
 int gtav_op_skinny_f32(const float* x, int32_t ldx, const float* w, const float* bias, float* y, int32_t ldy, int32_t M,
@@ -920,9 +961,13 @@ int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const floa
     pd.gate_stride = gate_stride; pd.rows_per_gate = rows_per_gate;
     return launch_ln_modulate(resid, N, (f16*)out_f16, N, M, N, shift, scale, mod_stride, nullptr, rows_per_gate, &pd, (hipStream_t)stream);
 }
+int gtav_op_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int32_t npos, void* stream) {
+    return launch_rope_interleave(cos_t, sin_t, cs, npos, (hipStream_t)stream);
+}
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K) { return gemm_choose_splitk(M, N, K); }
 void gtav_op_gemm_set_stages(int32_t ns) { gemm_set_stages(ns); }
 void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }
+void gtav_op_gemm_set_wm(int32_t wm) { gemm_set_wm(wm); }
 
 int gtav_op_convert_f16(const float* src, int32_t lds, int32_t R, int32_t C, void* dst, int32_t Rp, int32_t Cp, int32_t tiled,
                         void* stream) {

@@ -54,14 +54,14 @@ __host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
 // ---- small device math ------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 
-// GELU(approximate="tanh") as torch computes it: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+// GELU(approximate="tanh") as torch computes it: 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
+// 0.5 (1 + tanh u) == sigmoid(2u) == 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 + one v_rcp_f32 (1 ulp each; the
+// result is rounded to fp16 right after), exact limits at both tails (2^+inf -> rcp(inf) = 0, 2^-inf -> 1).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1); exact at both tails, no fast-math
-    float e = __expf(2.0f * u);
-    float th = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + th);
+    const float u = k0 * (x + k1 * x * x * x);
+    const float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // exact (erf) GELU: 0.5 x (1 + erf(x / sqrt(2)))

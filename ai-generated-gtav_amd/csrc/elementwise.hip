@@ -10,41 +10,146 @@ namespace gtav {
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm (eps 1e-6) over D, ONE BLOCK PER ROW (D/4 threads, one float4 each; D % 256 == 0 or D < 256), two-pass
-// fp32 statistics through LDS.  Optional deferred residual update first (LnPending): all slab/bias/gate loads of a
-// thread are independent and issued together, so the kernel is bandwidth- not latency-bound at small M.
+// LayerNorm (eps 1e-6) over D: ONE WAVE PER ROW (4 rows per 256-thread block), the row lives in registers
+// (NV float4 per lane, D <= 256 NV), two-pass fp32 statistics by wave shuffles — no LDS, no block barrier.
+// Every global load of a lane (row, split-K slabs, bias, gate, modulation vectors) is independent and issued
+// before the first reduction: one memory round trip per row.  Optional deferred residual update first (LnPending).
 // MODE 0: adaLN modulate  y = xhat * (1 + (scale + 1e-6)) + shift     (model/dit.py:19-27)
 // MODE 1: affine          y = xhat * gamma + beta                     (nn.LayerNorm, model/vae.py:174)
 // Output: fp16, tile-major (GEMM A-operand).
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool PEND>
-__global__ __launch_bounds__(512) void ln_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
+template <int MODE, bool PEND, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
                                                  const float* __restrict__ p0, const float* __restrict__ p1, int mod_stride,
                                                  const int* __restrict__ rows, int rows_per_mod, LnPending pd) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float* xr = x + (size_t)m * ldx;
+    const float *a, *b;  // MODE 0: a = scale row, b = shift row; MODE 1: a = gamma, b = beta
+    if (MODE == 0) {
+        int row = m / rows_per_mod;
+        if (rows) row = rows[row];
+        a = p1 + (size_t)row * mod_stride;
+        b = p0 + (size_t)row * mod_stride;
+    } else {
+        a = p0;
+        b = p1;
+    }
+    const float* grow = nullptr;
+    if (PEND && pd.gate) {
+        int gr = m / pd.rows_per_gate;
+        if (pd.gate_rows) gr = pd.gate_rows[gr];
+        grow = pd.gate + (size_t)gr * pd.gate_stride;
+    }
+    f32x4 v[NV], av[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        av[i] = v[i];
+        bv[i] = v[i];
+        if (c < D) {
+            v[i] = *(const f32x4*)(xr + c);
+            av[i] = *(const f32x4*)(a + c);
+            bv[i] = *(const f32x4*)(b + c);
+        }
+    }
+    if (PEND) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (c < D) {
+                f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* pp = pd.parts + (size_t)m * pd.ld + c;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp)
+                    if (sp < pd.nsplit) y = y + *(const f32x4*)(pp + (size_t)sp * pd.slab_stride);
+                if (grow) y = y * *(const f32x4*)(grow + c);
+                v[i] = v[i] + y;
+                *(f32x4*)(xr + c) = v[i];
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);   // idle chunks are zero
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i * 256 + lane * 4 < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[i][e] - mean) * rstd;
+                float y;
+                if (MODE == 0) {
+                    const float sc = av[i][e] + 1e-6f;
+                    y = xh * (1.0f + sc) + bv[i][e];
+                } else {
+                    y = xh * av[i][e] + bv[i][e];
+                }
+                o[e] = (f16)y;
+            }
+            *(f16x4*)(out + tiled_off(m, c, D)) = o;
+        }
+    }
+}
+
+// Small-M variant: ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS.  With only a few hundred
+// rows the wave-per-row kernel leaves most CUs idle; here every row gets its own block (measured: 720 rows 8.5 us vs 14.7).
+template <int MODE, bool PEND>
+__global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
+                                                           const float* __restrict__ p0, const float* __restrict__ p1,
+                                                           int mod_stride, const int* __restrict__ rows, int rows_per_mod,
+                                                           LnPending pd) {
     __shared__ float red[16];
     const int m = blockIdx.x;
     const int c = threadIdx.x * 4;
     const int nw = (blockDim.x + 63) >> 6, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* xr = x + (size_t)m * ldx;
-    const bool act = c < D;   // blocks are padded to whole waves (D / 4 may be < 64): idle lanes carry zeros
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (act) v = *(const f32x4*)(xr + c);
+    const bool act = c < D;
+    const float *a, *b;
+    if (MODE == 0) {
+        int row = m / rows_per_mod;
+        if (rows) row = rows[row];
+        a = p1 + (size_t)row * mod_stride;
+        b = p0 + (size_t)row * mod_stride;
+    } else {
+        a = p0;
+        b = p1;
+    }
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, av = v, bv = v;
+    if (act) {
+        v = *(const f32x4*)(xr + c);
+        av = *(const f32x4*)(a + c);
+        bv = *(const f32x4*)(b + c);
+    }
     if (PEND && act) {
-        f32x4 part[8];
+        f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* pp = pd.parts + (size_t)m * pd.ld + c;
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp)
-            if (sp < pd.nsplit) part[sp] = *(const f32x4*)(pd.parts + (size_t)sp * pd.slab_stride + (size_t)m * pd.ld + c);
-        f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 gt = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (sp < pd.nsplit) y = y + *(const f32x4*)(pp + (size_t)sp * pd.slab_stride);
         if (pd.gate) {
             int gr = m / pd.rows_per_gate;
             if (pd.gate_rows) gr = pd.gate_rows[gr];
-            gt = *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
+            y = y * *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
         }
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp)
-            if (sp < pd.nsplit) y = y + part[sp];
-        v = v + gt * y;
+        v = v + y;
         *(f32x4*)(xr + c) = v;
     }
     float s = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
@@ -60,19 +165,7 @@ __global__ __launch_bounds__(512) void ln_kernel(float* __restrict__ x, int ldx,
     float tq = 0.f;
     for (int i = 0; i < nw; ++i) tq += red[8 + i];
     const float rstd = 1.0f / sqrtf(tq / (float)D + 1e-6f);
-    const float *a, *b;  // MODE 0: a = scale row, b = shift row; MODE 1: a = gamma, b = beta
-    if (MODE == 0) {
-        int row = m / rows_per_mod;
-        if (rows) row = rows[row];
-        a = p1 + (size_t)row * mod_stride;
-        b = p0 + (size_t)row * mod_stride;
-    } else {
-        a = p0;
-        b = p1;
-    }
     if (!act) return;
-    const f32x4 av = *(const f32x4*)(a + c);
-    const f32x4 bv = *(const f32x4*)(b + c);
     const float dd[4] = {d0, d1, d2, d3};
     f16x4 o;
 #pragma unroll
@@ -144,6 +237,15 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, int lds, int R, i
     }
 }
 
+__global__ void rope_interleave_kernel(const float* cos_t, const float* sin_t, float* cs, int npos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < npos * 32) {
+        const int pos = i >> 5, k = i & 31;
+        cs[(size_t)pos * 64 + 2 * k] = cos_t[(size_t)pos * 64 + 2 * k];
+        cs[(size_t)pos * 64 + 2 * k + 1] = sin_t[(size_t)pos * 64 + 2 * k];
+    }
+}
+
 __global__ void fill_f32_kernel(float* dst, size_t n, float v) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) dst[idx] = v;
 }
@@ -153,8 +255,46 @@ __global__ void add_f32_kernel(const float* a, const float* b, float* out, size_
         out[idx] = a[idx] + b[idx];
 }
 
-__global__ void set_step_kernel(StepParams* dst, StepParams v) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+__global__ void step_setup_kernel(StepParams* dst, StepParams v, int* frame_idx, int* mod_rows, int B, int Tq, int T, int F,
+                                  int use_cur) {
+    if (threadIdx.x == 0) *dst = v;
+    const int first = use_cur ? v.cur : v.first;
+    for (int i = threadIdx.x; i < B * Tq; i += blockDim.x) {
+        const int b = i / Tq, tl = i - b * Tq;
+        frame_idx[i] = b * F + first + tl;
+        if (v.cond_step >= 0) {
+            const int tw = use_cur ? T - 1 : tl;   // position inside the window
+            mod_rows[i] = tw < T - 1 ? b * (T - 1) + tw : B * (T - 1) + v.cond_step * B + b;
+        }
+    }
+}
+
+__global__ void cond_inputs_frame_kernel(int rows, int B, int T, int F, int start, int cur, int t_ctx, const int* __restrict__ t_steps,
+                                         const float* __restrict__ sincos, float* __restrict__ E,
+                                         const float* __restrict__ actions, int A, float* __restrict__ HC, int ldhc, int D,
+                                         int Apad, int* err_flag) {
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    const int nctx = B * (T - 1);
+    int t, b, frame;
+    if (r < nctx) {
+        b = r / (T - 1);
+        frame = start + (r - b * (T - 1));
+        t = t_ctx;
+    } else {
+        const int q = r - nctx;
+        const int sidx = q / B;
+        b = q - sidx * B;
+        frame = cur;
+        t = t_steps[sidx];
+    }
+    if (t < 0 || t > 999) {
+        if (threadIdx.x == 0 && err_flag) atomicOr(err_flag, 1);
+        t = t < 0 ? 0 : 999;
+    }
+    for (int j = threadIdx.x; j < 256; j += blockDim.x) E[(size_t)r * 256 + j] = sincos[(size_t)t * 256 + j];
+    const float* arow = actions ? actions + ((size_t)b * F + frame) * A : nullptr;
+    for (int j = threadIdx.x; j < Apad; j += blockDim.x) HC[(size_t)r * ldhc + D + j] = (arow && j < A) ? arow[j] : 0.f;
 }
 
 __global__ void cond_inputs_kernel(const int64_t* __restrict__ t64, int rows, int Tq, const StepParams* __restrict__ sp, int use_cur,
@@ -278,11 +418,6 @@ __global__ void clamp_cols_kernel(float* buf, int M, int ld, int c0, int c1, flo
         buf[m * ld + c] = fminf(fmaxf(v, lo), hi);
     }
 }
-__global__ void frame_index_kernel(int* idx, int B, int Tq, int F, const StepParams* __restrict__ sp, int use_cur) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int first = use_cur ? sp->cur : sp->first;
-    if (i < B * Tq) idx[i] = (i / Tq) * F + first + (i % Tq);
-}
 // (N,3,H,W) f32 -> (N,H,W,3) u8 = clamp(img*255, 0, 255) truncated (torch .byte())
 __global__ void frames_to_u8_kernel(const float* __restrict__ img, uint8_t* __restrict__ out, int N, int H, int W) {
     const size_t total = (size_t)N * H * W * 3;
@@ -325,14 +460,29 @@ inline int grid_for(size_t total, int block = 256) {
 
 }  // namespace
 
-#define LN_DISPATCH(MODE, P0, P1, STRIDE, ROWS, RPM)                                                                      \
-    do {                                                                                                               \
-        LnPending pd_;                                                                                                 \
-        memset(&pd_, 0, sizeof(pd_));                                                                                  \
-        if (pend) pd_ = *pend;                                                                                         \
-        const dim3 grid_(M), block_(round_up(D / 4, 64));                                                              \
-        if (pend) hipLaunchKernelGGL((ln_kernel<MODE, true>), grid_, block_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
-        else hipLaunchKernelGGL((ln_kernel<MODE, false>), grid_, block_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
+#define LN_LAUNCH_(MODE, PEND, NV, P0, P1, STRIDE, ROWS, RPM) \
+    hipLaunchKernelGGL((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)
+#define LN_DISPATCH(MODE, P0, P1, STRIDE, ROWS, RPM)                                                     \
+    do {                                                                                                  \
+        LnPending pd_;                                                                                    \
+        memset(&pd_, 0, sizeof(pd_));                                                                     \
+        if (pend) pd_ = *pend;                                                                            \
+        const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
+        if (M <= 2048) { /* small M: one block per row */                                                 \
+            const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
+            if (pend) hipLaunchKernelGGL((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
+            else hipLaunchKernelGGL((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
+        } else if (pend) {                                                                                       \
+            if (nv_ == 1) LN_LAUNCH_(MODE, true, 1, P0, P1, STRIDE, ROWS, RPM);                           \
+            else if (nv_ == 2) LN_LAUNCH_(MODE, true, 2, P0, P1, STRIDE, ROWS, RPM);                      \
+            else if (nv_ == 4) LN_LAUNCH_(MODE, true, 4, P0, P1, STRIDE, ROWS, RPM);                      \
+            else LN_LAUNCH_(MODE, true, 8, P0, P1, STRIDE, ROWS, RPM);                                    \
+        } else {                                                                                          \
+            if (nv_ == 1) LN_LAUNCH_(MODE, false, 1, P0, P1, STRIDE, ROWS, RPM);                          \
+            else if (nv_ == 2) LN_LAUNCH_(MODE, false, 2, P0, P1, STRIDE, ROWS, RPM);                     \
+            else if (nv_ == 4) LN_LAUNCH_(MODE, false, 4, P0, P1, STRIDE, ROWS, RPM);                     \
+            else LN_LAUNCH_(MODE, false, 8, P0, P1, STRIDE, ROWS, RPM);                                   \
+        }                                                                                                 \
     } while (0)
 
 int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
@@ -355,6 +505,7 @@ int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const f
     return 0;
 }
 #undef LN_DISPATCH
+#undef LN_LAUNCH_
 
 int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo,
                     float a, float b, hipStream_t stream) {
@@ -392,6 +543,12 @@ int launch_copy_f32(const float* src, int lds, int R, int C, float* dst, int ldd
     return 0;
 }
 
+int launch_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int npos, hipStream_t stream) {
+    hipLaunchKernelGGL(rope_interleave_kernel, dim3(cdiv(npos * 32, 256)), dim3(256), 0, stream, cos_t, sin_t, cs, npos);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream) {
     hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, n, v);
     GTAV_CHECK_HIP(hipGetLastError());
@@ -404,8 +561,18 @@ int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStre
     return 0;
 }
 
-int launch_set_step(StepParams* dst, const StepParams& v, hipStream_t stream) {
-    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, stream, dst, v);
+int launch_step_setup(StepParams* dst, const StepParams& v, int* frame_idx, int* mod_rows, int B, int Tq, int T, int F,
+                      int use_cur, hipStream_t stream) {
+    hipLaunchKernelGGL(step_setup_kernel, dim3(1), dim3(64), 0, stream, dst, v, frame_idx, mod_rows, B, Tq, T, F, use_cur);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cond_inputs_frame(int rows, int B, int T, int F, int start, int cur, int t_ctx, const int* t_steps, const float* sincos,
+                             float* E, const float* actions, int A, float* HC, int ldhc, int D, int Apad, int* err_flag,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(cond_inputs_frame_kernel, dim3(rows), dim3(256), 0, stream, rows, B, T, F, start, cur, t_ctx, t_steps, sincos,
+                       E, actions, A, HC, ldhc, D, Apad, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -475,11 +642,6 @@ int launch_copy_rows_f32(const float* src, size_t src_stride, float* dst, size_t
 }
 int launch_clamp_cols(float* buf, int M, int ld, int c0, int c1, float lo, float hi, hipStream_t stream) {
     hipLaunchKernelGGL(clamp_cols_kernel, dim3(grid_for((size_t)M * (c1 - c0))), dim3(256), 0, stream, buf, M, ld, c0, c1, lo, hi);
-    GTAV_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-int launch_frame_index(int* idx, int B, int Tq, int F, const StepParams* sp, int use_cur, hipStream_t stream) {
-    hipLaunchKernelGGL(frame_index_kernel, dim3(cdiv(B * Tq, 256)), dim3(256), 0, stream, idx, B, Tq, F, sp, use_cur);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

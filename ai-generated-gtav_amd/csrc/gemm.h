@@ -48,8 +48,8 @@ struct GemmParams {
     int Tq;     // temporal: frames carried by this call's tokens
     int t0;     // temporal: window index of the first of those frames
     int Tmax;   // temporal: frames in the kv cache per batch item
-    const float* rope_cos;  // [npos][64]
-    const float* rope_sin;
+    const float* rope_cs;   // [npos][32][2]: (cos, sin) of rotation pair k at [pos][k] (interleaved-pair RoPE;
+                            // cos/sin of features 2k and 2k+1 are equal, rotary_embedding_torch.py:337)
 };
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.
@@ -59,5 +59,7 @@ int gemm_choose_splitk(int M, int N, int K);
 // Pipeline depth override for experiments (0 = heuristic, else 2 or 4 LDS stages).
 void gemm_set_stages(int ns);
 void gemm_set_debug(int bits);
+// Block shape override for experiments (0 = heuristic, 2 = 128 x 128 / 4 waves, 4 = 128 x 256 / 8 waves).
+void gemm_set_wm(int wm);
 
 }  // namespace gtav

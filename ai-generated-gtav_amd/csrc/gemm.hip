@@ -17,7 +17,7 @@ namespace gtav {
 
 namespace {
 
-constexpr int TN = 128, TM = 128, TK = 64;
+constexpr int TN = 128, TK = 64;
 constexpr int TILE_BYTES = 128 * TK * 2;  // 16 KiB per operand tile
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -36,77 +36,106 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
 // NS-stage LDS ring.  Tile t lives in stage t % NS.  Steady state: NS-1 tiles are in flight when iteration t starts;
 // the wave waits (counted vmcnt, never 0 in the main loop) until ITS OWN share of tile t has landed, the raw
 // s_barrier then (a) makes every wave's share of tile t visible and (b) proves every wave has finished reading
-// tile t-1, whose stage is refilled right after the barrier with tile t+NS-1.  One barrier per K-step; the
-// HBM/L2 -> LDS latency (~1.1 us under load) is covered by NS-2 further tiles in flight.
-template <bool TR, int NS>
+// tile t-1, whose stage is refilled right after the barrier with tile t+NS-1.  One barrier per K-step.
+//
+// Block shape: 2 waves along N (64 features each) x WM waves along M (16 FJ tokens each):
+//   WM = 2, FJ = 4: 128 x 128 tile, 4 waves, 32 KiB / stage
+//   WM = 4, FJ = 2: 128 x 128 tile, 8 waves (two per SIMD), 32 KiB / stage   (small M: overlap fills with MFMA)
+//   WM = 4, FJ = 4: 128 x 256 tile, 8 waves, 48 KiB / stage                  (large M: 1.5x fewer fill bytes per FLOP)
+// With two waves per SIMD the second half of the waves (4..7, the SIMD partners of 0..3) issues its share of the
+// next tile AFTER its MFMAs instead of before: a wave's direct-to-LDS loads back-pressure its in-order instruction
+// stream at the ~63 GB/s/CU fill rate (profiles/round1/v5_gemm_8wave_microbench.txt: fills-only and MFMA-only loops
+// cost the same and used to add up), so the partners' fill and MFMA phases now run beside each other.
+template <bool TR, int NS, int WM, int FJ>
 __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
-                                         f32x4 (&acc)[4][4]) {
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+                                         f32x4 (&acc)[4][FJ]) {
+    constexpr int NWAVE = 2 * WM;
+    constexpr int TMB = WM * 16 * FJ;                  // tokens per block tile
+    constexpr int XT = TMB / 128;                      // 128-row X tiles per stage
+    constexpr int STAGE_BYTES = (1 + XT) * TILE_BYTES;
+    constexpr int WP = 16 / NWAVE;                     // W pieces (1 KiB) per wave per stage
+    constexpr int XP = 16 * XT / NWAVE;                // X pieces per wave per stage
+    constexpr int G = WP + XP;                         // direct-to-LDS loads per wave per stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = w >> 1, wm = w & 1;
+    const int wn = w & 1, wm = w >> 1;
+    const bool late = NWAVE == 8 && w >= 4;             // SIMD partner of wave w - 4: fills after its MFMAs
 
     // ---- staging: operands are tile-major (common.h tiled_off): the 16 KiB tile (row-tile, k-tile) is contiguous and
-    // already in LDS-image order, so wave w copies bytes [4w KiB, 4w+4 KiB) of each tile with 4 linear 1 KiB pieces ----
+    // already in LDS-image order, so each 1 KiB piece is one linear direct-to-LDS instruction ----
     const int nktot = p.K / TK;
-    const char* wsrc = (const char*)p.W + ((size_t)(n0 >> 7) * nktot + kt0) * TILE_BYTES + (4 * w) * 1024 + lane * 16;
-    const char* xsrc = (const char*)p.X + ((size_t)(m0 >> 7) * nktot + kt0) * TILE_BYTES + (4 * w) * 1024 + lane * 16;
+    const char* wsrc = (const char*)p.W + ((size_t)(n0 >> 7) * nktot + kt0) * TILE_BYTES + (w * WP) * 1024 + lane * 16;
+    const int xq = w * XP;                              // first X piece of this wave (pieces 0 .. 16 XT - 1)
+    int xrt = (m0 >> 7) + (xq >> 4);
+    const int last_rt = (p.M - 1) >> 7;
+    xrt = xrt < last_rt ? xrt : last_rt;                // ragged last tile: re-read a valid row tile (results are masked)
+    const char* xsrc = (const char*)p.X + ((size_t)xrt * nktot + kt0) * TILE_BYTES + (xq & 15) * 1024 + lane * 16;
     auto stage = [&](int t) {
-        char* base = smem + (t % NS) * STAGE_BYTES + (4 * w) * 1024;
+        char* base = smem + (t % NS) * STAGE_BYTES;
         const char* ws = wsrc + (size_t)t * TILE_BYTES;
         const char* xs = xsrc + (size_t)t * TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(ws + i * 1024, base + i * 1024);
-            glds16(xs + i * 1024, base + TILE_BYTES + i * 1024);
-        }
+        for (int i = 0; i < WP; ++i) glds16(ws + i * 1024, base + (w * WP + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) glds16(xs + i * 1024, base + TILE_BYTES + (xq + i) * 1024);
     };
 
     // ---- fragment read offsets ----
     const int li = lane & 15, g = lane >> 4;
+    const int xrow0 = wm * 16 * FJ;                     // first token row of this wave inside the block tile
     int woff[2], xoff[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int ch = ((4 * s + g) ^ (li & 7)) << 4;
         woff[s] = (64 * wn + li) * 128 + ch;
-        xoff[s] = TILE_BYTES + (64 * wm + li) * 128 + ch;
+        xoff[s] = TILE_BYTES + (xrow0 >> 7) * TILE_BYTES + ((xrow0 & 127) + li) * 128 + ch;
     }
 
     const int npro = nkt < NS - 1 ? nkt : NS - 1;
     for (int t = 0; t < npro; ++t) stage(t);
     for (int t = 0; t < nkt; ++t) {
-        // tiles newer than t already issued: min(NS - 2, nkt - 1 - t), 8 loads each
+        // tiles newer than t already issued: min(NS - 2, nkt - 1 - t), G loads each
         const int rem = nkt - 1 - t;
-        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (t + NS - 1 < nkt && !(p.debug & 1)) stage(t + NS - 1);
+        const bool refill = t + NS - 1 < nkt && !(p.debug & 1);
+        if (refill && !late) stage(t + NS - 1);
         const char* b = smem + (t % NS) * STAGE_BYTES;
-        if (p.debug & 2) continue;
+        if (!(p.debug & 2)) {
+            // both 32-deep halves of the K-step are fetched up front: the second half's fragments arrive under the
+            // first half's MFMAs (the compiler emits the counted lgkmcnt waits)
+            f16x8 wf[2][4], xf[2][FJ];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 wf[4], xf[4];
+            for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
-                xf[i] = *(const f16x8*)(b + xoff[s] + i * 16 * 128);
+                for (int i = 0; i < 4; ++i) wf[s][i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) xf[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (TR)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[j], wf[i], acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j) {
+                        if (TR)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                    }
+        }
+        if (refill && late) {
+            asm volatile("" ::: "memory");   // keep the loads behind the MFMA block in program order
+            stage(t + NS - 1);
         }
     }
 }
 
-template <int EPI, int NS>
-__global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[NS * 2 * TILE_BYTES];
+template <int EPI, int NS, int WM, int FJ>
+__global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1)) void gemm_kernel(GemmParams p) {
+    constexpr int TM = WM * 16 * FJ;
+    __shared__ __attribute__((aligned(16))) char smem[NS * (1 + TM / 128) * TILE_BYTES];
     const int tiles_m = (p.M + TM - 1) / TM;
 
     // XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous
@@ -125,24 +154,24 @@ __global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p
     const int tile_n = tile_id / tiles_m, tile_m = tile_id - tile_n * tiles_m;
     const int n0 = tile_n * TN, m0 = tile_m * TM;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][FJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bool tr = false;
     if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
     if constexpr (EPI == EPI_QKV) {
-        if (tr) mainloop<true, NS>(p, smem, n0, m0, kt0, nkt, acc);
-        else mainloop<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
+        if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
+        else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
     } else {
-        mainloop<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
+        mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
     }
 
     // ------------------------------------ epilogue ------------------------------------
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wn = w >> 1, wm = w & 1, li = lane & 15, g = lane >> 4;
+    const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
 
     if constexpr (EPI == EPI_QKV) {
         if (tr) {
@@ -155,8 +184,8 @@ __global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p
                 const float bv = p.bias ? p.bias[n] : 0.f;
                 const int head = nn >> 6, d = nn & 63;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + 64 * wm + 16 * j + 4 * g;
+                for (int j = 0; j < FJ; ++j) {
+                    const int m = m0 + 16 * FJ * wm + 16 * j + 4 * g;
                     if (m >= p.M) continue;
                     const int nb = m / p.S, s = m - nb * p.S;
                     f16* dst = p.v + ((size_t)(nb * heads + head) * 64 + d) * p.S + s;
@@ -175,8 +204,8 @@ __global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI != EPI_PARTIAL && p.bias) bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + 64 * wm + 16 * j + li;
+        for (int j = 0; j < FJ; ++j) {
+            const int m = m0 + 16 * FJ * wm + 16 * j + li;
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + bv;
             if constexpr (EPI == EPI_PARTIAL) {
@@ -219,13 +248,13 @@ __global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p
                     pos = tfr;
                 }
                 if (which < 2) {
-                    const f32x4 c = *(const f32x4*)(p.rope_cos + pos * 64 + d);
-                    const f32x4 sn = *(const f32x4*)(p.rope_sin + pos * 64 + d);
+                    // interleaved table: (cos, sin) of pair d/2 and of pair d/2+1 in one 16-byte load
+                    const f32x4 cs = *(const f32x4*)(p.rope_cs + pos * 64 + d);
                     f32x4 r;
-                    r[0] = v[0] * c[0] - v[1] * sn[0];
-                    r[1] = v[1] * c[1] + v[0] * sn[1];
-                    r[2] = v[2] * c[2] - v[3] * sn[2];
-                    r[3] = v[3] * c[3] + v[2] * sn[3];
+                    r[0] = v[0] * cs[0] - v[1] * cs[1];
+                    r[1] = v[1] * cs[0] + v[0] * cs[1];
+                    r[2] = v[2] * cs[2] - v[3] * cs[3];
+                    r[3] = v[3] * cs[2] + v[2] * cs[3];
                     v = r;
                 }
                 const uint2 pk = pack4(v[0], v[1], v[2], v[3]);
@@ -249,21 +278,36 @@ __global__ __launch_bounds__(256, NS <= 2 ? 2 : 1) void gemm_kernel(GemmParams p
 
 }  // namespace
 
-static int g_force_stages = 0, g_debug = 0;
+static int g_force_stages = 0, g_debug = 0, g_force_wm = 0;
 void gemm_set_stages(int ns) { g_force_stages = ns; }
 void gemm_set_debug(int bits) { g_debug = bits; }
+void gemm_set_wm(int wm) { g_force_wm = wm; }
 
 int gemm_choose_splitk(int M, int N, int K) {
-    const int tiles = cdiv(M, TM) * cdiv(N, TN);
+    const int tiles = cdiv(M, 128) * cdiv(N, TN);
     int s = 1;
     while (tiles * s < 192 && s < 8 && (K / TK) % (s * 2) == 0 && K / (s * 2) >= 256) s *= 2;
     return s;
 }
 
+// shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves
 template <int EPI>
-static void launch_epi(const GemmParams& p, int ns, dim3 grid, hipStream_t stream) {
-    if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_kernel<EPI, 4>), grid, dim3(256), 0, stream, p);
+static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
+    if (shape == 4) {
+        const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, TN) * splitk);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4>), grid, dim3(512), 0, stream, p);
+    } else if (shape == 3) {
+        const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 2>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 4, 2>), grid, dim3(512), 0, stream, p);
+    } else {
+        const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 2, 4>), grid, dim3(256), 0, stream, p);
+    }
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
@@ -275,7 +319,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     int splitk = 1;
     if (epi == EPI_QKV) {
         GTAV_REQUIRE(p.N == 3 * p.D && p.D % 128 == 0, "gemm/qkv: N=%d must equal 3*D, D=%d %% 128 == 0", p.N, p.D);
-        GTAV_REQUIRE(p.S > 0 && p.q && p.k && p.rope_cos && p.rope_sin, "gemm/qkv: missing buffers");
+        GTAV_REQUIRE(p.S > 0 && p.q && p.k && p.rope_cs, "gemm/qkv: missing buffers");
         if (p.qkv_mode == QKV_SPATIAL) {
             GTAV_REQUIRE(p.S % 4 == 0 && p.M % p.S == 0 && p.v, "gemm/qkv spatial: S=%d must divide M=%d, S %% 4 == 0", p.S, p.M);
         } else {
@@ -283,28 +327,30 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         }
     } else {
         GTAV_REQUIRE(p.out && p.ldo >= p.N && p.ldo % 4 == 0, "gemm: bad output ldo=%d", p.ldo);
-        if (epi == EPI_GELU_TANH || epi == EPI_GELU_ERF) GTAV_REQUIRE(p.ldo % 64 == 0, "gemm/gelu: tile-major output needs ldo %% 64 == 0");
         if (epi == EPI_RESID && p.gate) GTAV_REQUIRE(p.rows_per_gate > 0, "gemm/resid: rows_per_gate");
+        if (epi == EPI_GELU_TANH || epi == EPI_GELU_ERF) GTAV_REQUIRE(p.ldo % 64 == 0, "gemm/gelu: tile-major output needs ldo %% 64 == 0");
         if (epi == EPI_PARTIAL) {
             splitk = p.splitk;
             GTAV_REQUIRE(splitk >= 1 && (p.K / TK) % splitk == 0, "gemm/partial: splitk=%d must divide K/64=%d", splitk, p.K / TK);
         }
     }
-    const int tiles = cdiv(p.M, TM) * cdiv(p.N, TN);
-    // pipeline depth: 4 stages (128 KB LDS, 1 block per CU) when the grid cannot put two blocks on every CU anyway
-    int ns = g_force_stages ? g_force_stages : (tiles * splitk < 2 * 256 ? 4 : 2);
-    dim3 grid(tiles * splitk);
+    // Block shape (measured, profiles/round1/v6_gemm_shapes_microbench.txt):
+    //   grid < 256 blocks of 128 x 128 (one block per CU at most): 8 waves per block (two staggered waves per SIMD),
+    //     4-stage ring — 17-25 % faster than 4 waves at M = 720;
+    //   larger grids: 4 waves, 2-stage ring, two co-resident blocks per CU; the 128 x 256 / 8-wave tile (shape 4) ties it.
+    const int blocks128 = cdiv(p.M, 128) * cdiv(p.N, TN) * splitk;
+    int wm = g_force_wm ? g_force_wm : (blocks128 <= 256 ? 3 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm == 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
-        case EPI_F32: launch_epi<EPI_F32>(p, ns, grid, stream); break;
-        case EPI_F16: launch_epi<EPI_F16>(p, ns, grid, stream); break;
-        case EPI_GELU_TANH: launch_epi<EPI_GELU_TANH>(p, ns, grid, stream); break;
-        case EPI_GELU_ERF: launch_epi<EPI_GELU_ERF>(p, ns, grid, stream); break;
-        case EPI_RESID: launch_epi<EPI_RESID>(p, ns, grid, stream); break;
-        case EPI_QKV: launch_epi<EPI_QKV>(p, ns, grid, stream); break;
-        case EPI_PARTIAL: launch_epi<EPI_PARTIAL>(p, ns, grid, stream); break;
+        case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
+        case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);
+        case EPI_GELU_TANH: return launch_epi<EPI_GELU_TANH>(p, ns, wm, splitk, stream);
+        case EPI_GELU_ERF: return launch_epi<EPI_GELU_ERF>(p, ns, wm, splitk, stream);
+        case EPI_RESID: return launch_epi<EPI_RESID>(p, ns, wm, splitk, stream);
+        case EPI_QKV: return launch_epi<EPI_QKV>(p, ns, wm, splitk, stream);
+        case EPI_PARTIAL: return launch_epi<EPI_PARTIAL>(p, ns, wm, splitk, stream);
         default: GTAV_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
-    GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -20,9 +20,17 @@ struct StepParams {
     int t_cur;      // timestep of frame `cur`
     int is_final;   // noise_idx == 0: return x_start (train_dit.py:119-120)
     float alpha_t, alpha_next;
-    int pad;
+    int cond_step;  // >= 0: row set of the per-frame conditioning table prepared by gtav_dit_prepare_frame; -1: inline
 };
-int launch_set_step(StepParams* dst, const StepParams& v, hipStream_t stream);
+// One launch ahead of the (possibly graph-replayed) step: *dst = v, frame_idx[b*Tq+tl] = b*F + first + tl
+// (first = use_cur ? v.cur : v.first) and, when v.cond_step >= 0, the conditioning-table row of every processed frame:
+// context frame (b, tl < T-1) -> b*(T-1)+tl, frame `cur` of sample b -> B*(T-1) + cond_step*B + b.
+int launch_step_setup(StepParams* dst, const StepParams& v, int* frame_idx, int* mod_rows, int B, int Tq, int T, int F,
+                      int use_cur, hipStream_t stream);
+// Conditioning inputs for a whole generated frame (rows laid out as above, n_steps row sets for frame `cur`).
+int launch_cond_inputs_frame(int rows, int B, int T, int F, int start, int cur, int t_ctx, const int* t_steps, const float* sincos,
+                             float* E, const float* actions, int A, float* HC, int ldhc, int D, int Apad, int* err_flag,
+                             hipStream_t stream);
 
 // Deferred residual update executed by the LayerNorm that follows a residual GEMM (model/dit.py:207-223):
 //   x[m] += gate[row(m)] * (sum_s parts[s][m] + bias)      (gate == nullptr -> 1, i.e. the VAE's plain residual)
@@ -69,14 +77,14 @@ int launch_copy_f32_strided(const float* src, int lds, int R, int C, float* dst,
 int launch_copy_rows_f32(const float* src, size_t src_stride, float* dst, size_t dst_stride, int rows, size_t n, hipStream_t stream);
 // buf[m][c] = clamp(buf[m][c], lo, hi) for c in [c0, c1)
 int launch_clamp_cols(float* buf, int M, int ld, int c0, int c1, float lo, float hi, hipStream_t stream);
-// idx[b * Tq + tl] = b * F + first + tl, first = use_cur ? sp->cur : sp->first
-int launch_frame_index(int* idx, int B, int Tq, int F, const StepParams* sp, int use_cur, hipStream_t stream);
 int launch_frames_to_u8(const float* img, uint8_t* out, int N, int H, int W, hipStream_t stream);
 int launch_moments_to_latents(const float* mom, float* lat, int N, int hw, int latent, int mom_ch, float scale, hipStream_t stream);
 int launch_latents_to_tokens(const float* lat, float* z, int N, int hw, int latent, hipStream_t stream);
 // fp32 strided copy with padding (used to build concatenated fp32 weights): dst[r][c0 + c] = src[r][c]
 int launch_copy_f32(const float* src, int lds, int R, int C, float* dst, int ldd, int c0, hipStream_t stream);
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
+// cs[pos][k] = (cos[pos][2k], sin[pos][2k]) for k < 32: the GEMM epilogue's interleaved RoPE table
+int launch_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int npos, hipStream_t stream);
 int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
 
 // Conditioning inputs (model/dit.py:96-118,359-364) for `rows` (b, frame) pairs, row r = (r / Tq, r % Tq):

@@ -50,12 +50,14 @@ def vae_decode_frames(x: torch.Tensor, vae, scaling_factor: float = SCALING_FACT
 @torch.inference_mode()
 def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_steps: int, noise_chunks: torch.Tensor,
                      actions: Optional[torch.Tensor] = None, stabilization_level: int = 15, noise_abs_max: float = 20.0,
-                     clamp_min: float = 1e-4, ctx_cache: bool = False) -> torch.Tensor:
+                     clamp_min: float = 1e-4, ctx_cache: bool = False, hoist_cond: bool = True) -> torch.Tensor:
     """generate.py:186-220.  x_prompt (B, n_prompt, C, h, w) latents; noise_chunks (B, total-n_prompt, C, h, w)
     standard-normal draws (clamped to +-noise_abs_max here, generate.py:201-202); actions (B, total, 25) or None.
     ctx_cache=False re-runs the whole window on every noise step exactly like the reference;
     ctx_cache=True runs the window once per generated frame and then only the frame being denoised,
     taking the context K/V of the temporal layers from the cache (same result, ~4.8x less work).
+    hoist_cond=True builds the conditioning (adaLN) table of all noise steps of a frame in one batch per frame (the
+    conditioning never depends on x); False recomputes it inside every step like DiT.forward does. Same results.
     Returns latents (B, total_frames, C, h, w) on the model's device."""
     dev = model.device
     B, n_prompt = x_prompt.shape[:2]
@@ -66,12 +68,15 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
     model.set_schedule(_alphas_cumprod(clamp_min))
     noise_range = torch.linspace(0, 999, noise_steps + 1)                      # generate.py:194 (float)
     t_of = [int(v) for v in noise_range]                                       # long() truncation (train_dit.py:70)
+    order = list(reversed(range(0, noise_steps + 1)))
     for i in range(n_prompt, total_frames):
         start = max(0, i + 1 - model.max_frames)                              # generate.py:204
-        for noise_idx in reversed(range(0, noise_steps + 1)):
+        if hoist_cond:
+            model.prepare_frame_(B, total_frames, start, i, stabilization_level, [t_of[k] for k in order], act)
+        for step, noise_idx in enumerate(order):
             cached = ctx_cache and noise_idx != noise_steps
             model.denoise_step_(x, start, i, stabilization_level, t_of[noise_idx], t_of[max(0, noise_idx - 1)],
-                                noise_idx <= 0, act, cached=cached)
+                                noise_idx <= 0, act, cached=cached, cond_step=step if hoist_cond else -1)
     model.check()
     return x
 

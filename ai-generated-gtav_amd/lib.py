@@ -54,7 +54,8 @@ SIGNATURES = {
     "gtav_dit_get_weight": [_p, C.c_char_p, _p, _l, _p],
     "gtav_dit_forward": [_p, _p, _p, _p, _p, _i, _i, _p],
     "gtav_dit_set_schedule": [_p, C.POINTER(C.c_float), _i],
-    "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
+    "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
+    "gtav_dit_prepare_frame": [_p, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _p, _p],
     "gtav_dit_check": [_p, _p],
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_profile": [_p, _i],
@@ -74,7 +75,8 @@ SIGNATURES = {
     "gtav_moments_to_latents": [_p, _p, _i, _i, _i, _i, _f, _p],
     "gtav_latents_to_tokens": [_p, _p, _i, _i, _i, _p],
     "gtav_op_gemm_f16": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
-    "gtav_op_gemm_qkv": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p],
+    "gtav_op_gemm_qkv": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "gtav_op_rope_interleave": [_p, _p, _p, _i, _p],
     "gtav_op_skinny_f32": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "gtav_op_ln_modulate": [_p, _p, _i, _i, _p, _p, _i, _i, _p],
     "gtav_op_ln_affine": [_p, _p, _i, _i, _p, _p, _p],
@@ -85,9 +87,10 @@ SIGNATURES = {
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],
     "gtav_op_gemm_set_stages": [_i],
     "gtav_op_gemm_set_debug": [_i],
+    "gtav_op_gemm_set_wm": [_i],
 }
 _RESTYPES = {"gtav_last_error": C.c_char_p, "gtav_dit_destroy": None, "gtav_vae_destroy": None, "gtav_op_gemm_set_stages": None,
-             "gtav_op_gemm_set_debug": None}
+             "gtav_op_gemm_set_debug": None, "gtav_op_gemm_set_wm": None}
 
 _lib = None
 

@@ -157,6 +157,7 @@ class DiT(_HipModule):
                                 hidden_size=hidden_size, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
                                 external_cond_dim=external_cond_dim)
         self._capacity_b, self._capacity_t = max_batch, max(max_frames, 1)
+        self._capacity_rows = 0
         hd = hidden_size // num_heads
         self._spatial_freqs = _w.rope_freqs_pixel(hd // 2, 256)   # model/dit.py:259-261
         self._temporal_freqs = _w.rope_freqs_lang(hd)             # model/dit.py:262
@@ -207,7 +208,10 @@ class DiT(_HipModule):
         self._dirty = True
 
     # ------------------------------------------------------------------------------------------
-    def _ensure(self, B: int, T: int):
+    def _ensure(self, B: int, T: int, cond_rows: int = 0):
+        if cond_rows > max(self._capacity_rows, self._capacity_b * self._capacity_t):
+            self._capacity_rows = cond_rows
+            self._free()
         if T > self._capacity_t:
             self._capacity_t = T
             self._free()
@@ -217,7 +221,7 @@ class DiT(_HipModule):
         if not self._handle:
             L = _lib.load()
             cfg = _lib.DitConfig(max_frames=self._capacity_t, max_batch=self._capacity_b,
-                                 max_cond_rows=self._capacity_b * self._capacity_t, **self._cfg_kwargs)
+                                 max_cond_rows=max(self._capacity_b * self._capacity_t, self._capacity_rows), **self._cfg_kwargs)
             with torch.cuda.device(self.device):
                 _lib.check(L.gtav_dit_create(C.byref(cfg), C.byref(self._handle)))
             self._dirty = True
@@ -260,16 +264,28 @@ class DiT(_HipModule):
             arr = (C.c_float * 1000).from_buffer_copy(ac.numpy().tobytes())
             _lib.check(_lib.load().gtav_dit_set_schedule(self._handle, arr, 1000))
 
+    def prepare_frame_(self, B: int, F: int, start: int, cur: int, t_ctx: int, t_steps, actions: Optional[torch.Tensor] = None):
+        """Builds the conditioning (adaLN) table for every noise step of one generated frame (gtav_dit_prepare_frame);
+        step k of that frame then passes cond_step=k to denoise_step_."""
+        n = len(t_steps)
+        self._ensure(B, cur - start + 1, cond_rows=B * (cur - start + n))
+        arr = (C.c_int32 * n)(*[int(v) for v in t_steps])
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_prepare_frame(self._handle, B, F, start, cur, int(t_ctx), arr, n, _lib.ptr(actions),
+                                                          _lib.current_stream()))
+
     def denoise_step_(self, x: torch.Tensor, start: int, cur: int, t_ctx: int, t_cur: int, t_next: int, is_final: bool,
-                      actions: Optional[torch.Tensor] = None, cached: bool = False, v_out: Optional[torch.Tensor] = None):
+                      actions: Optional[torch.Tensor] = None, cached: bool = False, v_out: Optional[torch.Tensor] = None,
+                      cond_step: int = -1):
         """In-place fused step on latents x (B, F, C, H, W) fp32 contiguous on the model's device."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         B, F = x.shape[:2]
-        self._ensure(B, cur - start + 1)
+        if cond_step < 0:
+            self._ensure(B, cur - start + 1)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().gtav_dit_denoise_step(
                 self._handle, x.data_ptr(), B, F, start, cur, int(t_ctx), int(t_cur), int(t_next), int(bool(is_final)),
-                _lib.ptr(actions), 1 if cached else 0, _lib.ptr(v_out), _lib.current_stream()))
+                _lib.ptr(actions), 1 if cached else 0, int(cond_step), _lib.ptr(v_out), _lib.current_stream()))
 
     PROFILE_CLASSES = ("ln_modulate", "gemm_qkv", "attn_spatial", "attn_temporal", "gemm_out", "gemm_fc1", "gemm_fc2", "other")
 

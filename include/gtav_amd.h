@@ -69,10 +69,18 @@ int gtav_dit_set_schedule(gtav_dit* h, const float* alphas_cumprod_host, int32_t
  * mode 1: context-cached step — only frame `cur` is pushed through the network, context K/V of every
  *         temporal layer come from the cache left by the last mode-0 call on the same window
  *         (exact: context activations do not depend on frame `cur`).
- * actions (B, F, external_cond_dim) or NULL.  v_out (B, C, H, W) optional: v_pred of frame `cur`. */
+ * actions (B, F, external_cond_dim) or NULL.  v_out (B, C, H, W) optional: v_pred of frame `cur`.
+ * cond_step: -1 computes the conditioning c = t_emb(t) + action and its adaLN projections inside the step (as
+ *   DiT.forward does, model/dit.py:359-366); >= 0 takes them from the table built by gtav_dit_prepare_frame. */
 int gtav_dit_denoise_step(gtav_dit* h, float* x_dev, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
                           int32_t t_cur, int32_t t_next, int32_t is_final, const float* actions_dev, int32_t mode,
-                          float* v_out_dev, void* stream);
+                          int32_t cond_step, float* v_out_dev, void* stream);
+/* The conditioning does not depend on x: for one generated frame (window [start, cur]) the adaLN table of every noise
+ * step is computed at once — context rows with t_ctx, n_steps row sets for frame `cur` with t_steps_host[s] — so the
+ * 0.8 GB of fp32 conditioning weights are streamed once per frame instead of once per step.  Same arithmetic, same
+ * results; needs max_cond_rows >= B * (cur - start + n_steps). */
+int gtav_dit_prepare_frame(gtav_dit* h, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
+                           const int32_t* t_steps_host, int32_t n_steps, const float* actions_dev, void* stream);
 
 /* The fused step replays a captured hipGraph per (shape, buffers) key by default (env GTAV_GRAPH=0 or this call
  * switch to plain launches; results are identical). */
@@ -152,10 +160,12 @@ int gtav_latents_to_tokens(const float* lat_dev, float* z_dev, int32_t N, int32_
 int gtav_op_gemm_f16(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, void* out_dev,
                      int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* gate_dev,
                      int32_t gate_stride, int32_t rows_per_gate, void* stream);
-/* fused QKV projection + RoPE + attention-layout scatter. mode 0 spatial, 1 temporal (see csrc/gemm.h). */
+/* fused QKV projection + RoPE + attention-layout scatter. mode 0 spatial, 1 temporal (see csrc/gemm.h).
+ * rope_cs_dev: interleaved (cos, sin) table [npos][32][2] built by gtav_op_rope_interleave from cos/sin [npos][64]. */
 int gtav_op_gemm_qkv(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,
                      int32_t D, int32_t mode, void* q_dev, void* k_dev, void* v_dev, int32_t S, int32_t Tq, int32_t t0,
-                     int32_t Tmax, const float* rope_cos_dev, const float* rope_sin_dev, void* stream);
+                     int32_t Tmax, const float* rope_cs_dev, void* stream);
+int gtav_op_rope_interleave(const float* cos_dev, const float* sin_dev, float* cs_dev, int32_t npos, void* stream);
 int gtav_op_skinny_f32(const float* x_dev, int32_t ldx, const float* w_dev, const float* bias_dev, float* y_dev,
                        int32_t ldy, int32_t M, int32_t N, int32_t K, int32_t act_silu, void* stream);
 int gtav_op_ln_modulate(const float* x_dev, void* out_f16_dev, int32_t M, int32_t D, const float* shift_dev,
@@ -177,6 +187,8 @@ int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K);
 void gtav_op_gemm_set_stages(int32_t ns);
 /* Experiments (results become WRONG): bit 0 skips the LDS fills after the prologue, bit 1 skips LDS reads + MFMA. */
 void gtav_op_gemm_set_debug(int32_t bits);
+/* Experiments: force the GEMM block shape (0 = heuristic, 2 = 128x128 tile / 4 waves, 4 = 128x256 tile / 8 waves). */
+void gtav_op_gemm_set_wm(int32_t wm);
 /* fp32 [R][C] -> fp16 [Rp][Cp] zero padded; tiled != 0 writes the GEMM's tile-major operand layout (128 x 64 tiles,
  * csrc/common.h tiled_off; Rp % 128 == 0, Cp % 64 == 0).  All fp16 GEMM operands (x_f16_dev, w_f16_dev) and the fp16
  * outputs of gtav_op_ln_*, gtav_op_attn_* and the GELU epilogues use that layout. */

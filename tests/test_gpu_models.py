@@ -163,10 +163,12 @@ def test_small_rollout_config1_shape():
         ref = O.generate_latents(dit_fn, x0, 4, 10, noise, a, max_frames=5)
     out = generate_latents(m, x0, 4, 10, noise, a)
     out_c = generate_latents(m, x0, 4, 10, noise, a, ctx_cache=True)
+    out_i = generate_latents(m, x0, 4, 10, noise, a, hoist_cond=False)   # conditioning recomputed inside every step
     e, ec = rel_l2(out, ref), rel_l2(out_c, ref)
-    print("rollout rel-L2 window", e, "cached", ec, "cached-vs-window", rel_l2(out_c, out))
+    print("rollout rel-L2 window", e, "cached", ec, "cached-vs-window", rel_l2(out_c, out), "inline-cond-vs-hoisted", rel_l2(out_i, out))
     assert e < 1e-2 and ec < 1e-2   # 33 chained forwards; per-forward bound is tested above
     assert rel_l2(out_c, out) < 1e-4
+    assert rel_l2(out_i, out) < 1e-6   # hoisting the conditioning is the same arithmetic
 
 
 def test_train_forward_loss():

@@ -84,15 +84,17 @@ def test_gemm_qkv_spatial_layout_and_rope():
     x = _rand(M, D, seed=1).half()
     w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
     bias = _rand(3 * D, seed=7)
-    ang = _rand(S, 64, seed=3) * 3
+    ang = (_rand(S, 32, seed=3) * 3).repeat_interleave(2, dim=-1)   # each frequency repeated twice (rotary_embedding_torch.py:337)
     cos, sin = ang.cos(), ang.sin()
     w16 = pad_weight_f16(w)
     q = torch.zeros(NB, heads, S, 64, device=dev(), dtype=torch.float16)
     k = torch.zeros_like(q)
     vt = torch.zeros(NB, heads, 64, S, device=dev(), dtype=torch.float16)
     xd, bd, cd, sd_ = to_tiled_f16(x), bias.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
+    cs = torch.empty_like(cd)
+    L.check(L.load().gtav_op_rope_interleave(cd.data_ptr(), sd_.data_ptr(), cs.data_ptr(), S, stream()))
     L.check(L.load().gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), bd.data_ptr(), M, D, 0, q.data_ptr(),
-                                      k.data_ptr(), vt.data_ptr(), S, 0, 0, 0, cd.data_ptr(), sd_.data_ptr(), stream()))
+                                      k.data_ptr(), vt.data_ptr(), S, 0, 0, 0, cs.data_ptr(), stream()))
     y = (x.float() @ w.half().float().t() + bias).reshape(NB, S, 3, heads, 64)
     qr = _rope_ref(y[:, :, 0].permute(0, 2, 1, 3), cos[None, None], sin[None, None])
     kr = _rope_ref(y[:, :, 1].permute(0, 2, 1, 3), cos[None, None], sin[None, None])
@@ -107,14 +109,16 @@ def test_gemm_qkv_temporal_layout():
     M = B * Tq * P
     x = _rand(M, D, seed=1).half()
     w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
-    ang = _rand(Tmax, 64, seed=3) * 3
+    ang = (_rand(Tmax, 32, seed=3) * 3).repeat_interleave(2, dim=-1)
     cos, sin = ang.cos(), ang.sin()
     w16 = pad_weight_f16(w)
     q = torch.zeros(M, D, device=dev(), dtype=torch.float16)
     kv = torch.zeros(B, Tmax, P, 2, D, device=dev(), dtype=torch.float16)
     xd, cd, sd_ = to_tiled_f16(x), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
+    cs = torch.empty_like(cd)
+    L.check(L.load().gtav_op_rope_interleave(cd.data_ptr(), sd_.data_ptr(), cs.data_ptr(), Tmax, stream()))
     L.check(L.load().gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), 0, M, D, 1, q.data_ptr(), kv.data_ptr(),
-                                      kv.data_ptr(), P, Tq, t0, Tmax, cd.data_ptr(), sd_.data_ptr(), stream()))
+                                      kv.data_ptr(), P, Tq, t0, Tmax, cs.data_ptr(), stream()))
     y = (x.float() @ w.half().float().t()).reshape(B, Tq, P, 3, D // 64, 64)
     pos = torch.arange(t0, t0 + Tq)
     c, s = cos[pos][None, :, None, None, :], sin[pos][None, :, None, None, :]
@@ -139,12 +143,12 @@ def test_skinny_f32(M, N, K, act):
     assert rel_l2(y, ref) < 2e-6
 
 
-@pytest.mark.parametrize("D", [128, 256, 1024])
-def test_layernorm_kernels(D):
-    M, P = 96, 32
+@pytest.mark.parametrize("D,M", [(128, 96), (256, 96), (1024, 96), (1024, 2304)])
+def test_layernorm_kernels(D, M):
+    P = 32
     x = _rand(M, D, seed=1) * 3 + 0.5
     mod = _rand(M // P, 2 * D, seed=2)
-    out = torch.zeros(128, D, device=dev(), dtype=torch.float16)
+    out = torch.zeros((M + 127) // 128 * 128, D, device=dev(), dtype=torch.float16)
     md, xd = mod.to(dev()), x.to(dev())
     L.check(L.load().gtav_op_ln_modulate(xd.data_ptr(), out.data_ptr(), M, D, md.data_ptr(), md[:, D:].data_ptr(), 2 * D, P,
                                          stream()))
@@ -264,4 +268,25 @@ def test_gemm_pipeline_depths_agree(ns):
             gemm(xd, w16, None, M, N, K, 0, out, N)
             assert rel_l2(out, x.float() @ w.half().float().t()) < 2e-5, (ns, M, N, K)
     finally:
+        lib.gtav_op_gemm_set_stages(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(5760, 1024, 1024), (700, 384, 192), (256, 128, 64), (1300, 256, 4096)])
+def test_gemm_8wave_tile_matches(M, N, K):
+    """The 8-wave block shapes (3: 128 x 128, 4: 128 x 256; staggered fills) against fp32 math, incl. ragged last tiles."""
+    lib = L.load()
+    try:
+      for shape in (3, 4):
+        lib.gtav_op_gemm_set_wm(shape)
+        for ns in ((2, 4) if shape == 3 else (2, 3)):
+            lib.gtav_op_gemm_set_stages(ns)
+            x = _rand(M, K, seed=1).half()
+            w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+            b = _rand(N, seed=3)
+            w16, xd, bd = pad_weight_f16(w), to_tiled_f16(x), b.to(dev())
+            out = torch.full((M, N), float("nan"), device=dev())
+            gemm(xd, w16, bd, M, N, K, 0, out, N)
+            assert rel_l2(out, x.float() @ w.half().float().t() + b) < 2e-5, (shape, ns, M, N, K)
+    finally:
+        lib.gtav_op_gemm_set_wm(0)
         lib.gtav_op_gemm_set_stages(0)

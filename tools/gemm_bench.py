@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--ms", type=int, nargs="+", default=[144, 720, 1152, 5760, 11520])
     ap.add_argument("--debug", type=int, nargs="+", default=[0], help="gemm debug bits to sweep (1 = no fills, 2 = no MFMA)")
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--wm", type=int, nargs="+", default=[0], help="block shapes to sweep: 0 heuristic, 2 = 128x128/4 waves, 4 = 128x256/8 waves")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda", 0)
@@ -38,16 +39,17 @@ def main():
             q = torch.empty(3, M, 1024, device=dev, dtype=torch.float16)
             cs = torch.ones(144, 64, device=dev)
             sn = torch.zeros(144, 64, device=dev)
-            for ns, dbg in [(n_, d_) for n_ in a.stages for d_ in a.debug]:
+            for ns, dbg, wm in [(n_, d_, w_) for w_ in a.wm for n_ in a.stages for d_ in a.debug]:
                 lib.gtav_op_gemm_set_stages(ns)
                 lib.gtav_op_gemm_set_debug(dbg)
+                lib.gtav_op_gemm_set_wm(wm)
 
                 def run(i):
                     w = ws[i % a.copies]
                     if epi == 5:
                         Mq = (M // 144) * 144
                         L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Mq, 1024, 0, q[0].data_ptr(), q[1].data_ptr(),
-                                                     q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), sn.data_ptr(), st))
+                                                     q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), st))
                     elif epi == 6:
                         g = lib.gtav_op_gemm_splitk_ln  # noqa: F841  (partial GEMM only: use the raw op below)
                         L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), 0, out.data_ptr(), N, M, N, K, 6, 0, sk, 1, st))
@@ -64,9 +66,10 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / a.iters
-                print(f"{name:>5} {M:6d} {N:5d} {K:5d} {ns:3d} {sk:5d} {us:9.2f} {2.0 * M * N * K / us / 1e6:9.1f}  dbg={dbg}")
+                print(f"{name:>5} {M:6d} {N:5d} {K:5d} {ns:3d} {sk:5d} {us:9.2f} {2.0 * M * N * K / us / 1e6:9.1f}  dbg={dbg} wm={wm}")
     lib.gtav_op_gemm_set_stages(0)
     lib.gtav_op_gemm_set_debug(0)
+    lib.gtav_op_gemm_set_wm(0)
 
 
 if __name__ == "__main__":
