@@ -132,8 +132,92 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
     }
 }
 
-template <int EPI, int NS, int WM, int FJ>
-__global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1)) void gemm_kernel(GemmParams p) {
+// Loader-specialised main loop (shape 5: 128 x 256 tile, 8 compute waves + 2 loader waves = 640 threads).
+// A wave's direct-to-LDS loads back-pressure its in-order instruction stream at the ~63 GB/s/CU fill rate, so when
+// every wave both fills and computes, fill time and MFMA time add up between two barriers.  Here waves 8 and 9 do
+// nothing but issue the 48 one-KiB pieces of every stage (24 each, counted vmcnt, <= 48 in flight) and waves 0..7
+// nothing but ds_read + MFMA; all ten meet at the one barrier per K-step, which publishes tile t and frees stage t-1.
+template <bool TR, int NS>
+__device__ __forceinline__ void mainloop_ls(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                            f32x4 (&acc)[4][4]) {
+    constexpr int STAGE_BYTES = 3 * TILE_BYTES;   // [W 16 KiB][X rows 0..127][X rows 128..255]
+    constexpr int PIECES = 24;                     // per loader wave per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nktot = p.K / TK;
+    if (w >= 8) {
+        // ------------------------------ loader waves ------------------------------
+        const int l = w - 8;
+        const int last_rt = (p.M - 1) >> 7;
+        int rt0 = m0 >> 7, rt1 = rt0 + 1;
+        rt0 = rt0 < last_rt ? rt0 : last_rt;
+        rt1 = rt1 < last_rt ? rt1 : last_rt;       // ragged last tile: re-read a valid row tile (results are masked)
+        const char* wb = (const char*)p.W + ((size_t)(n0 >> 7) * nktot + kt0) * TILE_BYTES + lane * 16;
+        const char* x0 = (const char*)p.X + ((size_t)rt0 * nktot + kt0) * TILE_BYTES + lane * 16;
+        const char* x1 = (const char*)p.X + ((size_t)rt1 * nktot + kt0) * TILE_BYTES + lane * 16;
+        auto stage = [&](int t) {
+            char* base = smem + (t % NS) * STAGE_BYTES;
+            const size_t ko = (size_t)t * TILE_BYTES;
+            if (l == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) glds16(wb + ko + i * 1024, base + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) glds16(x0 + ko + i * 1024, base + TILE_BYTES + i * 1024);
+            } else {
+#pragma unroll
+                for (int i = 8; i < 16; ++i) glds16(x0 + ko + i * 1024, base + TILE_BYTES + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) glds16(x1 + ko + i * 1024, base + 2 * TILE_BYTES + i * 1024);
+            }
+        };
+        const int npro = nkt < NS - 1 ? nkt : NS - 1;
+        for (int t = 0; t < npro; ++t) stage(t);
+        for (int t = 0; t < nkt; ++t) {
+            const int rem = nkt - 1 - t;
+            if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + NS - 1 < nkt && !(p.debug & 1)) stage(t + NS - 1);
+        }
+        return;
+    }
+    // ------------------------------ compute waves ------------------------------
+    const int wn = w & 1, wm = w >> 1;
+    const int li = lane & 15, g = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = (64 * wn + li) * 128 + ch;
+        xoff[s] = TILE_BYTES + (wm >> 1) * TILE_BYTES + (64 * (wm & 1) + li) * 128 + ch;
+    }
+    for (int t = 0; t < nkt; ++t) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (p.debug & 2) continue;
+        const char* b = smem + (t % NS) * STAGE_BYTES;
+        f16x8 wf[2][4], xf[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wf[s][i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+                xf[s][i] = *(const f16x8*)(b + xoff[s] + i * 16 * 128);
+            }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (TR)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                }
+    }
+}
+
+template <int EPI, int NS, int WM, int FJ, int NL>
+__global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1))) void gemm_kernel(GemmParams p) {
     constexpr int TM = WM * 16 * FJ;
     __shared__ __attribute__((aligned(16))) char smem[NS * (1 + TM / 128) * TILE_BYTES];
     const int tiles_m = (p.M + TM - 1) / TM;
@@ -162,7 +246,15 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 :
 
     bool tr = false;
     if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-    if constexpr (EPI == EPI_QKV) {
+    if constexpr (NL > 0) {
+        static_assert(NL == 0 || (WM == 4 && FJ == 4), "loader waves: 128 x 256 tile only");
+        if constexpr (EPI == EPI_QKV) {
+            if (tr) mainloop_ls<true, NS>(p, smem, n0, m0, kt0, nkt, acc);
+            else mainloop_ls<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
+        } else {
+            mainloop_ls<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
+        }
+    } else if constexpr (EPI == EPI_QKV) {
         if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
         else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
     } else {
@@ -172,6 +264,47 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 :
     // ------------------------------------ epilogue ------------------------------------
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
+    const bool compute_wave = threadIdx.x < 128 * WM;   // loader waves (NL > 0) carry no accumulators
+
+    if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
+        // The fp16 output is the next GEMM's A operand (tile-major).  The block's TM x 128 result is assembled in LDS in
+        // exactly that image — (TM / 128) x 2 sub-tiles of [128 tokens][64 features], 16 KiB each — and then copied out
+        // as fully contiguous 1 KiB pieces (16 B per lane) instead of 16 scattered 8-byte stores per lane.
+        __syncthreads();   // every wave is done reading the last K-step's stage
+        if (compute_wave) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nl = 64 * wn + 16 * i + 4 * g;           // feature inside the block tile (4 consecutive)
+                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *(const f32x4*)(p.bias + n0 + nl);
+                const int c = nl & 63;                              // feature inside the 64-wide sub-tile (= 16 i + 4 g)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    const int ml = 16 * FJ * wm + 16 * j + li;      // token inside the block tile
+                    const int r = ml & 127;
+                    char* dst = smem + ((ml >> 7) * 2 + wn) * TILE_BYTES + r * 128 + (((c >> 3) ^ (r & 7)) << 4) + (c & 7) * 2;
+                    const f32x4 v = acc[i][j] + bv;
+                    if constexpr (EPI == EPI_GELU_TANH)
+                        *(uint2*)dst = pack4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+                    else
+                        *(uint2*)dst = pack4(gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
+                }
+            }
+        }
+        __syncthreads();
+        const int nkt_out = p.ldo >> 6, last_rt = (p.M - 1) >> 7;
+        constexpr int NPIECE = (TM / 128) * 2 * 16;
+        for (int q = w; q < NPIECE; q += (int)(blockDim.x >> 6)) {
+            const int st = q >> 4, pq = q & 15;
+            const int rt = (m0 >> 7) + (st >> 1);
+            if (rt > last_rt) continue;                              // ragged last block tile
+            const uint4 val = *(const uint4*)(smem + st * TILE_BYTES + pq * 1024 + lane * 16);
+            char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + (st & 1)) * TILE_BYTES + pq * 1024 + lane * 16;
+            *(uint4*)dst = val;
+        }
+        return;
+    }
+    if (!compute_wave) return;
 
     if constexpr (EPI == EPI_QKV) {
         if (tr) {
@@ -290,21 +423,25 @@ int gemm_choose_splitk(int M, int N, int K) {
     return s;
 }
 
-// shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves
+// shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 4) {
+    if (shape == 5) {
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4>), grid, dim3(512), 0, stream, p);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4, 2>), grid, dim3(640), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4, 2>), grid, dim3(640), 0, stream, p);
+    } else if (shape == 4) {
+        const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, TN) * splitk);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4, 0>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4, 0>), grid, dim3(512), 0, stream, p);
     } else if (shape == 3) {
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 2>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 4, 2>), grid, dim3(512), 0, stream, p);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 2, 0>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 4, 2, 0>), grid, dim3(512), 0, stream, p);
     } else {
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 2, 4>), grid, dim3(256), 0, stream, p);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4, 0>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 2, 4, 0>), grid, dim3(256), 0, stream, p);
     }
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
@@ -340,7 +477,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     //   larger grids: 4 waves, 2-stage ring, two co-resident blocks per CU; the 128 x 256 / 8-wave tile (shape 4) ties it.
     const int blocks128 = cdiv(p.M, 128) * cdiv(p.N, TN) * splitk;
     int wm = g_force_wm ? g_force_wm : (blocks128 <= 256 ? 3 : 2);
-    int ns = g_force_stages ? g_force_stages : (wm == 4 ? 3 : wm == 3 ? 4 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm >= 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);

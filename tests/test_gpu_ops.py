@@ -273,10 +273,10 @@ def test_gemm_pipeline_depths_agree(ns):
 
 @pytest.mark.parametrize("M,N,K", [(5760, 1024, 1024), (700, 384, 192), (256, 128, 64), (1300, 256, 4096)])
 def test_gemm_8wave_tile_matches(M, N, K):
-    """The 8-wave block shapes (3: 128 x 128, 4: 128 x 256; staggered fills) against fp32 math, incl. ragged last tiles."""
+    """The 8-wave block shapes (3: 128 x 128, 4: 128 x 256 with staggered fills, 5: 128 x 256 with 2 dedicated loader waves) against fp32 math, incl. ragged last tiles."""
     lib = L.load()
     try:
-      for shape in (3, 4):
+      for shape in (3, 4, 5):
         lib.gtav_op_gemm_set_wm(shape)
         for ns in ((2, 4) if shape == 3 else (2, 3)):
             lib.gtav_op_gemm_set_stages(ns)
