@@ -146,7 +146,7 @@ static void build_axial_table(const std::vector<float>& freqs, int gh, int gw, s
 
 // In-situ kernel timing (opt-in): HIP events on the launch stream around every kernel of a forward,
 // accumulated per kernel class.  Used by bench.py for the roofline line; off in normal operation.
-enum ProfClass { PC_LN = 0, PC_QKV, PC_ATTN_S, PC_ATTN_T, PC_OUT, PC_FC1, PC_FC2, PC_OTHER, PC_COUNT };
+enum ProfClass { PC_LN = 0, PC_QKV, PC_ATTN_S, PC_ATTN_T, PC_OUT, PC_FC1, PC_FC2, PC_OTHER, PC_EMPTY, PC_COUNT };
 struct Profiler {
     bool on = false;
     std::vector<hipEvent_t> ev;   // pairs
@@ -324,6 +324,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
     PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
     PROF(h, PC_OTHER, s, launch_unpatchify(h->fo, h->Nfin, v_out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
+    PROF(h, PC_EMPTY, s, 0);   // an event pair around nothing: the per-pair overhead to subtract from every class
     return h->prof.collect(s);
 }
 

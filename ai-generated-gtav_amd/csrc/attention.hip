@@ -35,19 +35,49 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
     const f16* Vg = Vt + (size_t)bh * 64 * S;
     const f16* Qg = Q + (size_t)bh * S * 64;
 
-    // ---- stage K (swizzled) and Vt (padded), zero the padding ----
-    for (int idx = tid; idx < S_pad * 8; idx += 256) {
-        const int r = idx >> 3, c = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < S) v = *(const uint4*)(Kg + (size_t)r * 64 + c * 8);
-        *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = v;
-    }
-    const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
-    for (int idx = tid; idx < 64 * vchunks; idx += 256) {
-        const int d = idx / vchunks, c = idx - d * vchunks;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c * 8 < S) v = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
-        *(uint4*)(Vs + d * vstride + c * 16) = v;
+    // ---- stage K (swizzled) and Vt (padded), zero the padding; loads are issued in batches of 6 before the LDS
+    // writes so that a thread has all of them in flight at once (S = 144: one batch each) ----
+    {
+        const int nk = S_pad * 8;
+        for (int base = tid; base < nk; base += 256 * 6) {
+            uint4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * 256;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nk && (idx >> 3) < S) v[u] = *(const uint4*)(Kg + (size_t)(idx >> 3) * 64 + (idx & 7) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * 256;
+                if (idx < nk) {
+                    const int r = idx >> 3, c = idx & 7;
+                    *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = v[u];
+                }
+            }
+        }
+        const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
+        const int nv = 64 * vchunks;
+        for (int base = tid; base < nv; base += 256 * 6) {
+            uint4 v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * 256;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nv) {
+                    const int d = idx / vchunks, c = idx - d * vchunks;
+                    if (c * 8 < S) v[u] = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * 256;
+                if (idx < nv) {
+                    const int d = idx / vchunks, c = idx - d * vchunks;
+                    *(uint4*)(Vs + d * vstride + c * 16) = v[u];
+                }
+            }
+        }
     }
     __syncthreads();
 

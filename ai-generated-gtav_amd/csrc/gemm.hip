@@ -235,7 +235,17 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
         nkt = nkt / p.splitk;
         kt0 = ks * nkt;
     }
-    const int tile_n = tile_id / tiles_m, tile_m = tile_id - tile_n * tiles_m;
+    // Inside an XCD's contiguous run of tiles the order is (m, n) with n FASTEST over a group of `gn` n-panels (gn =
+    // tiles_n / 8, the panels one XCD owns): co-resident blocks then share X row-tiles as well as W panels in that XCD's
+    // 4 MiB L2.  With m fastest, X (11.8 MB at M = 5760) was re-streamed from the fabric once per n-panel: rocprofv3
+    // FETCH_SIZE 301 MB per fc1 launch against 20 MB algorithmic (profiles/round1/pmc).
+    const int tiles_n = (p.N + TN - 1) / TN;
+    int gn = tiles_n >= 8 ? tiles_n >> 3 : 1;
+    const int group = tiles_m * gn;
+    const int ng = tile_id / group, rem = tile_id - ng * group;
+    const int n_first = ng * gn;
+    if (n_first + gn > tiles_n) gn = tiles_n - n_first;   // last, partial group
+    const int tile_m = rem / gn, tile_n = n_first + (rem - tile_m * gn);
     const int n0 = tile_n * TN, m0 = tile_m * TM;
 
     f32x4 acc[4][FJ];
@@ -330,12 +340,41 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
         }
     }
 
+    // token-side index math once per token column (integer divisions by runtime S / Tq are ~40 instructions each)
+    int tok_m[FJ], tok_a[FJ], tok_b[FJ], tok_pos[FJ];
+    if constexpr (EPI == EPI_QKV) {
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int m = m0 + 16 * FJ * wm + 16 * j + li;
+            tok_m[j] = m;
+            if (p.qkv_mode == QKV_SPATIAL) {
+                const int nb = m / p.S;
+                tok_a[j] = nb;                 // frame
+                tok_b[j] = m - nb * p.S;       // token in frame
+                tok_pos[j] = tok_b[j];
+            } else {
+                const int fr = m / p.S;        // frame counter over (b, tl)
+                const int b = fr / p.Tq;
+                const int tfr = p.t0 + (fr - b * p.Tq);
+                tok_a[j] = (b * p.Tmax + tfr) * p.S + (m - fr * p.S);   // kv-cache token slot
+                tok_b[j] = 0;
+                tok_pos[j] = tfr;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + 64 * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
         if (n >= p.N) continue;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI != EPI_PARTIAL && p.bias) bv = *(const f32x4*)(p.bias + n);
+        int which = 0, nn = n, head = 0, d = 0;
+        if constexpr (EPI == EPI_QKV) {
+            which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
+            nn = n - which * p.D;
+            head = nn >> 6;
+            d = nn & 63;
+        }
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
             const int m = m0 + 16 * FJ * wm + 16 * j + li;
@@ -347,12 +386,6 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
                 *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
             } else if constexpr (EPI == EPI_F16) {
                 *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) = pack4(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == EPI_GELU_TANH) {
-                *(uint2*)((f16*)p.out + tiled_off(m, n, p.ldo)) =
-                    pack4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
-            } else if constexpr (EPI == EPI_GELU_ERF) {
-                *(uint2*)((f16*)p.out + tiled_off(m, n, p.ldo)) =
-                    pack4(gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
             } else if constexpr (EPI == EPI_RESID) {
                 float* dst = (float*)p.out + (size_t)m * p.ldo + n;
                 f32x4 x = *(const f32x4*)dst;
@@ -366,23 +399,9 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
                 }
                 *(f32x4*)dst = x;
             } else if constexpr (EPI == EPI_QKV) {
-                const int which = n / p.D, nn = n - which * p.D;
-                const int head = nn >> 6, d = nn & 63;
-                int pos, b = 0, tfr = 0, pp = 0, nb = 0, s = 0;
-                if (p.qkv_mode == QKV_SPATIAL) {
-                    nb = m / p.S;
-                    s = m - nb * p.S;
-                    pos = s;
-                } else {
-                    const int fr = m / p.S;  // frame counter over (b, tl)
-                    pp = m - fr * p.S;
-                    b = fr / p.Tq;
-                    tfr = p.t0 + (fr - b * p.Tq);
-                    pos = tfr;
-                }
                 if (which < 2) {
                     // interleaved table: (cos, sin) of pair d/2 and of pair d/2+1 in one 16-byte load
-                    const f32x4 cs = *(const f32x4*)(p.rope_cs + pos * 64 + d);
+                    const f32x4 cs = *(const f32x4*)(p.rope_cs + tok_pos[j] * 64 + d);
                     f32x4 r;
                     r[0] = v[0] * cs[0] - v[1] * cs[1];
                     r[1] = v[1] * cs[0] + v[0] * cs[1];
@@ -394,13 +413,12 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
                 if (p.qkv_mode == QKV_SPATIAL) {
                     const int heads = p.D >> 6;
                     f16* base = which == 0 ? p.q : p.k;
-                    *(uint2*)(base + ((size_t)(nb * heads + head) * p.S + s) * 64 + d) = pk;
+                    *(uint2*)(base + ((size_t)(tok_a[j] * heads + head) * p.S + tok_b[j]) * 64 + d) = pk;
                 } else {
                     if (which == 0) {
                         *(uint2*)(p.q + (size_t)m * p.D + nn) = pk;
                     } else {
-                        const size_t tok = ((size_t)b * p.Tmax + tfr) * p.S + pp;
-                        f16* base = p.k + tok * 2 * p.D + (which == 2 ? p.D : 0);
+                        f16* base = p.k + (size_t)tok_a[j] * 2 * p.D + (which == 2 ? p.D : 0);
                         *(uint2*)(base + nn) = pk;
                     }
                 }

@@ -287,15 +287,16 @@ class DiT(_HipModule):
                 self._handle, x.data_ptr(), B, F, start, cur, int(t_ctx), int(t_cur), int(t_next), int(bool(is_final)),
                 _lib.ptr(actions), 1 if cached else 0, int(cond_step), _lib.ptr(v_out), _lib.current_stream()))
 
-    PROFILE_CLASSES = ("ln_modulate", "gemm_qkv", "attn_spatial", "attn_temporal", "gemm_out", "gemm_fc1", "gemm_fc2", "other")
+    PROFILE_CLASSES = ("ln_modulate", "gemm_qkv", "attn_spatial", "attn_temporal", "gemm_out", "gemm_fc1", "gemm_fc2", "other",
+                       "empty_event_pair")
 
     def profile(self, enable: bool):
         """In-situ per-kernel-class HIP-event timing (measurement passes only; see include/gtav_amd.h)."""
         _lib.check(_lib.load().gtav_dit_profile(self._handle, int(bool(enable))))
 
     def profile_read(self):
-        ms = (C.c_double * 8)()
-        n = (C.c_int64 * 8)()
+        ms = (C.c_double * 9)()
+        n = (C.c_int64 * 9)()
         _lib.check(_lib.load().gtav_dit_profile_read(self._handle, ms, n))
         return {k: (ms[i], n[i]) for i, k in enumerate(self.PROFILE_CLASSES)}
 

@@ -185,13 +185,22 @@ def main():
     fwd_ms = (time.perf_counter() - t0) / nfw * 1e3
     M = B * 5 * P_TOK
     flops_fc1 = 2.0 * M * HM * D_MODEL
+    ev_ms, ev_n = prof.pop("empty_event_pair")
+    ev_over_ms = ev_ms / max(ev_n, 1)                  # cost of one HIP-event pair around nothing
     ms_fc1, n_fc1 = prof["gemm_fc1"]
+    # raw event-pair time: it includes ~2 us of marker overhead per launch (rocprofv3 shows the kernel itself ~2 us shorter,
+    # profiles/README.md), i.e. the roofline fraction below is conservative; the empty-pair time is reported for reference
     avg_fc1_ms = ms_fc1 / max(n_fc1, 1)
     ach = flops_fc1 / (avg_fc1_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per fc1 launch from rocprofv3 --pmc passes (profiles/README.md)
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj.get("fc1_M%d" % M, {}).get("hbm_bytes_per_launch")
     roofline = {"kernel": "gemm_kernel<EPI_GELU_TANH> (fc1 GEMM M=%d N=4096 K=1024, fp16 MFMA)" % M, "bound": "mfma",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": round(avg_fc1_ms * 1e3, 2), "launches_timed": int(n_fc1),
-                "flops_per_launch": flops_fc1}
+                "traffic": traffic, "avg_launch_us": round(avg_fc1_ms * 1e3, 2), "launches_timed": int(n_fc1),
+                "flops_per_launch": flops_fc1, "empty_event_pair_us": round(ev_over_ms * 1e3, 2)}
     classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
     fwd_flops = dit_forward_flops(M, B * 5, 15, B)
     step_tflops = fwd_flops / (fwd_ms * 1e-3) / 1e12

@@ -89,8 +89,9 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
  * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).
  * Classes: 0 LN+modulate, 1 QKV GEMM, 2 spatial attention, 3 temporal attention, 4 out-proj GEMM, 5 fc1 GEMM,
- * 6 fc2 GEMM, 7 other (patchify, embed, final, unpatchify).  Conditioning kernels are not included. */
-#define GTAV_PROFILE_CLASSES 8
+ * 6 fc2 GEMM, 7 other (patchify, embed, final, unpatchify), 8 an EMPTY event pair (the timing overhead per pair, to be
+ * subtracted from every class average).  Conditioning kernels are not included. */
+#define GTAV_PROFILE_CLASSES 9
 int gtav_dit_profile(gtav_dit* h, int32_t enable);
 int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class);
 
