@@ -26,6 +26,24 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx,
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     float* xr = x + (size_t)m * ldx;
+    // loads that do not depend on the (optional) row indirection go first: the row itself and the split-K slabs
+    f32x4 v[NV], y[NV], av[NV], bv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        y[i] = v[i];
+        if (c < D) {
+            v[i] = *(const f32x4*)(xr + c);
+            if (PEND) {
+                if (pd.bias) y[i] = *(const f32x4*)(pd.bias + c);
+                const float* pp = pd.parts + (size_t)m * pd.ld + c;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp)
+                    if (sp < pd.nsplit) y[i] = y[i] + *(const f32x4*)(pp + (size_t)sp * pd.slab_stride);
+            }
+        }
+    }
     const float *a, *b;  // MODE 0: a = scale row, b = shift row; MODE 1: a = gamma, b = beta
     if (MODE == 0) {
         int row = m / rows_per_mod;
@@ -42,31 +60,17 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx,
         if (pd.gate_rows) gr = pd.gate_rows[gr];
         grow = pd.gate + (size_t)gr * pd.gate_stride;
     }
-    f32x4 v[NV], av[NV], bv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        av[i] = v[i];
-        bv[i] = v[i];
+        av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[i] = av[i];
         if (c < D) {
-            v[i] = *(const f32x4*)(xr + c);
             av[i] = *(const f32x4*)(a + c);
             bv[i] = *(const f32x4*)(b + c);
-        }
-    }
-    if (PEND) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = i * 256 + lane * 4;
-            if (c < D) {
-                f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const float* pp = pd.parts + (size_t)m * pd.ld + c;
-#pragma unroll
-                for (int sp = 0; sp < 8; ++sp)
-                    if (sp < pd.nsplit) y = y + *(const f32x4*)(pp + (size_t)sp * pd.slab_stride);
-                if (grow) y = y * *(const f32x4*)(grow + c);
-                v[i] = v[i] + y;
+            if (PEND) {
+                if (grow) y[i] = y[i] * *(const f32x4*)(grow + c);
+                v[i] = v[i] + y[i];
                 *(f32x4*)(xr + c) = v[i];
             }
         }

@@ -63,6 +63,66 @@ def host_cores():
     return max(1, min(n, 32))
 
 
+def bench_train(args, world, rank, dev, dist):
+    """configs[4]: forward + loss of train_dit.py `_shared_step` (configs/train_dit_actions.yaml: batch 16 per GPU, 4 prompt
+    frames + 1 target, ddim_noise_steps 50, ctx_max_noise_idx 40, clamp_min 1e-6) on synthetic 360x640 clips.  A step = one
+    batch per GPU: VAE-encode 80 frames -> noise -> one DiT forward (B, T=5) -> v-target MSE; the scalar loss is all-reduced."""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT_models
+    from gtav_amd.model.vae import VAE_models
+    from gtav_amd.train import encode_frames, forward_loss
+    B = args.batch_per_gpu if args.batch_per_gpu > 1 else 16
+    dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+    dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
+    vae = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=40)
+    vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
+    g = torch.Generator().manual_seed(100 + rank)
+    frames = torch.rand(B, 5, 3, 360, 640, generator=g).to(dev)
+    actions = torch.zeros(B, 5, 25, device=dev)
+    actions[:, :, 3] = 1
+    tgt = torch.randint(1, 51, (B,), generator=g)
+    ctx = torch.randint(1, 41, (B,), generator=g)
+    ctx_noise = torch.randn(B, 4, 16, 18, 32, generator=g).to(dev)
+    noise = torch.randn(B, 1, 16, 18, 32, generator=g).to(dev)
+
+    def step():
+        lat = encode_frames(vae, frames)
+        loss, _, _ = forward_loss(dit, lat, actions, tgt, ctx, ctx_noise, noise)
+        if world > 1:
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+            loss /= world
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+    if rank == 0:
+        flops = B * (dit_forward_flops(5 * P_TOK, 5, 15, 1) + 5 * 96.6e9)   # DiT forward + VAE encode (SURVEY.md §8(d))
+        print(json.dumps({
+            "metric": "training forward+loss samples/sec (5-frame clips, configs/train_dit_actions.yaml shapes)",
+            "value": round(world * B * args.steps / el, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "fp16 (fp32 accumulate/residual)", "data": "synthetic", "loss": float(loss.item()),
+            "config": {"workload": "BASELINE configs[4]: train_dit.py forward+loss, batch %d per GPU, DiT-S/2 + VAE encode of %d frames" % (B, 5 * B),
+                       "global_batch": world * B, "parallelism": "data-parallel x%d (forward only; loss all-reduce)" % world},
+            "achieved_tflops_per_gpu": round(flops * args.steps / el / 1e12, 1)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +138,9 @@ def main():
                          "cached = exact context-K/V-cached variant; both = time both (value = window)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip VAE encode/decode (DiT loop only; not the headline)")
+    ap.add_argument("--mode", choices=["generate", "train"], default="generate",
+                    help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
+                         "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,6 +159,8 @@ def main():
     from gtav_amd.model.dit import DiT_models
     from gtav_amd.model.vae import VAE_models
 
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev, dist)
     B = args.batch_per_gpu
     total, n_prompt, steps = args.total_frames, args.n_prompt, args.noise_steps
     # ---- models with deterministic synthetic weights (every matrix non-zero, incl. adaLN) ----

@@ -190,3 +190,51 @@ def test_train_forward_loss():
     assert rel_l2(vt, vt_r) < 1e-6
     assert rel_l2(vp, vp_r) < 2e-3
     assert abs(loss.item() - loss_r.item()) / loss_r.item() < 2e-3
+
+
+def test_state_dict_round_trip_through_the_cabi(tmp_path):
+    """load from a .safetensors file (either alias convention), read every parameter back through gtav_dit_get_weight:
+    fp32 conditioning weights exactly, fp16-packed GEMM weights to fp16 rounding."""
+    import ctypes as C
+    from gtav_amd import lib as L
+    from gtav_amd.weights import load_state_dict_file, save_state_dict_file
+    kw = dict(SMALL_DIT)
+    sd = W.synth_state_dict(W.dit_param_shapes(**kw), seed=9)
+    path = str(tmp_path / "dit.safetensors")
+    save_state_dict_file(dict(sd, **{"blocks.0.s_attn.rotary_emb.freqs": W.rope_freqs_pixel(32, 256),
+                                     "blocks.0.t_attn.rotary_emb.freqs": W.rope_freqs_lang(64)}), path)
+    m = DiT(**kw, init_weights=False)
+    missing, unexpected = m.load_state_dict(load_state_dict_file(path))
+    assert not missing and not unexpected
+    x, t, a = _inputs(O.DiTConfig(**kw), 1, 2, seed=1)
+    m(x, t, a)   # creates the handle and uploads
+    lib = L.load()
+    for name, ref in sd.items():
+        out = torch.empty(ref.numel(), device=dev())
+        L.check(lib.gtav_dit_get_weight(m._handle, name.encode(), out.data_ptr(), ref.numel(), L.current_stream()))
+        got = out.cpu().reshape(ref.shape)
+        exact = ("adaLN" in name or name.startswith("t_embedder") or name.startswith("external_cond") or name.endswith(".bias"))
+        if exact:
+            assert torch.equal(got, ref), name
+        else:
+            assert torch.equal(got, ref.half().float()), name
+    assert set(m.state_dict()) == set(sd) | {"spatial_rotary_emb.freqs", "temporal_rotary_emb.freqs"}
+
+
+def test_dit_edge_shapes_and_errors():
+    m, sd, cfg = _mk_dit(SMALL_DIT, seed=3)
+    # T = 1 (single frame window) and batch growth beyond the initial capacity
+    for B, T in ((1, 1), (3, 2)):
+        x, t, a = _inputs(cfg, B, T, seed=20 + B)
+        with torch.no_grad():
+            ref = O.dit_forward(sd, cfg, x, t, a)
+        assert rel_l2(m(x, t, a), ref) < 2e-3
+    x, t, a = _inputs(cfg, 1, 2, seed=5)
+    with pytest.raises(AssertionError):
+        m(x[..., :4, :], t, a)            # wrong spatial size (model/dit.py:67-69)
+    bad_t = t.clone()
+    bad_t[0, 0] = 1000                    # outside the schedule
+    m(x, bad_t, a)
+    from gtav_amd.lib import GtavError
+    with pytest.raises(GtavError):
+        m.check()
