@@ -310,7 +310,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
             else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, &pend, s));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad;
@@ -422,7 +422,8 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     for (int l = 0; l < h->L; ++l) A_(a.alloc_t(&h->kvcache[l], Mx * 2 * D));
     A_(a.alloc_t(&h->resid, Mx * D)); A_(a.alloc_t(&h->fo, Mx * h->Nfin));
     A_(a.alloc_t(&h->vout, Mx / h->P * h->C * h->H * h->W));
-    h->parts_rows = Mx > 8192 ? Mx : 8192;   // split-K slabs: splitk * M rows (splitk * M <= ~6.2 K rows when splitk > 1)
+    // split-K slabs: splitk * M * D floats; gemm_choose_splitk keeps tiles * splitk < 384, i.e. < 384 * 128 * 128 = 6.3 M floats
+    h->parts_rows = (Mx * D > (size_t)(8u << 20) ? Mx * D : (size_t)(8u << 20)) / D;
     A_(a.alloc_t(&h->parts, h->parts_rows * D));
     const size_t R = h->max_rows;
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
@@ -695,7 +696,7 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = dim; q.K = K; q.out = h->parts; q.ldo = dim;
         q.splitk = gemm_choose_splitk(M, dim, K);
-        GTAV_REQUIRE((size_t)q.splitk * M <= h->parts_rows, "split-K slabs exceed workspace");
+        GTAV_REQUIRE((size_t)q.splitk * M * dim <= h->parts_rows * (size_t)h->Dmax, "split-K slabs exceed workspace");
         RET_IF(launch_gemm(q, EPI_PARTIAL, s));
         memset(&pend, 0, sizeof(pend));
         pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * dim; pend.ld = dim; pend.bias = bias;
@@ -711,7 +712,7 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         RET_IF(launch_gemm(g, EPI_QKV, s));
         RET_IF(launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s));
         RET_IF(resid_gemm(h->ao, dim, b.w_proj, dim, b.b_proj));
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, &pend, s));
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad;
@@ -792,7 +793,7 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->xp, Mx * h->Kp)); A_(a.alloc_t(&h->xn, Mx * Dm)); A_(a.alloc_t(&h->q, Mx * Dm)); A_(a.alloc_t(&h->k, Mx * Dm));
     A_(a.alloc_t(&h->vt, Mx * Dm)); A_(a.alloc_t(&h->ao, Mx * Dm)); A_(a.alloc_t(&h->hbuf, Mx * h->Hmax)); A_(a.alloc_t(&h->zin, Mx * 64));
     A_(a.alloc_t(&h->resid, Mx * Dm)); A_(a.alloc_t(&h->po, Mx * h->Npred));
-    h->parts_rows = Mx > 8192 ? Mx : 8192;
+    h->parts_rows = (Mx * Dm > (size_t)(8u << 20) ? Mx * Dm : (size_t)(8u << 20)) / Dm;   // in rows of Dmax floats
     A_(a.alloc_t(&h->parts, h->parts_rows * Dm));
 #undef A_
     if (rc) {

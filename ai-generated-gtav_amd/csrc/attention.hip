@@ -35,6 +35,17 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
     const f16* Vg = Vt + (size_t)bh * 64 * S;
     const f16* Qg = Q + (size_t)bh * S * 64;
 
+    // the wave's first query tile is fetched together with K / Vt (one memory round trip instead of two)
+    const int nqt = (S + 15) >> 4;
+    const int qt_first = blockIdx.y * 4 + w;
+    f16x8 qpre[2] = {};
+    if (qt_first < nqt) {
+        int qr = qt_first * 16 + li;
+        qr = qr < S ? qr : S - 1;
+        qpre[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
+        qpre[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+    }
+
     // ---- stage K (swizzled) and Vt (padded), zero the padding; loads are issued in batches of 6 before the LDS
     // writes so that a thread has all of them in flight at once (S = 144: one batch each) ----
     {
@@ -81,16 +92,20 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
     }
     __syncthreads();
 
-    const int nqt = (S + 15) >> 4;
     const int nkb = (S_pad + 63) >> 6;
     const int Dm = heads * 64;
-    for (int qt = blockIdx.y * 4 + w; qt < nqt; qt += 4 * qsplit) {
+    for (int qt = qt_first; qt < nqt; qt += 4 * qsplit) {
         const int q0 = qt * 16;
-        int qr = q0 + li;
-        qr = qr < S ? qr : S - 1;
         f16x8 qf[2];
-        qf[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
-        qf[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+        if (qt == qt_first) {
+            qf[0] = qpre[0];
+            qf[1] = qpre[1];
+        } else {
+            int qr = q0 + li;
+            qr = qr < S ? qr : S - 1;
+            qf[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
+            qf[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+        }
 
         f32x4 o[4];
 #pragma unroll
@@ -201,10 +216,17 @@ __global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restric
             }
         }
     }
-    for (int tl = 0; tl < Tq; ++tl) {
+    // every query row of this (b, p) is fetched up front, together with K / V (one memory round trip for the block)
+    f16x4 qall[8];
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl)
+        if (tl < Tq) qall[tl] = *(const f16x4*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
+#pragma unroll
+    for (int tl = 0; tl < 8; ++tl) {
+        if (tl >= Tq) break;
         const int tq = t0 + tl;
         const size_t row = ((size_t)b * Tq + tl) * P + p;
-        const f16x4 q4 = *(const f16x4*)(q + row * D + c);
+        const f16x4 q4 = qall[tl];
         float qf[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) qf[e] = (float)q4[e];

@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: full-size CPU oracle cases (tens of seconds)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The HIP library is built in-tree (hipcc cross-compiles gfx950 without a GPU); tests never run on a fallback."""
+    from gtav_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        L.build()
+    L.load()
+
+
 @pytest.fixture(scope="session")
 def lib():
     from gtav_amd import lib as L

@@ -238,3 +238,48 @@ def test_dit_edge_shapes_and_errors():
     from gtav_amd.lib import GtavError
     with pytest.raises(GtavError):
         m.check()
+
+
+def test_large_token_count_paths():
+    """M > 2048 tokens switches the residual GEMMs to the in-place epilogue, LayerNorm to the wave-per-row kernel and the
+    GEMMs to the two-blocks-per-CU shape: same parity bound (small DiT at B=16, T=5 -> 2560 tokens; small VAE on 24 frames)."""
+    m, sd, cfg = _mk_dit(SMALL_DIT, seed=8, max_batch=16)
+    x, t, a = _inputs(cfg, 16, 5, seed=31)
+    with torch.no_grad():
+        ref = O.dit_forward(sd, cfg, x, t, a)
+    assert rel_l2(m(x, t, a), ref) < 2e-3
+    vsd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE), seed=5)
+    v = AutoencoderKL(**SMALL_VAE, init_weights=False, max_frames_per_call=24)
+    v.load_state_dict(vsd)
+    vcfg = O.VAEConfig(**SMALL_VAE)
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(24, 3, 64, 96, generator=g) * 2 - 1
+    with torch.no_grad():
+        mom = O.vae_encode_moments(vsd, vcfg, img)
+    assert rel_l2(v.encode(img).mean, mom[..., :16]) < 2e-3
+    z = torch.randn(24, vcfg.seq_len, 16, generator=g)
+    with torch.no_grad():
+        ref = O.vae_decode(vsd, vcfg, z)
+    assert rel_l2(v.decode(z), ref) < 2e-3
+
+
+def test_g256_geometry_preset():
+    """BASELINE.json says '256x256' frames; the reference's factories are 360x640 only, but its constructors accept the
+    g256 preset of SURVEY.md §8(d) (VAE patch 16 -> 16x16x16 latents, 64 DiT tokens per frame): same kernels, other shapes."""
+    vkw = dict(latent_dim=16, input_height=256, input_width=256, patch_size=16, enc_dim=128, enc_depth=1, enc_heads=2, dec_dim=128,
+               dec_depth=1, dec_heads=2)
+    vsd = W.synth_state_dict(W.vae_param_shapes(**vkw), seed=11)
+    v = AutoencoderKL(**vkw, init_weights=False)
+    v.load_state_dict(vsd)
+    vcfg = O.VAEConfig(**vkw)
+    g = torch.Generator().manual_seed(6)
+    img = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        mom = O.vae_encode_moments(vsd, vcfg, img)
+    assert rel_l2(v.encode(img).mean, mom[..., :16]) < 2e-3
+    dkw = dict(input_h=16, input_w=16, patch_size=2, in_channels=16, hidden_size=256, depth=1, num_heads=4, external_cond_dim=25)
+    m, sd, cfg = _mk_dit(dkw, seed=12)
+    x, t, a = _inputs(cfg, 2, 4, seed=13)
+    with torch.no_grad():
+        ref = O.dit_forward(sd, cfg, x, t, a)
+    assert rel_l2(m(x, t, a), ref) < 2e-3
