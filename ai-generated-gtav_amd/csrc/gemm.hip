@@ -132,22 +132,27 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
     }
 }
 
-// Loader-specialised main loop (shape 5: 128 x 256 tile, 8 compute waves + 2 loader waves = 640 threads).
-// A wave's direct-to-LDS loads back-pressure its in-order instruction stream at the ~63 GB/s/CU fill rate, so when
-// every wave both fills and computes, fill time and MFMA time add up between two barriers.  Here waves 8 and 9 do
-// nothing but issue the 48 one-KiB pieces of every stage (24 each, counted vmcnt, <= 48 in flight) and waves 0..7
-// nothing but ds_read + MFMA; all ten meet at the one barrier per K-step, which publishes tile t and frees stage t-1.
-template <bool TR, int NS>
+// Loader-specialised main loops.  A wave's direct-to-LDS loads back-pressure its in-order instruction stream at the
+// ~63-94 GB/s/CU fill rate, so when every wave both fills and computes, fill time and MFMA time add up between two
+// barriers.  Here dedicated loader waves do nothing but issue the one-KiB pieces of every stage (counted vmcnt) and the
+// compute waves nothing but ds_read + MFMA; all meet at the one barrier per K-step, which publishes tile t and frees
+// stage t-1.
+//   WM = 4 (shape 5): 128 x 256 tile, 8 compute + 2 loader waves (24 pieces each per stage), 3 x 48 KiB ring, 1 block / CU
+//   WM = 2 (shape 6): 128 x 128 tile, 4 compute + 1 loader wave (32 pieces per stage), 2 x 32 KiB ring, 2 blocks / CU
+template <bool TR, int NS, int WM>
 __device__ __forceinline__ void mainloop_ls(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
                                             f32x4 (&acc)[4][4]) {
-    constexpr int STAGE_BYTES = 3 * TILE_BYTES;   // [W 16 KiB][X rows 0..127][X rows 128..255]
-    constexpr int PIECES = 24;                     // per loader wave per stage
+    constexpr int XT = WM / 2;                          // 128-row X tiles per stage
+    constexpr int STAGE_BYTES = (1 + XT) * TILE_BYTES;
+    constexpr int NCOMP = 2 * WM;                       // compute waves
+    constexpr int NLOAD = WM / 2;                       // loader waves
+    constexpr int PIECES = 16 * (1 + XT) / NLOAD;       // per loader wave per stage (32 or 24)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nktot = p.K / TK;
-    if (w >= 8) {
+    if (w >= NCOMP) {
         // ------------------------------ loader waves ------------------------------
-        const int l = w - 8;
+        const int l = w - NCOMP;
         const int last_rt = (p.M - 1) >> 7;
         int rt0 = m0 >> 7, rt1 = rt0 + 1;
         rt0 = rt0 < last_rt ? rt0 : last_rt;
@@ -158,7 +163,12 @@ __device__ __forceinline__ void mainloop_ls(const GemmParams& p, char* smem, int
         auto stage = [&](int t) {
             char* base = smem + (t % NS) * STAGE_BYTES;
             const size_t ko = (size_t)t * TILE_BYTES;
-            if (l == 0) {
+            if (WM == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) glds16(wb + ko + i * 1024, base + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) glds16(x0 + ko + i * 1024, base + TILE_BYTES + i * 1024);
+            } else if (l == 0) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) glds16(wb + ko + i * 1024, base + i * 1024);
 #pragma unroll
@@ -218,6 +228,7 @@ __device__ __forceinline__ void mainloop_ls(const GemmParams& p, char* smem, int
 
 template <int EPI, int NS, int WM, int FJ, int NL>
 __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1))) void gemm_kernel(GemmParams p) {
+    static_assert(NL == 0 || (FJ == 4 && NL == WM / 2), "loader waves: 64 x 64 wave tiles, one loader per two compute wave rows");
     constexpr int TM = WM * 16 * FJ;
     __shared__ __attribute__((aligned(16))) char smem[NS * (1 + TM / 128) * TILE_BYTES];
     const int tiles_m = (p.M + TM - 1) / TM;
@@ -257,12 +268,11 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
     bool tr = false;
     if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
     if constexpr (NL > 0) {
-        static_assert(NL == 0 || (WM == 4 && FJ == 4), "loader waves: 128 x 256 tile only");
         if constexpr (EPI == EPI_QKV) {
-            if (tr) mainloop_ls<true, NS>(p, smem, n0, m0, kt0, nkt, acc);
-            else mainloop_ls<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
+            if (tr) mainloop_ls<true, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
+            else mainloop_ls<false, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
         } else {
-            mainloop_ls<false, NS>(p, smem, n0, m0, kt0, nkt, acc);
+            mainloop_ls<false, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
         }
     } else if constexpr (EPI == EPI_QKV) {
         if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
@@ -441,10 +451,15 @@ int gemm_choose_splitk(int M, int N, int K) {
     return s;
 }
 
-// shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves
+// shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
+//        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 5) {
+    if (shape == 6) {
+        const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
+        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4, 1>), grid, dim3(320), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 2, 4, 1>), grid, dim3(320), 0, stream, p);
+    } else if (shape == 5) {
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, TN) * splitk);
         if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4, 2>), grid, dim3(640), 0, stream, p);
         else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4, 2>), grid, dim3(640), 0, stream, p);
@@ -495,7 +510,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     //   larger grids: 4 waves, 2-stage ring, two co-resident blocks per CU; the 128 x 256 / 8-wave tile (shape 4) ties it.
     const int blocks128 = cdiv(p.M, 128) * cdiv(p.N, TN) * splitk;
     int wm = g_force_wm ? g_force_wm : (blocks128 <= 256 ? 3 : 2);
-    int ns = g_force_stages ? g_force_stages : (wm >= 4 ? 3 : wm == 3 ? 4 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);

@@ -276,7 +276,7 @@ def test_gemm_8wave_tile_matches(M, N, K):
     """The 8-wave block shapes (3: 128 x 128, 4: 128 x 256 with staggered fills, 5: 128 x 256 with 2 dedicated loader waves) against fp32 math, incl. ragged last tiles."""
     lib = L.load()
     try:
-      for shape in (3, 4, 5):
+      for shape in (3, 4, 5, 6):
         lib.gtav_op_gemm_set_wm(shape)
         for ns in ((2, 4) if shape == 3 else (2, 3)):
             lib.gtav_op_gemm_set_stages(ns)
