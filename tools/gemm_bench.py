@@ -25,6 +25,8 @@ def main():
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     shapes = [("qkv", 3072, 1024, 5), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]
+    if "floor" in a.only:   # one K-step only: launch + first tile + epilogue (the per-launch floor of each epilogue)
+        shapes += [("floor_gelu", 4096, 64, 2), ("floor_f32", 4096, 64, 0), ("floor_part", 1024, 64, 6), ("floor_n128", 128, 64, 0)]
     print(f"{'shape':>5} {'M':>6} {'N':>5} {'K':>5} {'ns':>3} {'split':>5} {'us':>9} {'TFLOP/s':>9}")
     for M in a.ms:
         for name, N, K, epi in shapes:
@@ -35,7 +37,9 @@ def main():
             ws = [(torch.randn((N + 127) // 128 * 128, K, device=dev) * 0.03).half() for _ in range(a.copies)]
             bias = torch.randn(N, device=dev)
             sk = lib.gtav_op_gemm_choose_splitk(M, N, K) if epi == 6 else 1
-            out = torch.empty((max(sk, 1) * (M + 127) // 128 * 128, N), device=dev, dtype=torch.float32 if epi == 6 else torch.float16)
+            # fp32 row-major for epilogues 0 / 6, fp16 (tile-major, rows padded to 128) otherwise; sized for the padded M
+            Mp = (M + 127) // 128 * 128
+            out = torch.empty((max(sk, 1) * Mp, N), device=dev, dtype=torch.float32 if epi in (0, 6) else torch.float16)
             q = torch.empty(3, M, 1024, device=dev, dtype=torch.float16)
             cs = torch.ones(144, 64, device=dev)
             sn = torch.zeros(144, 64, device=dev)
