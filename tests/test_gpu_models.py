@@ -283,3 +283,55 @@ def test_g256_geometry_preset():
     with torch.no_grad():
         ref = O.dit_forward(sd, cfg, x, t, a)
     assert rel_l2(m(x, t, a), ref) < 2e-3
+
+
+def test_constructor_variants():
+    """external_cond_dim = 0 (nn.Identity in the reference, model/dit.py:263-267), a non-variational VAE
+    (model/vae.py:316-317) and growing `max_frames` after construction (generate.py:139)."""
+    kw = dict(SMALL_DIT, external_cond_dim=0)
+    sd = W.synth_state_dict(W.dit_param_shapes(**kw), seed=21)
+    assert not any(k.startswith("external_cond") for k in sd)
+    m = DiT(**kw, init_weights=False, max_frames=2)
+    m.load_state_dict(sd)
+    cfg = O.DiTConfig(**kw)
+    x, t, _ = _inputs(cfg, 1, 2, seed=3, actions=False)
+    with torch.no_grad():
+        ref = O.dit_forward(sd, cfg, x, t, None)
+    assert rel_l2(m(x, t, None), ref) < 2e-3
+    m.max_frames = 6                                   # beyond the initial capacity: the handle is rebuilt transparently
+    x, t, _ = _inputs(cfg, 1, 6, seed=4, actions=False)
+    with torch.no_grad():
+        ref = O.dit_forward(sd, cfg, x, t, None)
+    assert m.max_frames == 6 and rel_l2(m(x, t, None), ref) < 2e-3
+
+    vkw = dict(SMALL_VAE)
+    vsd = W.synth_state_dict(W.vae_param_shapes(**vkw, use_variational=False), seed=22)
+    assert vsd["quant_conv.weight"].shape == (16, 128)
+    v = AutoencoderKL(**vkw, use_variational=False, init_weights=False)
+    v.load_state_dict(vsd)
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand(2, 3, 64, 96, generator=g) * 2 - 1
+    post = v.encode(img)
+    # oracle: moments = quant_conv output (latent channels only); the reference pads zeros for logvar and is deterministic
+    vcfg = O.VAEConfig(**vkw)
+    with torch.no_grad():
+        mom = O.vae_encode_moments(vsd, vcfg, img)
+    assert mom.shape[-1] == 16 and rel_l2(post.mean, mom) < 2e-3
+    assert post.deterministic and torch.equal(post.sample(), post.mean) and post.std.abs().max().item() == 0
+
+
+def test_rollout_four_prompt_frames_sliding_window():
+    """generate.py's default prompt (4 frames) with max_frames = 5: the window saturates at 5 frames and slides
+    (start_frame = 0, 1, 2); no actions; 6 noise steps; window and context-cached algorithms vs the oracle."""
+    from gtav_amd.generate import generate_latents
+    m, sd, cfg = _mk_dit(SMALL_DIT, seed=23, max_batch=1)
+    g = torch.Generator().manual_seed(14)
+    x0 = torch.randn(1, 4, 16, 8, 16, generator=g) * 0.5
+    noise = torch.randn(1, 3, 16, 8, 16, generator=g) * 9      # exercises the +-20 clamp (generate.py:202)
+    dit_fn = lambda xx, tt, aa: O.dit_forward(sd, cfg, xx, tt, aa)
+    with torch.no_grad():
+        ref = O.generate_latents(dit_fn, x0, 7, 6, noise, None, max_frames=5)
+    out = generate_latents(m, x0, 7, 6, noise, None)
+    out_c = generate_latents(m, x0, 7, 6, noise, None, ctx_cache=True)
+    assert torch.equal(out[:, :4].cpu(), x0)                     # prompt frames untouched
+    assert rel_l2(out, ref) < 1e-2 and rel_l2(out_c, out) < 1e-4
