@@ -226,62 +226,168 @@ __device__ __forceinline__ void mainloop_ls(const GemmParams& p, char* smem, int
     }
 }
 
-template <int EPI, int NS, int WM, int FJ, int NL>
-__global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1))) void gemm_kernel(GemmParams p) {
-    static_assert(NL == 0 || (FJ == 4 && NL == WM / 2), "loader waves: 64 x 64 wave tiles, one loader per two compute wave rows");
-    constexpr int TM = WM * 16 * FJ;
-    __shared__ __attribute__((aligned(16))) char smem[NS * (1 + TM / 128) * TILE_BYTES];
-    const int tiles_m = (p.M + TM - 1) / TM;
+// 256 features x 256 tokens per block, 8 waves (2 along N x 4 along M), each wave 128 x 64 = 8 x 4 MFMA tiles: half the
+// L2->LDS fill bytes per FLOP of the 128 x 128 tile, which is what bounds the large-M GEMMs (755 MB of fills per fc1 launch
+// at M = 5760 = 46 GB/s per CU over the whole launch, against a 66-73 GB/s per-CU LDS-DMA ceiling).
+// LDS: two K-tile parities x four 16 KiB half-tiles {W0, W1, X0, X1} = 128 KiB.  A K-tile (64 MFMAs per wave) runs as four
+// quadrant phases of 16 MFMAs; one half-tile (two 1-KiB pieces per wave) of a later K-tile is issued per phase, so fills,
+// fragment reads and MFMAs interleave finely:
+//   phase 1: issue W0(t+1) | read W rows 0-63 (8) + X cols 0-31 (4) + X cols 32-63 (4) | MFMA W[0:4] x X[0:2]
+//   phase 2: issue W1(t+1) | read W rows 64-127 (8, for phase 3)                        | MFMA W[0:4] x X[2:4]
+//   -- barrier (b): every wave has finished reading the X half-tiles of this parity --
+//   phase 3: issue X0(t+2) into this parity's X0                                       | MFMA W[4:8] x X[2:4]
+//   phase 4: issue X1(t+2)                                                             | MFMA W[4:8] x X[0:2]
+//   -- vmcnt(4): everything but X0/X1(t+2) landed = K-tile t+1 complete; barrier (a) --
+// WAR: W slots of parity p are last read in phase 2 (prefetched) of K-tile t and refilled in phases 1-2 of t+1, after
+// barrier (a); X slots are last read in phase 1 and refilled after barrier (b).  RAW: a half-tile is read only after the
+// issuing waves' counted vmcnt and a barrier (MI355X_MICROARCH.md: LDS-DMA ordering).
+template <bool TR>
+__device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                            f32x4 (&acc)[8][4]) {
+    constexpr int PAR = 4 * TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wm = w >> 1;
+    const int nktot = p.K / TK;
+    const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
+    const int wt0 = n0 >> 7, wt1 = wt0 + 1 < last_wt ? wt0 + 1 : last_wt;     // ragged edges re-read a valid tile (masked)
+    const int rt0 = (m0 >> 7) < last_rt ? (m0 >> 7) : last_rt, rt1 = (m0 >> 7) + 1 < last_rt ? (m0 >> 7) + 1 : last_rt;
+    const size_t po = (size_t)(2 * w) * 1024 + lane * 16;
+    const char* const sw0 = (const char*)p.W + ((size_t)wt0 * nktot + kt0) * TILE_BYTES + po;
+    const char* const sw1 = (const char*)p.W + ((size_t)wt1 * nktot + kt0) * TILE_BYTES + po;
+    const char* const sx0 = (const char*)p.X + ((size_t)rt0 * nktot + kt0) * TILE_BYTES + po;
+    const char* const sx1 = (const char*)p.X + ((size_t)rt1 * nktot + kt0) * TILE_BYTES + po;
+    char* const dst0 = smem + (2 * w) * 1024;
+    auto stage = [&](const char* src, int h, int t) {
+        const char* s = src + (size_t)t * TILE_BYTES;
+        char* d = dst0 + (t & 1) * PAR + h * TILE_BYTES;
+        glds16(s, d);
+        glds16(s + 1024, d + 1024);
+    };
 
-    // XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous
-    // run of tiles, m fastest, so neighbours on one L2 stream the same W panel.
+    const int li = lane & 15, g = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = wn * TILE_BYTES + li * 128 + ch;
+        xoff[s] = (2 + (wm >> 1)) * TILE_BYTES + (64 * (wm & 1) + li) * 128 + ch;
+    }
+    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) {
+        if (TR) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xv, wv, c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0);
+    };
+
+    stage(sx0, 2, 0); stage(sx1, 3, 0); stage(sw0, 0, 0); stage(sw1, 1, 0);
+    if (nkt > 1) {
+        stage(sx0, 2, 1); stage(sx1, 3, 1);
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    const bool fills = !(p.debug & 1);
+    for (int t = 0; t < nkt; ++t) {
+        const char* b = smem + (t & 1) * PAR;
+        const bool n1 = t + 1 < nkt && fills, n2 = t + 2 < nkt && fills;
+        f16x8 wa[2][4], wb[2][4], xa[2][2], xb[2][2];
+        // ---- phase 1 ----
+        if (n1) stage(sw0, 0, t + 1);
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wa[s][i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xa[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xb[s][j] = *(const f16x8*)(b + xoff[s] + (2 + j) * 16 * 128);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma(wa[s][i], xa[s][j], acc[i][j]);
+        }
+        // ---- phase 2 ----
+        if (n1) stage(sw1, 1, t + 1);
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wb[s][i] = *(const f16x8*)(b + woff[s] + (4 + i) * 16 * 128);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma(wa[s][i], xb[s][j], acc[i][2 + j]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (b)
+        // ---- phase 3 ----
+        if (n2) stage(sx0, 2, t + 2);
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma(wb[s][i], xb[s][j], acc[4 + i][2 + j]);
+        }
+        // ---- phase 4 ----
+        if (n2) stage(sx1, 3, t + 2);
+        {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma(wb[s][i], xa[s][j], acc[4 + i][j]);
+        }
+        if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a)
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
+// Inside an XCD's run the order is (m, n) with n FASTEST over a group of `gn` n-panels (gn = tiles_n / 8, the panels one
+// XCD owns): co-resident blocks then share X row-tiles as well as W panels in that XCD's 4 MiB L2.  With m fastest, X
+// (11.8 MB at M = 5760) was re-streamed from the fabric once per n-panel: rocprofv3 FETCH_SIZE 301 MB per fc1 launch
+// against 20 MB algorithmic (profiles/round1/pmc).  Split-K: the K slice is the slowest index, so the slices of one W
+// panel stay on one XCD.
+template <bool SPLITK, int TNB, int TMB>
+__device__ __forceinline__ void tile_map(const GemmParams& p, int& n0, int& m0, int& ks, int& kt0, int& nkt) {
+    const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + TNB - 1) / TNB;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    int tile_id = swz, ks = 0, kt0 = 0, nkt = p.K / TK;
-    if constexpr (EPI == EPI_PARTIAL) {
-        const int tiles = tiles_m * ((p.N + TN - 1) / TN);
-        ks = swz / tiles;  // K slice is the slowest index: the slices of one W panel stay on one XCD
+    int tile_id = swz;
+    ks = 0, kt0 = 0, nkt = p.K / TK;
+    if constexpr (SPLITK) {
+        const int tiles = tiles_m * tiles_n;
+        ks = swz / tiles;
         tile_id = swz - ks * tiles;
         nkt = nkt / p.splitk;
         kt0 = ks * nkt;
     }
-    // Inside an XCD's contiguous run of tiles the order is (m, n) with n FASTEST over a group of `gn` n-panels (gn =
-    // tiles_n / 8, the panels one XCD owns): co-resident blocks then share X row-tiles as well as W panels in that XCD's
-    // 4 MiB L2.  With m fastest, X (11.8 MB at M = 5760) was re-streamed from the fabric once per n-panel: rocprofv3
-    // FETCH_SIZE 301 MB per fc1 launch against 20 MB algorithmic (profiles/round1/pmc).
-    const int tiles_n = (p.N + TN - 1) / TN;
     int gn = tiles_n >= 8 ? tiles_n >> 3 : 1;
     const int group = tiles_m * gn;
     const int ng = tile_id / group, rem = tile_id - ng * group;
     const int n_first = ng * gn;
     if (n_first + gn > tiles_n) gn = tiles_n - n_first;   // last, partial group
     const int tile_m = rem / gn, tile_n = n_first + (rem - tile_m * gn);
-    const int n0 = tile_n * TN, m0 = tile_m * TM;
+    n0 = tile_n * TNB;
+    m0 = tile_m * TMB;
+}
 
-    f32x4 acc[4][FJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bool tr = false;
-    if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-    if constexpr (NL > 0) {
-        if constexpr (EPI == EPI_QKV) {
-            if (tr) mainloop_ls<true, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
-            else mainloop_ls<false, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
-        } else {
-            mainloop_ls<false, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
-        }
-    } else if constexpr (EPI == EPI_QKV) {
-        if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
-        else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
-    } else {
-        mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
-    }
-
-    // ------------------------------------ epilogue ------------------------------------
+// Epilogue shared by every block shape.  The block tile is TNB = 32 FI features x TM = 16 FJ WM tokens; wave (wn, wm) owns
+// features 16 FI wn .. and tokens 16 FJ wm ..; acc[i][j] is the 16 x 16 MFMA tile (feature group i, token group j).
+template <int EPI, int FI, int FJ, int WM>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], char* smem, int n0, int m0, int ks, bool tr) {
+    constexpr int TM = WM * 16 * FJ;
+    constexpr int CT = FI / 2;                      // 64-feature sub-tiles per block tile row
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
     const bool compute_wave = threadIdx.x < 128 * WM;   // loader waves (NL > 0) carry no accumulators
@@ -293,16 +399,16 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
         __syncthreads();   // every wave is done reading the last K-step's stage
         if (compute_wave) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int nl = 64 * wn + 16 * i + 4 * g;           // feature inside the block tile (4 consecutive)
+            for (int i = 0; i < FI; ++i) {
+                const int nl = 16 * FI * wn + 16 * i + 4 * g;           // feature inside the block tile (4 consecutive)
                 f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *(const f32x4*)(p.bias + n0 + nl);
+                if (p.bias && n0 + nl < p.N) bv = *(const f32x4*)(p.bias + n0 + nl);
                 const int c = nl & 63;                              // feature inside the 64-wide sub-tile (= 16 i + 4 g)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
                     const int ml = 16 * FJ * wm + 16 * j + li;      // token inside the block tile
                     const int r = ml & 127;
-                    char* dst = smem + ((ml >> 7) * 2 + wn) * TILE_BYTES + r * 128 + (((c >> 3) ^ (r & 7)) << 4) + (c & 7) * 2;
+                    char* dst = smem + ((ml >> 7) * CT + (nl >> 6)) * TILE_BYTES + r * 128 + (((c >> 3) ^ (r & 7)) << 4) + (c & 7) * 2;
                     const f32x4 v = acc[i][j] + bv;
                     if constexpr (EPI == EPI_GELU_TANH)
                         *(uint2*)dst = pack4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
@@ -313,13 +419,13 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
         }
         __syncthreads();
         const int nkt_out = p.ldo >> 6, last_rt = (p.M - 1) >> 7;
-        constexpr int NPIECE = (TM / 128) * 2 * 16;
+        constexpr int NPIECE = (TM / 128) * CT * 16;
         for (int q = w; q < NPIECE; q += (int)(blockDim.x >> 6)) {
             const int st = q >> 4, pq = q & 15;
-            const int rt = (m0 >> 7) + (st >> 1);
-            if (rt > last_rt) continue;                              // ragged last block tile
+            const int rt = (m0 >> 7) + st / CT;
+            if (rt > last_rt || (n0 >> 6) + st % CT >= nkt_out) continue;   // ragged last block tile (tokens / features)
             const uint4 val = *(const uint4*)(smem + st * TILE_BYTES + pq * 1024 + lane * 16);
-            char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + (st & 1)) * TILE_BYTES + pq * 1024 + lane * 16;
+            char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + st % CT) * TILE_BYTES + pq * 1024 + lane * 16;
             *(uint4*)dst = val;
         }
         return;
@@ -331,8 +437,8 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
             // D[row = token][col = feature]: lane owns tokens m..m+3 of feature n (V part, spatial mode)
             const int heads = p.D >> 6;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + 64 * wn + 16 * i + li;
+            for (int i = 0; i < FI; ++i) {
+                const int n = n0 + 16 * FI * wn + 16 * i + li;
                 const int nn = n - 2 * p.D;
                 const float bv = p.bias ? p.bias[n] : 0.f;
                 const int head = nn >> 6, d = nn & 63;
@@ -373,8 +479,8 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + 64 * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
+    for (int i = 0; i < FI; ++i) {
+        const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
         if (n >= p.N) continue;
         f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI != EPI_PARTIAL && p.bias) bv = *(const f32x4*)(p.bias + n);
@@ -437,6 +543,60 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
     }
 }
 
+template <int EPI, int NS, int WM, int FJ, int NL>
+__global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1))) void gemm_kernel(GemmParams p) {
+    static_assert(NL == 0 || (FJ == 4 && NL == WM / 2), "loader waves: 64 x 64 wave tiles, one loader per two compute wave rows");
+    constexpr int TM = WM * 16 * FJ;
+    __shared__ __attribute__((aligned(16))) char smem[NS * (1 + TM / 128) * TILE_BYTES];
+    int n0, m0, ks, kt0, nkt;
+    tile_map<EPI == EPI_PARTIAL, TN, TM>(p, n0, m0, ks, kt0, nkt);
+
+    f32x4 acc[4][FJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bool tr = false;
+    if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+    if constexpr (NL > 0) {
+        if constexpr (EPI == EPI_QKV) {
+            if (tr) mainloop_ls<true, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
+            else mainloop_ls<false, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
+        } else {
+            mainloop_ls<false, NS, WM>(p, smem, n0, m0, kt0, nkt, acc);
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
+        else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
+    } else {
+        mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc);
+    }
+
+    epilogue<EPI, 4, FJ, WM>(p, acc, smem, n0, m0, ks, tr);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES];
+    int n0, m0, ks, kt0, nkt;
+    tile_map<EPI == EPI_PARTIAL, 256, 256>(p, n0, m0, ks, kt0, nkt);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool tr = false;
+    if constexpr (EPI == EPI_QKV) {
+        tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+        if (tr) mainloop256<true>(p, smem, n0, m0, kt0, nkt, acc);
+        else mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc);
+    } else {
+        mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc);
+    }
+    epilogue<EPI, 8, 4, 4>(p, acc, smem, n0, m0, ks, tr);
+}
+
 }  // namespace
 
 static int g_force_stages = 0, g_debug = 0, g_force_wm = 0;
@@ -452,10 +612,13 @@ int gemm_choose_splitk(int M, int N, int K) {
 }
 
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
-//        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU)
+//        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 6) {
+    if (shape == 7) {
+        const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
+        hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), 0, stream, p);
+    } else if (shape == 6) {
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
         if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4, 1>), grid, dim3(320), 0, stream, p);
         else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 2, 4, 1>), grid, dim3(320), 0, stream, p);
@@ -510,6 +673,14 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     //   larger grids: 4 waves, 2-stage ring, two co-resident blocks per CU; the 128 x 256 / 8-wave tile (shape 4) ties it.
     const int blocks128 = cdiv(p.M, 128) * cdiv(p.N, TN) * splitk;
     int wm = g_force_wm ? g_force_wm : (blocks128 <= 256 ? 3 : 2);
+    // 256 x 256 tiles (shape 7) halve the fill bytes per FLOP but run one block per CU, so a tile's epilogue (a 32 MB
+    // store burst per round of 256 tiles) is not hidden by a co-resident block: they win only where the K loop is long
+    // relative to the output and the grid is one well-filled round — the N = 1024 residual GEMMs at M >= 11 520
+    // (profiles/round1/v12_gemm_256tile_microbench.txt: fc2 129 -> 98 us, out-proj 40 -> 35 us).
+    if (!g_force_wm && splitk == 1 && epi != EPI_QKV && p.N % 256 == 0 && p.N <= 1024 && p.K >= 1024) {
+        const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
+        if (t256 * 10 >= rounds * 256 * 7) wm = 7;
+    }
     int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);

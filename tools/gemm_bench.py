@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--ms", type=int, nargs="+", default=[144, 720, 1152, 5760, 11520])
     ap.add_argument("--debug", type=int, nargs="+", default=[0], help="gemm debug bits to sweep (1 = no fills, 2 = no MFMA)")
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--splitk", type=int, default=0, help="split-K factor for the partial-slab GEMMs (0 = heuristic)")
     ap.add_argument("--wm", type=int, nargs="+", default=[0], help="block shapes to sweep: 0 heuristic, 2 = 128x128/4 waves, 4 = 128x256/8 waves")
     a = ap.parse_args()
     lib = L.load()
@@ -36,7 +37,7 @@ def main():
             x = (torch.randn((M + 127) // 128 * 128, K, device=dev) * 0.5).half()
             ws = [(torch.randn((N + 127) // 128 * 128, K, device=dev) * 0.03).half() for _ in range(a.copies)]
             bias = torch.randn(N, device=dev)
-            sk = lib.gtav_op_gemm_choose_splitk(M, N, K) if epi == 6 else 1
+            sk = (a.splitk or lib.gtav_op_gemm_choose_splitk(M, N, K)) if epi == 6 else 1
             # fp32 row-major for epilogues 0 / 6, fp16 (tile-major, rows padded to 128) otherwise; sized for the padded M
             Mp = (M + 127) // 128 * 128
             out = torch.empty((max(sk, 1) * Mp, N), device=dev, dtype=torch.float32 if epi in (0, 6) else torch.float16)
