@@ -28,6 +28,7 @@ struct GemmParams {
     const f16* W;  // tile-major [round_up(N,128)][K]
     int M, N, K;   // K % 64 == 0
     int debug;     // experiments only: bit 0 = skip the LDS fills after the prologue, bit 1 = skip LDS reads + MFMA
+    int out_sc1;   // set by launch_gemm: 16-byte output stores bypass-and-drop in L2 (large outputs)
     int splitk;    // EPI_PARTIAL only: number of K slices (grid = tiles * splitk); (K / 64) % splitk == 0
     const float* bias;  // [N] or nullptr
     void* out;          // EPI_F32/RESID/PARTIAL: f32 row-major [M][ldo]; EPI_F16: f16 row-major [M][ldo];

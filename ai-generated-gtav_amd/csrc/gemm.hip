@@ -27,6 +27,15 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Stores that drop the line from the XCD's L2 once written through (sc1): the output of a large-M GEMM is far bigger than
+// the 4 MiB L2 and is not re-read by this launch, so keeping it would only evict operand tiles.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(void* dst, uint4 v) {
+    const u32x4 r = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r) : "memory");
+}
+
+
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     union { f16x4 h; uint2 u; } cv;
     cv.h = f16x4{(f16)a, (f16)b, (f16)c, (f16)d};
@@ -426,7 +435,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
             if (rt > last_rt || (n0 >> 6) + st % CT >= nkt_out) continue;   // ragged last block tile (tokens / features)
             const uint4 val = *(const uint4*)(smem + st * TILE_BYTES + pq * 1024 + lane * 16);
             char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + st % CT) * TILE_BYTES + pq * 1024 + lane * 16;
-            *(uint4*)dst = val;
+            if (p.out_sc1) store16_sc1(dst, val);
+            else *(uint4*)dst = val;
         }
         return;
     }
@@ -497,7 +507,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + bv;
             if constexpr (EPI == EPI_PARTIAL) {
-                *(f32x4*)((float*)p.out + ((size_t)ks * p.M + m) * p.ldo + n) = v;
+                float* dst = (float*)p.out + ((size_t)ks * p.M + m) * p.ldo + n;
+                if (p.out_sc1) { union { f32x4 f; uint4 u; } cv; cv.f = v; store16_sc1(dst, cv.u); }
+                else *(f32x4*)dst = v;
             } else if constexpr (EPI == EPI_F32) {
                 *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
             } else if constexpr (EPI == EPI_F16) {
@@ -529,7 +541,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 if (p.qkv_mode == QKV_SPATIAL) {
                     const int heads = p.D >> 6;
                     f16* base = which == 0 ? p.q : p.k;
-                    *(uint2*)(base + ((size_t)(tok_a[j] * heads + head) * p.S + tok_b[j]) * 64 + d) = pk;
+                    f16* dst = base + ((size_t)(tok_a[j] * heads + head) * p.S + tok_b[j]) * 64 + d;
+                    *(uint2*)dst = pk;   // 8-byte sc1 stores are slower (one fabric write each): QKV 64 -> 73 us at M = 5760
                 } else {
                     if (which == 0) {
                         *(uint2*)(p.q + (size_t)m * p.D + nn) = pk;
@@ -645,7 +658,17 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_debug;
+    p.debug = g_debug & 3;
+    // 16-byte output stores of the split-K slabs and of the tile-major GELU output go out write-through-and-drop (sc1)
+    // once the output is too big to be re-read from L2 by the next kernel anyway: out-proj 22.9 -> 21.1 us at M = 5760,
+    // 38 -> 34 us at M = 11 520 (profiles/round1/v13_gemm_sc1_stores_microbench.txt).  bit 2 of the debug word forces it
+    // on, bit 3 off (experiments).
+    {
+        const size_t out_bytes = (size_t)p.M * p.N * (epi == EPI_PARTIAL ? 4 * (p.splitk > 0 ? p.splitk : 1) : 2);
+        p.out_sc1 = ((epi == EPI_PARTIAL || epi == EPI_GELU_TANH || epi == EPI_GELU_ERF) && out_bytes >= ((size_t)16 << 20)) ? 1 : 0;
+        if (g_debug & 4) p.out_sc1 = 1;
+        if (g_debug & 8) p.out_sc1 = 0;
+    }
     GTAV_REQUIRE(p.K > 0 && p.K % TK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, TK);
     GTAV_REQUIRE(p.M > 0 && p.N > 0 && p.N % 4 == 0, "gemm: bad M=%d N=%d", p.M, p.N);
     GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
