@@ -14,6 +14,8 @@
 // 25 dot products of length 64 per head: VALU + 16-lane xor-shuffle reductions, everything in registers.
 #include "ops.h"
 
+#include <cstdlib>
+
 namespace gtav {
 
 namespace {
@@ -22,7 +24,7 @@ constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log
 
 __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
                                                            const f16* __restrict__ Vt, f16* __restrict__ O, int heads, int S,
-                                                           int S_pad, int qsplit) {
+                                                           int S_pad, int qsplit, int sc1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;                              // [S_pad][128 B], 16-B chunk c of row r stored at c ^ (r & 7)
     const int vstride = (S_pad + 8) * 2;          // bytes per Vt row
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
                 f16x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = (f16)(o[dt][r] * inv);
-                *(f16x4*)(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm)) = h;
+                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1);
             }
         }
     }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
 
 // block = D/4 threads: thread -> (head = tid / 16, d = 4 * (tid % 16)); one block per (b, p)
 __global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ kv,
-                                                            f16* __restrict__ O, int P, int D, int Tq, int t0, int Tmax) {
+                                                            f16* __restrict__ O, int P, int D, int Tq, int t0, int Tmax, int sc1) {
     const int bp = blockIdx.x;
     const int b = bp / P, p = bp - b * P;
     const int c = threadIdx.x * 4;
@@ -259,13 +261,15 @@ __global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restric
         f16x4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = (f16)(acc[e] * inv);
-        *(f16x4*)(O + tiled_off((int)row, c, D)) = o4;
+        store_f16x4_paired<1>(O + tiled_off((int)row, c, D), o4, threadIdx.x, sc1);
     }
 }
 
 }  // namespace
 
 static bool g_attn_attr_set = false;
+// output as paired 16-byte write-through stores (common.h store_f16x4_paired); GTAV_ATTN_SC1=1 enables it
+static int g_attn_sc1 = getenv("GTAV_ATTN_SC1") ? atoi(getenv("GTAV_ATTN_SC1")) : 0;   // measured neutral at B = 1 (attention re-reads nothing, writes little)
 
 int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream) {
     GTAV_REQUIRE(S > 0 && S % 8 == 0, "attn_spatial: S=%d must be a positive multiple of 8", S);
@@ -283,7 +287,7 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
     const int max_split = cdiv(nqt, 4);
     while (NB * heads * qsplit < 512 && qsplit < max_split) ++qsplit;
     dim3 grid(NB * heads, qsplit), block(256);
-    hipLaunchKernelGGL(attn_spatial_kernel, grid, block, lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit);
+    hipLaunchKernelGGL(attn_spatial_kernel, grid, block, lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -292,7 +296,7 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
                          hipStream_t stream) {
     GTAV_REQUIRE(D % 256 == 0 && D <= 2048, "attn_temporal: D=%d must be a multiple of 256 and <= 2048", D);
     GTAV_REQUIRE(Tq > 0 && t0 >= 0 && t0 + Tq <= Tmax && Tmax <= 8, "attn_temporal: window t0=%d Tq=%d Tmax=%d (max 8)", t0, Tq, Tmax);
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax);
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax, g_attn_sc1);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

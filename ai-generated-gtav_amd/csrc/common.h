@@ -78,4 +78,34 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// 16-byte store that is written through and dropped from the XCD's L2 (sc1).  A kernel's plain stores stay dirty in L2
+// until the end-of-kernel release writes them back; with sc1 they have already left when the last wave ends, and outputs
+// that the same launch never re-reads do not evict its operands.  Only for 16-byte stores: narrower sc1 stores are one
+// fabric write each and slower than plain ones (MI355X_MICROARCH.md, stores of each flavour).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_sc1(void* dst, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store16_sc1(void* dst, f32x4 v) {
+    union { f32x4 f; u32x4 u; } cv;
+    cv.f = v;
+    store16_sc1(dst, cv.u);
+}
+
+// fp16x4 (8 bytes) per lane where lanes l and l ^ XM hold adjacent 4-column groups of one row (the lower group in the lane
+// with bit XM clear): either a plain 8-byte store per lane, or the lower lane collects its neighbour's half and writes 16
+// bytes write-through (sc1).  Both lanes of a pair must be active.
+template <int XM>
+__device__ __forceinline__ void store_f16x4_paired(f16* dst, f16x4 o, int lane, int paired) {
+    if (!paired) {
+        *(f16x4*)dst = o;
+        return;
+    }
+    union { f16x4 h; unsigned u[2]; } mine, other;
+    mine.h = o;
+    other.u[0] = __shfl_xor(mine.u[0], XM, 64);
+    other.u[1] = __shfl_xor(mine.u[1], XM, 64);
+    if (!(lane & XM)) store16_sc1(dst, u32x4{mine.u[0], mine.u[1], other.u[0], other.u[1]});
+}
+
 }  // namespace gtav

@@ -13,6 +13,8 @@
 // is the layout the PV product wants as its MFMA A operand.
 #include "gemm.h"
 
+#include <cstdlib>
+
 namespace gtav {
 
 namespace {
@@ -27,14 +29,7 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// Stores that drop the line from the XCD's L2 once written through (sc1): the output of a large-M GEMM is far bigger than
-// the 4 MiB L2 and is not re-read by this launch, so keeping it would only evict operand tiles.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16_sc1(void* dst, uint4 v) {
-    const u32x4 r = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r) : "memory");
-}
-
+__device__ __forceinline__ void store16q_sc1(void* dst, uint4 v) { store16_sc1(dst, u32x4{v.x, v.y, v.z, v.w}); }
 
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     union { f16x4 h; uint2 u; } cv;
@@ -391,6 +386,123 @@ __device__ __forceinline__ void tile_map(const GemmParams& p, int& n0, int& m0, 
     m0 = tile_m * TMB;
 }
 
+// QKV epilogue staged through LDS: bias + RoPE happen in registers (pairs are lane-local), the block's fp16 result is laid
+// out in LDS in the shape of its DESTINATION rows (q/k: [token][feature], V^T: [feature][token]) and leaves as 16-byte
+// stores — a whole 128-byte head row of one token (or 8 consecutive tokens of one V^T row) per 8 lanes — instead of 8-byte
+// stores scattered over 16 rows per wave-instruction.  tab[] holds the per-token destination coordinates (one integer
+// division per token instead of one per lane and token).
+template <int FI, int FJ, int WM>
+__device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], char* smem, int n0, int m0, bool tr) {
+    constexpr int TM = WM * 16 * FJ, TNB = 32 * FI;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
+    const bool compute_wave = threadIdx.x < 128 * WM;
+    const bool spatial = p.qkv_mode == QKV_SPATIAL;
+    int2* tab = (int2*)(smem + TM * TNB * 2);
+    __syncthreads();   // every wave is done reading the last K-step's stage
+    for (int r = threadIdx.x; r < TM; r += (int)blockDim.x) {
+        const int m = m0 + r;
+        int a = -1, b = 0;
+        if (m < p.M) {
+            const int fr = m / p.S;                     // spatial: attention item; temporal: frame counter over (b, tl)
+            if (spatial) {
+                a = fr;
+                b = m - fr * p.S;
+            } else {
+                const int bb = fr / p.Tq;
+                const int tfr = p.t0 + (fr - bb * p.Tq);
+                a = (bb * p.Tmax + tfr) * p.S + (m - fr * p.S);   // kv-cache token slot
+                b = tfr;
+            }
+        }
+        tab[r] = int2{a, b};
+    }
+    if (compute_wave) {
+        if (tr) {
+            // D[row = token][col = feature]: the lane owns tokens ml..ml+3 of feature nl -> V^T image [feature][token]
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int nl = 16 * FI * wn + 16 * i + li;
+                const float bv = (p.bias && n0 + nl < p.N) ? p.bias[n0 + nl] : 0.f;
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    const int ml = 16 * FJ * wm + 16 * j + 4 * g;
+                    char* dst = smem + nl * (TM * 2) + (((ml >> 3) ^ (nl & 7)) << 4) + ((ml >> 2) & 1) * 8;
+                    const f32x4 a = acc[i][j];
+                    *(uint2*)dst = pack4(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+                }
+            }
+        } else {
+            int pos[FJ];
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                int m = m0 + 16 * FJ * wm + 16 * j + li;
+                m = m < p.M ? m : p.M - 1;
+                const int fr = m / p.S;
+                pos[j] = spatial ? m - fr * p.S : p.t0 + fr % p.Tq;
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int nl = 16 * FI * wn + 16 * i + 4 * g;
+                const int n = n0 + nl;
+                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+                const bool rope = n < 2 * p.D;
+                const int d = n & 63;                    // D % 64 == 0: the offset inside the head
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    const int ml = 16 * FJ * wm + 16 * j + li;
+                    f32x4 v = acc[i][j] + bv;
+                    if (rope) {
+                        const f32x4 cs = *(const f32x4*)(p.rope_cs + pos[j] * 64 + d);
+                        f32x4 r;
+                        r[0] = v[0] * cs[0] - v[1] * cs[1];
+                        r[1] = v[1] * cs[0] + v[0] * cs[1];
+                        r[2] = v[2] * cs[2] - v[3] * cs[3];
+                        r[3] = v[3] * cs[2] + v[2] * cs[3];
+                        v = r;
+                    }
+                    char* dst = smem + ml * (TNB * 2) + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
+                    *(uint2*)dst = pack4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int heads = p.D >> 6;
+    if (tr) {
+        constexpr int CPR = TM / 8;                     // 16-byte chunks (8 tokens) per feature row
+        for (int q = threadIdx.x; q < TNB * CPR; q += (int)blockDim.x) {
+            const int nl = q / CPR, tc = q % CPR;
+            const int n = n0 + nl;
+            const int2 t = tab[tc * 8];
+            if (n >= p.N || t.x < 0) continue;
+            const uint4 val = *(const uint4*)(smem + nl * (TM * 2) + ((tc ^ (nl & 7)) << 4));
+            const int nn = n - 2 * p.D;
+            f16* dst = p.v + ((size_t)(t.x * heads + (nn >> 6)) * 64 + (nn & 63)) * p.S + t.y;
+            if (p.out_sc1) store16q_sc1(dst, val);
+            else *(uint4*)dst = val;
+        }
+    } else {
+        constexpr int CPR = TNB / 8;                    // 16-byte chunks (8 features) per token row
+        for (int q = threadIdx.x; q < TM * CPR; q += (int)blockDim.x) {
+            const int ml = q / CPR, c = q % CPR;
+            const int n = n0 + 8 * c;
+            const int2 t = tab[ml];
+            if (n >= p.N || t.x < 0) continue;
+            const uint4 val = *(const uint4*)(smem + ml * (TNB * 2) + ((c ^ (ml & 7)) << 4));
+            const int which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
+            const int nn = n - which * p.D;
+            f16* dst;
+            if (spatial) dst = (which == 0 ? p.q : p.k) + ((size_t)(t.x * heads + (nn >> 6)) * p.S + t.y) * 64 + (nn & 63);
+            else if (which == 0) dst = p.q + (size_t)(m0 + ml) * p.D + nn;
+            else dst = p.k + (size_t)t.x * 2 * p.D + (which == 2 ? p.D : 0) + nn;
+            if (p.out_sc1) store16q_sc1(dst, val);
+            else *(uint4*)dst = val;
+        }
+    }
+}
+
 // Epilogue shared by every block shape.  The block tile is TNB = 32 FI features x TM = 16 FJ WM tokens; wave (wn, wm) owns
 // features 16 FI wn .. and tokens 16 FJ wm ..; acc[i][j] is the 16 x 16 MFMA tile (feature group i, token group j).
 template <int EPI, int FI, int FJ, int WM>
@@ -435,10 +547,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
             if (rt > last_rt || (n0 >> 6) + st % CT >= nkt_out) continue;   // ragged last block tile (tokens / features)
             const uint4 val = *(const uint4*)(smem + st * TILE_BYTES + pq * 1024 + lane * 16);
             char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + st % CT) * TILE_BYTES + pq * 1024 + lane * 16;
-            if (p.out_sc1) store16_sc1(dst, val);
+            if (p.out_sc1) store16q_sc1(dst, val);
             else *(uint4*)dst = val;
         }
         return;
+    }
+    if constexpr (EPI == EPI_QKV) {
+        // block-uniform: 8-token groups of a V^T row must not straddle attention items
+        if (!(p.debug & 16) && (p.qkv_mode == QKV_TEMPORAL || p.S % 8 == 0)) {
+            qkv_staged<FI, FJ, WM>(p, acc, smem, n0, m0, tr);
+            return;
+        }
     }
     if (!compute_wave) return;
 
@@ -508,7 +627,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
             f32x4 v = acc[i][j] + bv;
             if constexpr (EPI == EPI_PARTIAL) {
                 float* dst = (float*)p.out + ((size_t)ks * p.M + m) * p.ldo + n;
-                if (p.out_sc1) { union { f32x4 f; uint4 u; } cv; cv.f = v; store16_sc1(dst, cv.u); }
+                if (p.out_sc1) store16_sc1(dst, v);
                 else *(f32x4*)dst = v;
             } else if constexpr (EPI == EPI_F32) {
                 *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
@@ -591,7 +710,7 @@ __global__ __launch_bounds__(128 * WM + 64 * NL, NL ? 3 : ((WM == 2 && NS <= 2) 
 
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES + (EPI == EPI_QKV ? 2048 : 0)];   // + qkv_staged's token table
     int n0, m0, ks, kt0, nkt;
     tile_map<EPI == EPI_PARTIAL, 256, 256>(p, n0, m0, ks, kt0, nkt);
     f32x4 acc[8][4];
@@ -612,7 +731,12 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 
 }  // namespace
 
-static int g_force_stages = 0, g_debug = 0, g_force_wm = 0;
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+// experiment knobs (also settable per process through GTAV_GEMM_DEBUG / GTAV_GEMM_SHAPE for A/B runs of bench.py)
+static int g_force_stages = 0, g_debug = env_int("GTAV_GEMM_DEBUG"), g_force_wm = env_int("GTAV_GEMM_SHAPE");
 void gemm_set_stages(int ns) { g_force_stages = ns; }
 void gemm_set_debug(int bits) { g_debug = bits; }
 void gemm_set_wm(int wm) { g_force_wm = wm; }
@@ -658,17 +782,13 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_debug & 3;
-    // 16-byte output stores of the split-K slabs and of the tile-major GELU output go out write-through-and-drop (sc1)
-    // once the output is too big to be re-read from L2 by the next kernel anyway: out-proj 22.9 -> 21.1 us at M = 5760,
-    // 38 -> 34 us at M = 11 520 (profiles/round1/v13_gemm_sc1_stores_microbench.txt).  bit 2 of the debug word forces it
-    // on, bit 3 off (experiments).
-    {
-        const size_t out_bytes = (size_t)p.M * p.N * (epi == EPI_PARTIAL ? 4 * (p.splitk > 0 ? p.splitk : 1) : 2);
-        p.out_sc1 = ((epi == EPI_PARTIAL || epi == EPI_GELU_TANH || epi == EPI_GELU_ERF) && out_bytes >= ((size_t)16 << 20)) ? 1 : 0;
-        if (g_debug & 4) p.out_sc1 = 1;
-        if (g_debug & 8) p.out_sc1 = 0;
-    }
+    p.debug = g_debug & (3 | 16);   // bit 4: direct (unstaged) QKV epilogue
+    // The 16-byte output stores of the split-K slabs, the tile-major GELU output and the staged QKV epilogue go out
+    // write-through-and-drop (sc1): nothing is left dirty in L2 for the end-of-kernel write-back, and the output does not
+    // evict operand tiles.  Measured in situ at B = 1 (every GEMM class 3-9 % shorter, consumers unchanged: 3.94 -> 4.10
+    // frames/s) and back-to-back (profiles/round1/v13_gemm_sc1_stores_microbench.txt).  8-byte sc1 stores are SLOWER (one
+    // fabric write each), so the unstaged epilogues keep plain stores.  Debug bit 3 turns it off (experiments).
+    p.out_sc1 = (g_debug & 8) ? 0 : 1;
     GTAV_REQUIRE(p.K > 0 && p.K % TK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, TK);
     GTAV_REQUIRE(p.M > 0 && p.N > 0 && p.N % 4 == 0, "gemm: bad M=%d N=%d", p.M, p.N);
     GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");

@@ -45,6 +45,7 @@ struct LnPending {
     int gate_stride;
     const int* gate_rows;
     int rows_per_gate;
+    int flags;   // set by the launcher: bit 0 = residual write-back as sc1 stores, bit 1 = fp16 output as paired 16-byte sc1 stores
 };
 
 // LayerNorm outputs are GEMM A-operands: fp16 TILE-MAJOR with logical row length D (buffer rows padded to 128).
