@@ -197,13 +197,18 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
     }
 }
 
-// block = D/4 threads: thread -> (head = tid / 16, d = 4 * (tid % 16)); one block per (b, p)
+// block = D/4 threads: thread -> (head = tid / 16, d = 4 * (tid % 16)); grid = (b * P + p, query-frame group): with `split`
+// every query frame of a (b, p) column gets its own block, which loads only the K / V frames its causal mask admits — five
+// times as many independent blocks for the 144-column batch-1 step (one block per column left 112 of 256 CUs idle and
+// chained five softmaxes per thread).
 __global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ kv,
-                                                            f16* __restrict__ O, int P, int D, int Tq, int t0, int Tmax, int sc1) {
+                                                            f16* __restrict__ O, int P, int D, int Tq, int t0, int Tmax, int sc1,
+                                                            int split) {
     const int bp = blockIdx.x;
     const int b = bp / P, p = bp - b * P;
     const int c = threadIdx.x * 4;
-    const int Tk = t0 + Tq;
+    const int tl_lo = split ? blockIdx.y : 0, tl_hi = split ? blockIdx.y + 1 : Tq;
+    const int Tk = t0 + tl_hi;                    // frames 0 .. t0 + tl_hi - 1 are visible to the last query of this block
     float kf[8][4], vf[8][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -222,10 +227,11 @@ __global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restric
     f16x4 qall[8];
 #pragma unroll
     for (int tl = 0; tl < 8; ++tl)
-        if (tl < Tq) qall[tl] = *(const f16x4*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
+        if (tl >= tl_lo && tl < tl_hi) qall[tl] = *(const f16x4*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
 #pragma unroll
     for (int tl = 0; tl < 8; ++tl) {
-        if (tl >= Tq) break;
+        if (tl >= tl_hi) break;
+        if (tl < tl_lo) continue;
         const int tq = t0 + tl;
         const size_t row = ((size_t)b * Tq + tl) * P + p;
         const f16x4 q4 = qall[tl];
@@ -296,7 +302,9 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
                          hipStream_t stream) {
     GTAV_REQUIRE(D % 256 == 0 && D <= 2048, "attn_temporal: D=%d must be a multiple of 256 and <= 2048", D);
     GTAV_REQUIRE(Tq > 0 && t0 >= 0 && t0 + Tq <= Tmax && Tmax <= 8, "attn_temporal: window t0=%d Tq=%d Tmax=%d (max 8)", t0, Tq, Tmax);
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax, g_attn_sc1);
+    const int split = (Tq > 1 && B * P < 1024) ? 1 : 0;   // few columns: one block per (column, query frame)
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P, split ? Tq : 1), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax,
+                       g_attn_sc1, split);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
