@@ -355,6 +355,86 @@ __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int
     }
 }
 
+// Piece-granular main loop for block tiles that are not multiples of the 128-row operand tiles: TNB = 32 FI features x
+// TMB = 16 FJ WM tokens, staged as 1-KiB pieces (8 rows x 64 k) whose source is located per piece, so a 96-row tile may
+// start anywhere on an 8-row boundary of the tile-major operand.  At M = 720 the 128 x 128 grid covers only 144-192 of the
+// 256 CUs and every block fills 512 KB through a ~65 GB/s per-CU LDS-DMA path; 128 x 96 / 96 x 96 tiles give 256 blocks of
+// 448 / 384 KB.  2 x WM waves; every wave issues G pieces per stage (the last waves repeat the final piece when the
+// piece count does not divide evenly: same bytes to the same place), NS-stage ring with counted vmcnt as in mainloop().
+template <bool TR, int NS, int FI, int FJ, int WM>
+__device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                           f32x4 (&acc)[FI][FJ]) {
+    constexpr int NWAVE = 2 * WM;
+    constexpr int WPC = 4 * FI, XPC = 2 * FJ * WM, NP = WPC + XPC;   // pieces per stage
+    constexpr int G = (NP + NWAVE - 1) / NWAVE;
+    constexpr int STAGE_BYTES = NP * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wm = w >> 1;
+    const int nktot = p.K / TK;
+    const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
+    const char* src[G];
+    int dsto[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        int q = w * G + i;
+        q = q < NP ? q : NP - 1;
+        const bool isw = q < WPC;
+        const int row = isw ? n0 + 8 * q : m0 + 8 * (q - WPC);
+        int rt = row >> 7;
+        const int lim = isw ? last_wt : last_rt;
+        rt = rt < lim ? rt : lim;                        // ragged edges re-read a valid tile (results are masked)
+        src[i] = (const char*)(isw ? p.W : p.X) + ((size_t)rt * nktot + kt0) * TILE_BYTES + ((row & 127) >> 3) * 1024 + lane * 16;
+        dsto[i] = q * 1024;
+    }
+    auto stage = [&](int t) {
+        char* base = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < G; ++i) glds16(src[i] + (size_t)t * TILE_BYTES, base + dsto[i]);
+    };
+    const int li = lane & 15, g = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = (16 * FI * wn + li) * 128 + ch;
+        xoff[s] = WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
+    }
+    const bool late = w >= 4;                           // second wave of a SIMD: fills after its MFMAs
+    const int npro = nkt < NS - 1 ? nkt : NS - 1;
+    for (int t = 0; t < npro; ++t) stage(t);
+    for (int t = 0; t < nkt; ++t) {
+        const int rem = nkt - 1 - t;
+        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool refill = t + NS - 1 < nkt && !(p.debug & 1);
+        if (refill && !late) stage(t + NS - 1);
+        const char* b = smem + (t % NS) * STAGE_BYTES;
+        f16x8 wf[2][FI], xf[2][FJ];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i) wf[s][i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) xf[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                }
+        if (refill && late) {
+            asm volatile("" ::: "memory");
+            stage(t + NS - 1);
+        }
+    }
+}
+
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
 // Inside an XCD's run the order is (m, n) with n FASTEST over a group of `gn` n-panels (gn = tiles_n / 8, the panels one
 // XCD owns): co-resident blocks then share X row-tiles as well as W panels in that XCD's 4 MiB L2.  With m fastest, X
@@ -398,7 +478,9 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
     const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
     const bool compute_wave = threadIdx.x < 128 * WM;
     const bool spatial = p.qkv_mode == QKV_SPATIAL;
-    int2* tab = (int2*)(smem + TM * TNB * 2);
+    constexpr int PN = (TNB / 8 + 7) / 8 * 8 * 16;   // LDS bytes per token row (q/k image): 16-byte chunks rounded up to 8
+    constexpr int PT = (TM / 8 + 7) / 8 * 8 * 16;    // LDS bytes per feature row (V^T image)
+    int2* tab = (int2*)(smem + (TM * PN > TNB * PT ? TM * PN : TNB * PT));
     __syncthreads();   // every wave is done reading the last K-step's stage
     for (int r = threadIdx.x; r < TM; r += (int)blockDim.x) {
         const int m = m0 + r;
@@ -427,7 +509,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
                     const int ml = 16 * FJ * wm + 16 * j + 4 * g;
-                    char* dst = smem + nl * (TM * 2) + (((ml >> 3) ^ (nl & 7)) << 4) + ((ml >> 2) & 1) * 8;
+                    char* dst = smem + nl * PT + (((ml >> 3) ^ (nl & 7)) << 4) + ((ml >> 2) & 1) * 8;
                     const f32x4 a = acc[i][j];
                     *(uint2*)dst = pack4(a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
                 }
@@ -462,7 +544,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
                         r[3] = v[3] * cs[2] + v[2] * cs[3];
                         v = r;
                     }
-                    char* dst = smem + ml * (TNB * 2) + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
+                    char* dst = smem + ml * PN + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
                     *(uint2*)dst = pack4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -477,7 +559,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
             const int n = n0 + nl;
             const int2 t = tab[tc * 8];
             if (n >= p.N || t.x < 0) continue;
-            const uint4 val = *(const uint4*)(smem + nl * (TM * 2) + ((tc ^ (nl & 7)) << 4));
+            const uint4 val = *(const uint4*)(smem + nl * PT + ((tc ^ (nl & 7)) << 4));
             const int nn = n - 2 * p.D;
             f16* dst = p.v + ((size_t)(t.x * heads + (nn >> 6)) * 64 + (nn & 63)) * p.S + t.y;
             if (p.out_sc1) store16q_sc1(dst, val);
@@ -490,7 +572,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
             const int n = n0 + 8 * c;
             const int2 t = tab[ml];
             if (n >= p.N || t.x < 0) continue;
-            const uint4 val = *(const uint4*)(smem + ml * (TNB * 2) + ((c ^ (ml & 7)) << 4));
+            const uint4 val = *(const uint4*)(smem + ml * PN + ((c ^ (ml & 7)) << 4));
             const int which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
             const int nn = n - which * p.D;
             f16* dst;
@@ -515,8 +597,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
 
     if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
         // The fp16 output is the next GEMM's A operand (tile-major).  The block's TM x 128 result is assembled in LDS in
-        // exactly that image — (TM / 128) x 2 sub-tiles of [128 tokens][64 features], 16 KiB each — and then copied out
-        // as fully contiguous 1 KiB pieces (16 B per lane) instead of 16 scattered 8-byte stores per lane.
+        // that image's row format — CT sub-tile columns of [TM tokens][64 features], rows swizzled like the destination —
+        // and then copied out as fully contiguous 1 KiB pieces (8 token rows, 16 B per lane) instead of 16 scattered 8-byte
+        // stores per lane.  Works for any block tile whose first token row is a multiple of 8 (96-token tiles included).
         __syncthreads();   // every wave is done reading the last K-step's stage
         if (compute_wave) {
 #pragma unroll
@@ -528,8 +611,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
                     const int ml = 16 * FJ * wm + 16 * j + li;      // token inside the block tile
-                    const int r = ml & 127;
-                    char* dst = smem + ((ml >> 7) * CT + (nl >> 6)) * TILE_BYTES + r * 128 + (((c >> 3) ^ (r & 7)) << 4) + (c & 7) * 2;
+                    char* dst = smem + ((nl >> 6) * TM + ml) * 128 + (((c >> 3) ^ (ml & 7)) << 4) + (c & 7) * 2;
                     const f32x4 v = acc[i][j] + bv;
                     if constexpr (EPI == EPI_GELU_TANH)
                         *(uint2*)dst = pack4(gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
@@ -540,13 +622,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         }
         __syncthreads();
         const int nkt_out = p.ldo >> 6, last_rt = (p.M - 1) >> 7;
-        constexpr int NPIECE = (TM / 128) * CT * 16;
-        for (int q = w; q < NPIECE; q += (int)(blockDim.x >> 6)) {
-            const int st = q >> 4, pq = q & 15;
-            const int rt = (m0 >> 7) + st / CT;
-            if (rt > last_rt || (n0 >> 6) + st % CT >= nkt_out) continue;   // ragged last block tile (tokens / features)
-            const uint4 val = *(const uint4*)(smem + st * TILE_BYTES + pq * 1024 + lane * 16);
-            char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + st % CT) * TILE_BYTES + pq * 1024 + lane * 16;
+        constexpr int PR = TM / 8;                      // 1-KiB pieces (8 token rows) per 64-feature sub-tile column
+        for (int q = w; q < CT * PR; q += (int)(blockDim.x >> 6)) {
+            const int cs = q / PR, pq = q - cs * PR;
+            const int gr = m0 + 8 * pq;                 // first token row of the piece (m0 % 8 == 0)
+            const int rt = gr >> 7;
+            if (rt > last_rt || (n0 >> 6) + cs >= nkt_out) continue;   // ragged last block tile (tokens / features)
+            const uint4 val = *(const uint4*)(smem + (cs * TM + 8 * pq) * 128 + lane * 16);
+            char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + cs) * TILE_BYTES + ((gr & 127) >> 3) * 1024 + lane * 16;
             if (p.out_sc1) store16q_sc1(dst, val);
             else *(uint4*)dst = val;
         }
@@ -729,6 +812,31 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     epilogue<EPI, 8, 4, 4>(p, acc, smem, n0, m0, ks, tr);
 }
 
+template <int EPI, int NS, int FI, int FJ, int WM>
+__global__ __launch_bounds__(128 * WM, 1) void gemm_g_kernel(GemmParams p) {
+    constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
+    constexpr int STAGE = (4 * FI + 2 * FJ * WM) * 1024;
+    // ring, or the QKV epilogue's pitched LDS image + token table, whichever is larger
+    constexpr int EPIB = TM * 256 + TNB * 256 + TM * 8;
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPIB ? NS * STAGE : EPIB];
+    int n0, m0, ks, kt0, nkt;
+    tile_map<EPI == EPI_PARTIAL, TNB, TM>(p, n0, m0, ks, kt0, nkt);
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool tr = false;
+    if constexpr (EPI == EPI_QKV) {
+        tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+        if (tr) mainloop_g<true, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc);
+        else mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc);
+    } else {
+        mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc);
+    }
+    epilogue<EPI, FI, FJ, WM>(p, acc, smem, n0, m0, ks, tr);
+}
+
 }  // namespace
 
 static int env_int(const char* name) {
@@ -749,10 +857,21 @@ int gemm_choose_splitk(int M, int N, int K) {
 }
 
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
-//        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256)
+//        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256),
+//        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves (piece-granular mainloop_g; small M)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 7) {
+    if (shape == 9) {          // 128 features x 96 tokens, 6 waves
+        const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);
+    } else if (shape == 8) {   // 96 x 96, 6 waves
+        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
+            GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
+        } else {
+            const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 96) * splitk);
+            hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 3, 2, 3>), grid, dim3(384), 0, stream, p);
+        }
+    } else if (shape == 7) {
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
         hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), 0, stream, p);
     } else if (shape == 6) {
@@ -816,6 +935,16 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     //   larger grids: 4 waves, 2-stage ring, two co-resident blocks per CU; the 128 x 256 / 8-wave tile (shape 4) ties it.
     const int blocks128 = cdiv(p.M, 128) * cdiv(p.N, TN) * splitk;
     int wm = g_force_wm ? g_force_wm : (blocks128 <= 256 ? 3 : 2);
+    if (!g_force_wm && blocks128 <= 256) {
+        // small M: every block is bound by its own L2->LDS fill (~65 GB/s per CU), i.e. by (TN + TM) x K bytes, and the grid
+        // by how many of the 256 CUs it covers.  Candidates: 128 x 128 (shape 3), 128 x 96 (shape 9), 96 x 96 (shape 8).
+        auto cost = [&](int tn, int tm) { return cdiv(cdiv(p.M, tm) * cdiv(p.N, tn) * splitk, 256) * (tn + tm); };
+        int best = cost(128, 128);
+        if (cost(128, 96) < best) best = cost(128, 96), wm = 9;
+        const bool ok96 = p.N % 96 == 0 && epi != EPI_GELU_TANH && epi != EPI_GELU_ERF && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL);
+        if (ok96 && cost(96, 96) < best) best = cost(96, 96), wm = 8;
+    }
+    GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");
     // 256 x 256 tiles (shape 7) halve the fill bytes per FLOP but run one block per CU, so a tile's epilogue (a 32 MB
     // store burst per round of 256 tiles) is not hidden by a co-resident block: they win only where the K loop is long
     // relative to the output and the grid is one well-filled round — the N = 1024 residual GEMMs at M >= 11 520
@@ -824,7 +953,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
         if (t256 * 10 >= rounds * 256 * 7) wm = 7;
     }
-    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm >= 8 ? 4 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);

@@ -61,8 +61,12 @@ def main():
                     else:
                         L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, 0, 0,
                                                      1, st))
-                for i in range(8):
-                    run(i)
+                try:
+                    for i in range(8):
+                        run(i)
+                except L.GtavError as e:          # e.g. the 96-feature tile cannot run the spatial QKV epilogue
+                    print(f"{name:>5} {M:6d} {N:5d} {K:5d}   skipped (wm={wm}): {e}")
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
