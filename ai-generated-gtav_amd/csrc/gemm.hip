@@ -813,11 +813,12 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 }
 
 template <int EPI, int NS, int FI, int FJ, int WM>
-__global__ __launch_bounds__(128 * WM, 1) void gemm_g_kernel(GemmParams p) {
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_g_kernel(GemmParams p) {
     constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
     constexpr int STAGE = (4 * FI + 2 * FJ * WM) * 1024;
-    // ring, or the QKV epilogue's pitched LDS image + token table, whichever is larger
-    constexpr int EPIB = TM * 256 + TNB * 256 + TM * 8;
+    // ring, or the QKV epilogue's pitched LDS image + token table (qkv_staged), whichever is larger
+    constexpr int PNB = (TNB / 8 + 7) / 8 * 8 * 16, PTB = (TM / 8 + 7) / 8 * 8 * 16;
+    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8;
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPIB ? NS * STAGE : EPIB];
     int n0, m0, ks, kt0, nkt;
     tile_map<EPI == EPI_PARTIAL, TNB, TM>(p, n0, m0, ks, kt0, nkt);
@@ -861,7 +862,10 @@ int gemm_choose_splitk(int M, int N, int K) {
 //        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves (piece-granular mainloop_g; small M)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 9) {          // 128 features x 96 tokens, 6 waves
+    if (shape == 10) {         // 128 features x 192 tokens, 4 waves (64 x 96 each), two blocks per CU
+        const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 6, 2>), grid, dim3(256), 0, stream, p);
+    } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
         hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);
     } else if (shape == 8) {   // 96 x 96, 6 waves
@@ -944,6 +948,12 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         const bool ok96 = p.N % 96 == 0 && epi != EPI_GELU_TANH && epi != EPI_GELU_ERF && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL);
         if (ok96 && cost(96, 96) < best) best = cost(96, 96), wm = 8;
     }
+    if (!g_force_wm && wm == 2 && cdiv(p.M, 192) * cdiv(p.N, 128) * splitk >= 320) {
+        // large M: 128 x 192 tiles (4 waves of 64 x 96, still two blocks per CU) move 17 % fewer fill bytes per FLOP than
+        // 128 x 128: QKV 62.6 -> 55.5 us, fc1 63.8 -> 61.1 us at M = 5760 (profiles/round1/v17_gemm_128x192_microbench.txt);
+        // below ~320 tiles the 512 block slots are too unevenly filled (fc2 at M = 5760: 240 tiles, 65.7 -> 73.1 us).
+        wm = 10;
+    }
     GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");
     // 256 x 256 tiles (shape 7) halve the fill bytes per FLOP but run one block per CU, so a tile's epilogue (a 32 MB
     // store burst per round of 256 tiles) is not hidden by a co-resident block: they win only where the K loop is long
@@ -953,7 +963,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
         if (t256 * 10 >= rounds * 256 * 7) wm = 7;
     }
-    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm >= 8 ? 4 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm == 10 ? 2 : wm >= 8 ? 4 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);
