@@ -423,7 +423,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->resid, Mx * D)); A_(a.alloc_t(&h->fo, Mx * h->Nfin));
     A_(a.alloc_t(&h->vout, Mx / h->P * h->C * h->H * h->W));
     // split-K slabs: splitk * M * D floats; gemm_choose_splitk keeps tiles * splitk < 384, i.e. < 384 * 128 * 128 = 6.3 M floats
-    h->parts_rows = (Mx * D > (size_t)(8u << 20) ? Mx * D : (size_t)(8u << 20)) / D;
+    h->parts_rows = (2 * Mx * D > (size_t)(8u << 20) ? 2 * Mx * D : (size_t)(8u << 20)) / D;   // two slabs at the largest M
     A_(a.alloc_t(&h->parts, h->parts_rows * D));
     const size_t R = h->max_rows;
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
@@ -793,7 +793,7 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->xp, Mx * h->Kp)); A_(a.alloc_t(&h->xn, Mx * Dm)); A_(a.alloc_t(&h->q, Mx * Dm)); A_(a.alloc_t(&h->k, Mx * Dm));
     A_(a.alloc_t(&h->vt, Mx * Dm)); A_(a.alloc_t(&h->ao, Mx * Dm)); A_(a.alloc_t(&h->hbuf, Mx * h->Hmax)); A_(a.alloc_t(&h->zin, Mx * 64));
     A_(a.alloc_t(&h->resid, Mx * Dm)); A_(a.alloc_t(&h->po, Mx * h->Npred));
-    h->parts_rows = (Mx * Dm > (size_t)(8u << 20) ? Mx * Dm : (size_t)(8u << 20)) / Dm;   // in rows of Dmax floats
+    h->parts_rows = (2 * Mx * Dm > (size_t)(8u << 20) ? 2 * Mx * Dm : (size_t)(8u << 20)) / Dm;   // in rows of Dmax floats; two slabs at the largest M
     A_(a.alloc_t(&h->parts, h->parts_rows * Dm));
 #undef A_
     if (rc) {
