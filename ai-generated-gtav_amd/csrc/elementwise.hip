@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx,
     }
 }
 
-// Small-M variant: ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS.  With only a few hundred
-// rows the wave-per-row kernel leaves most CUs idle; here every row gets its own block (measured: 720 rows 8.5 us vs 14.7).
+// ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS: the default at every M.  With a few hundred rows
+// the wave-per-row kernel leaves most CUs idle (720 rows: 8.5 us vs 14.7); at thousands of rows the 4x larger number of
+// independent blocks still keeps more loads in flight (5760 rows: 22 us vs 26).
 template <int MODE, bool PEND>
 __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
                                                            const float* __restrict__ p0, const float* __restrict__ p1,
@@ -471,6 +472,10 @@ inline int grid_for(size_t total, int block = 256) {
 // experiments: GTAV_LN_FLAGS (see LnPending::flags)
 static int g_ln_flags = getenv("GTAV_LN_FLAGS") ? atoi(getenv("GTAV_LN_FLAGS")) : 3;   // default: all stores written through (B = 1: LN 0.57 -> 0.54 ms per forward)
 
+// One block per row at every M since the write-through stores: B = 8 (M = 5760) LN 1.71 -> 1.43 ms per forward against the
+// wave-per-row kernel, M = 11 520 / 46 080 neutral.  GTAV_LN_ROWBLOCK_MAX restores a threshold for experiments.
+static int g_ln_rowblock_max = getenv("GTAV_LN_ROWBLOCK_MAX") ? atoi(getenv("GTAV_LN_ROWBLOCK_MAX")) : (1 << 30);
+
 #define LN_LAUNCH_(MODE, PEND, NV, P0, P1, STRIDE, ROWS, RPM) \
     hipLaunchKernelGGL((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)
 #define LN_DISPATCH(MODE, P0, P1, STRIDE, ROWS, RPM)                                                     \
@@ -480,7 +485,7 @@ static int g_ln_flags = getenv("GTAV_LN_FLAGS") ? atoi(getenv("GTAV_LN_FLAGS")) 
         if (pend) pd_ = *pend;                                                                            \
         pd_.flags = g_ln_flags;                                                                           \
         const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
-        if (M <= 2048) { /* small M: one block per row */                                                 \
+        if (M <= g_ln_rowblock_max) { /* small M: one block per row */                                                \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
             if (pend) hipLaunchKernelGGL((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
             else hipLaunchKernelGGL((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
