@@ -22,7 +22,8 @@ namespace {
 
 constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 
-__global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
                                                            const f16* __restrict__ Vt, f16* __restrict__ O, int heads, int S,
                                                            int S_pad, int qsplit, int sc1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
 
     // the wave's first query tile is fetched together with K / Vt (one memory round trip instead of two)
     const int nqt = (S + 15) >> 4;
-    const int qt_first = blockIdx.y * 4 + w;
+    constexpr int NT = 64 * NW;
+    const int qt_first = blockIdx.y * NW + w;
     f16x8 qpre[2] = {};
     if (qt_first < nqt) {
         int qr = qt_first * 16 + li;
@@ -52,17 +54,17 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
     // writes so that a thread has all of them in flight at once (S = 144: one batch each) ----
     {
         const int nk = S_pad * 8;
-        for (int base = tid; base < nk; base += 256 * 6) {
+        for (int base = tid; base < nk; base += NT * 6) {
             uint4 v[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * 256;
+                const int idx = base + u * NT;
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (idx < nk && (idx >> 3) < S) v[u] = *(const uint4*)(Kg + (size_t)(idx >> 3) * 64 + (idx & 7) * 8);
             }
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * 256;
+                const int idx = base + u * NT;
                 if (idx < nk) {
                     const int r = idx >> 3, c = idx & 7;
                     *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = v[u];
@@ -71,11 +73,11 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
         }
         const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
         const int nv = 64 * vchunks;
-        for (int base = tid; base < nv; base += 256 * 6) {
+        for (int base = tid; base < nv; base += NT * 6) {
             uint4 v[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * 256;
+                const int idx = base + u * NT;
                 v[u] = make_uint4(0, 0, 0, 0);
                 if (idx < nv) {
                     const int d = idx / vchunks, c = idx - d * vchunks;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
             }
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * 256;
+                const int idx = base + u * NT;
                 if (idx < nv) {
                     const int d = idx / vchunks, c = idx - d * vchunks;
                     *(uint4*)(Vs + d * vstride + c * 16) = v[u];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const f16* __restrict
 
     const int nkb = (S_pad + 63) >> 6;
     const int Dm = heads * 64;
-    for (int qt = qt_first; qt < nqt; qt += 4 * qsplit) {
+    for (int qt = qt_first; qt < nqt; qt += NW * qsplit) {
         const int q0 = qt * 16;
         f16x8 qf[2];
         if (qt == qt_first) {
@@ -283,17 +285,24 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
     const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
     GTAV_REQUIRE(lds <= 160 * 1024, "attn_spatial: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
     if (!g_attn_attr_set) {
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_attn_attr_set = true;
     }
     const int nqt = cdiv(S, 16);
     // enough blocks to fill 256 CUs when there are few (frame, head) pairs; each block re-stages K/Vt from L2
     int qsplit = 1;
     const int max_split = cdiv(nqt, 4);
-    while (NB * heads * qsplit < 512 && qsplit < max_split) ++qsplit;
-    dim3 grid(NB * heads, qsplit), block(256);
-    hipLaunchKernelGGL(attn_spatial_kernel, grid, block, lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
+    static const int blocks_target = getenv("GTAV_ATTN_S_BLOCKS") ? atoi(getenv("GTAV_ATTN_S_BLOCKS")) : 512;
+    while (NB * heads * qsplit < blocks_target && qsplit < max_split) ++qsplit;
+    // experiment (GTAV_ATTN_S_WIDE=1): with more than 4 query tiles per block nine waves walk them side by side (S = 144,
+    // many frames: 9 tiles in one round instead of 4 + 4 + 1) — each wave is a serial QK^T -> softmax -> PV chain
+    static const int wide = getenv("GTAV_ATTN_S_WIDE") ? atoi(getenv("GTAV_ATTN_S_WIDE")) : 0;   // measured neutral at B = 8 (0.41 vs 0.42 ms per forward): off
+    dim3 grid(NB * heads, qsplit);
+    if (wide && cdiv(nqt, qsplit) > 4)
+        hipLaunchKernelGGL(attn_spatial_kernel<9>, grid, dim3(576), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -302,7 +311,8 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
                          hipStream_t stream) {
     GTAV_REQUIRE(D % 256 == 0 && D <= 2048, "attn_temporal: D=%d must be a multiple of 256 and <= 2048", D);
     GTAV_REQUIRE(Tq > 0 && t0 >= 0 && t0 + Tq <= Tmax && Tmax <= 8, "attn_temporal: window t0=%d Tq=%d Tmax=%d (max 8)", t0, Tq, Tmax);
-    const int split = (Tq > 1 && B * P < 1024) ? 1 : 0;   // few columns: one block per (column, query frame)
+    static const int split_max = getenv("GTAV_ATTN_T_SPLIT_MAX") ? atoi(getenv("GTAV_ATTN_T_SPLIT_MAX")) : 1024;
+    const int split = (Tq > 1 && B * P < split_max) ? 1 : 0;   // few columns: one block per (column, query frame)
     hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P, split ? Tq : 1), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax,
                        g_attn_sc1, split);
     GTAV_CHECK_HIP(hipGetLastError());
