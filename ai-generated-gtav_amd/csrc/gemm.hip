@@ -865,10 +865,14 @@ int gemm_choose_splitk(int M, int N, int K) {
 
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
 //        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256),
-//        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves (piece-granular mainloop_g; small M)
+//        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves, 11 = 64x48 / 6 waves (piece-granular mainloop_g; small M),
+//        10 = 128x192 / 4 waves (mainloop_g; large M)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 10) {         // 128 features x 192 tokens, 4 waves (64 x 96 each), two blocks per CU
+    if (shape == 11) {         // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
+        const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384), 0, stream, p);
+    } else if (shape == 10) {  // 128 features x 192 tokens, 4 waves (64 x 96 each), two blocks per CU
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
         hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 6, 2>), grid, dim3(256), 0, stream, p);
     } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
@@ -953,6 +957,9 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         if (cost(128, 96) < best) best = cost(128, 96), wm = 9;
         const bool ok96 = p.N % 96 == 0 && epi != EPI_GELU_TANH && epi != EPI_GELU_ERF && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL);
         if (ok96 && cost(96, 96) < best) best = cost(96, 96), wm = 8;
+        // skinny M (M = 144: the context-cached sampler step): 64 x 48 tiles put 144-192 blocks of 224 KB where the
+        // 128 x 96 grid has 48-64 blocks of 448 KB
+        if (cost(64, 48) < best) best = cost(64, 48), wm = 11;
     }
     if (!g_force_wm && wm == 2 && cdiv(p.M, 192) * cdiv(p.N, 128) * splitk >= 320) {
         // large M: 128 x 192 tiles (4 waves of 64 x 96, still two blocks per CU) move 17 % fewer fill bytes per FLOP than
