@@ -1,10 +1,15 @@
-// fp16 MFMA GEMM for gfx950 with fused epilogues (see gemm.h).
+// fp16 MFMA GEMMs for gfx950 with fused epilogues (see gemm.h).
 //
-// Tile: 128 features (W rows) x 128 tokens (X rows) x 64 K per step, 256 threads = 4 waves (2 x 2),
-// each wave 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_f16.  Both operands are K-contiguous, so both
-// tiles are staged with 16-byte direct-to-LDS loads (global_load_lds_dwordx4, 1 KiB = 8 rows per
-// wave-instruction).  The LDS image is lane-linear; the bank-conflict swizzle (16-B chunk ^= row & 7)
-// is applied to the per-lane SOURCE address and to the ds_read_b128 address (same involution).
+// One family of kernels, all K-step 64, v_mfma_f32_16x16x32_f16, operands staged with 16-byte direct-to-LDS loads
+// (global_load_lds_dwordx4, 1 KiB = 8 rows per wave-instruction) into an LDS ring with counted s_waitcnt vmcnt(N) and ONE raw
+// s_barrier per K-step.  Both operands are K-contiguous and TILE-MAJOR in memory (common.h tiled_off), so a 1-KiB piece is
+// one linear copy; the LDS image is lane-linear and the bank-conflict swizzle (16-B chunk ^= row & 7) is already in the
+// source layout and is applied again to the ds_read_b128 address (same involution).
+//   gemm_kernel     128 x 128 / 128 x 256 tiles, 4 or 8 waves (+ optional loader waves)      mainloop / mainloop_ls
+//   gemm_g_kernel   piece-granular tiles that may start on any 8-row boundary: 128 x 96, 96 x 96, 64 x 48 (small M),
+//                   128 x 192 (large M, two blocks per CU)                                     mainloop_g
+//   gemm256_kernel  256 x 256 tile, K-tile in four quadrant phases                             mainloop256
+// launch_gemm() picks the shape per launch from a cost model / measured thresholds (bottom of this file).
 //
 // Orientation: the MFMA "A" operand is the W tile and "B" the X tile, so D[row = feature][col = token]:
 // every lane owns 4 CONSECUTIVE FEATURES of one token -> RoPE pairs, float4 bias/gate/residual and
