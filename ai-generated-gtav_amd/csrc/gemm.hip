@@ -818,7 +818,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 }
 
 template <int EPI, int NS, int FI, int FJ, int WM>
-__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_g_kernel(GemmParams p) {
+__global__ __launch_bounds__(128 * WM, (WM == 2 || (WM == 4 && NS == 2)) ? 2 : 1) void gemm_g_kernel(GemmParams p) {
     constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
     constexpr int STAGE = (4 * FI + 2 * FJ * WM) * 1024;
     // ring, or the QKV epilogue's pitched LDS image + token table (qkv_staged), whichever is larger
@@ -871,10 +871,13 @@ int gemm_choose_splitk(int M, int N, int K) {
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
 //        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256),
 //        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves, 11 = 64x48 / 6 waves (piece-granular mainloop_g; small M),
-//        10 = 128x192 / 4 waves (mainloop_g; large M)
+//        10 / 12 = 128x192 / 4 or 8 waves, two blocks per CU (mainloop_g; large M)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 11) {         // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
+    if (shape == 12) {         // 128 features x 192 tokens, 8 waves of 64 x 48, two blocks per CU (4 waves per SIMD)
+        const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 3, 4>), grid, dim3(512), 0, stream, p);
+    } else if (shape == 11) {  // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
         hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384), 0, stream, p);
     } else if (shape == 10) {  // 128 features x 192 tokens, 4 waves (64 x 96 each), two blocks per CU
@@ -970,7 +973,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         // large M: 128 x 192 tiles (4 waves of 64 x 96, still two blocks per CU) move 17 % fewer fill bytes per FLOP than
         // 128 x 128: QKV 62.6 -> 55.5 us, fc1 63.8 -> 61.1 us at M = 5760 (profiles/round1/v17_gemm_128x192_microbench.txt);
         // below ~320 tiles the 512 block slots are too unevenly filled (fc2 at M = 5760: 240 tiles, 65.7 -> 73.1 us).
-        wm = 10;
+        wm = 12;   // 8 waves of 64 x 48 (four per SIMD with the co-resident block): QKV 60.3 -> 54.8, fc1 62.1 -> 59.4 vs the 4-wave form (shape 10)
     }
     GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");
     // 256 x 256 tiles (shape 7) halve the fill bytes per FLOP but run one block per CU, so a tile's epilogue (a 32 MB
@@ -981,7 +984,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
         if (t256 * 10 >= rounds * 256 * 7) wm = 7;
     }
-    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : wm == 10 ? 2 : wm >= 8 ? 4 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm == 6 ? 2 : (wm == 10 || wm == 12) ? 2 : wm >= 8 ? 4 : wm >= 4 ? 3 : wm == 3 ? 4 : 2);
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);
