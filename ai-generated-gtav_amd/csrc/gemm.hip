@@ -410,7 +410,10 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
     for (int t = 0; t < npro; ++t) stage(t);
     for (int t = 0; t < nkt; ++t) {
         const int rem = nkt - 1 - t;
-        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+        // tiles newer than t already issued: min(NS - 2, rem), G loads each
+        if (NS >= 6 && rem >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * G) : "memory");
+        else if (NS >= 5 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * G) : "memory");
+        else if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
         else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const bool refill = t + NS - 1 < nkt && !(p.debug & 1);
@@ -879,13 +882,13 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
         hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 3, 4>), grid, dim3(512), 0, stream, p);
     } else if (shape == 11) {  // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384), 0, stream, p);
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384), 0, stream, p);   // 6 stages measured 6-8 % slower
     } else if (shape == 10) {  // 128 features x 192 tokens, 4 waves (64 x 96 each), two blocks per CU
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
         hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 6, 2>), grid, dim3(256), 0, stream, p);
     } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);   // 5 stages measured 4-5 % slower
     } else if (shape == 8) {   // 96 x 96, 6 waves
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
             GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
