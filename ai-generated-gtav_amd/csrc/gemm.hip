@@ -888,7 +888,7 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
         hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 6, 2>), grid, dim3(256), 0, stream, p);
     } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);   // 5 stages measured 4-5 % slower
+        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);   // 3 stages 1-3 % and 5 stages 4-5 % slower
     } else if (shape == 8) {   // 96 x 96, 6 waves
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
             GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
