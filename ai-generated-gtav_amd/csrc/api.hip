@@ -282,6 +282,16 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
         q.splitk = gemm_choose_splitk(M, D, K);
+        static const int inplace_min_m = getenv("GTAV_RESID_INPLACE_MIN_M") ? atoi(getenv("GTAV_RESID_INPLACE_MIN_M")) : (1 << 30);
+        if (q.splitk == 1 && M >= inplace_min_m) {
+            // experiment (off by default): gated residual update in the GEMM epilogue (no slab; the next LayerNorm only reads
+            // resid).  Measured at B = 8: LN 1.46 -> 1.17 ms but out-proj 0.77 -> 1.26 ms per forward (read-modify-write in the epilogue).
+            q.splitk = 0; q.out = h->resid; q.bias = bias; q.gate = gate; q.gate_stride = h->MODW; q.gate_rows = mod_rows;
+            q.rows_per_gate = P;
+            PROF(h, cls, s, launch_gemm(q, EPI_RESID, s));
+            have_pend = false;
+            return 0;
+        }
         GTAV_REQUIRE((size_t)q.splitk * M <= h->parts_rows, "split-K slabs exceed workspace");
         PROF(h, cls, s, launch_gemm(q, EPI_PARTIAL, s));
         memset(&pend, 0, sizeof(pend));

@@ -735,7 +735,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 } else {
                     x = x + v;
                 }
-                *(f32x4*)dst = x;
+                if (p.out_sc1) store16_sc1(dst, x);
+                else *(f32x4*)dst = x;
             } else if constexpr (EPI == EPI_QKV) {
                 if (which < 2) {
                     // interleaved table: (cos, sin) of pair d/2 and of pair d/2+1 in one 16-byte load
