@@ -148,7 +148,7 @@ static void build_axial_table(const std::vector<float>& freqs, int gh, int gw, s
 // accumulated per kernel class.  Used by bench.py for the roofline line; off in normal operation.
 enum ProfClass { PC_LN = 0, PC_QKV, PC_ATTN_S, PC_ATTN_T, PC_OUT, PC_FC1, PC_FC2, PC_OTHER, PC_EMPTY, PC_COUNT };
 struct Profiler {
-    bool on = false;
+    bool on = false, attached = false;
     std::vector<hipEvent_t> ev;   // pairs
     std::vector<int> cls;
     size_t used = 0;
@@ -165,12 +165,25 @@ struct Profiler {
         }
         cls.resize(ev.size() / 2);
         cls[used / 2] = c;
+        if (c == PC_QKV || c == PC_OUT || c == PC_FC1 || c == PC_FC2) {
+            // GEMM classes: the events ride on the kernel's own dispatch packet (no marker packets around it)
+            g_launch_ev[0] = ev[used];
+            g_launch_ev[1] = ev[used + 1];
+            attached = true;
+            return 0;
+        }
+        attached = false;
         GTAV_CHECK_HIP(hipEventRecord(ev[used], s));
         return 0;
     }
     int end(hipStream_t s) {
         if (!on) return 0;
-        GTAV_CHECK_HIP(hipEventRecord(ev[used + 1], s));
+        if (attached && g_launch_ev[0]) {   // nothing was launched: fall back to a plain pair
+            g_launch_ev[0] = nullptr;
+            GTAV_CHECK_HIP(hipEventRecord(ev[used], s));
+            attached = false;
+        }
+        if (!attached) GTAV_CHECK_HIP(hipEventRecord(ev[used + 1], s));
         used += 2;
         return 0;
     }

@@ -19,6 +19,7 @@
 #include "gemm.h"
 
 #include <cstdlib>
+#include <hip/hip_ext.h>
 
 namespace gtav {
 
@@ -872,6 +873,19 @@ int gemm_choose_splitk(int M, int N, int K) {
     return s;
 }
 
+// Kernel launch with optional dispatch-attached timing events (profiler): the start/stop events are filled from the
+// dispatch's own begin/end timestamps, so an in-situ measurement carries no marker-packet overhead (hip_ext.h).
+thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};
+#define GEMM_LAUNCH(kern, grid, block)                                                                        \
+    do {                                                                                                      \
+        if (g_launch_ev[0]) {                                                                                 \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, stream, g_launch_ev[0], g_launch_ev[1], 0, p);       \
+            g_launch_ev[0] = nullptr;                                                                         \
+        } else {                                                                                              \
+            hipLaunchKernelGGL(kern, grid, block, 0, stream, p);                                              \
+        }                                                                                                     \
+    } while (0)
+
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
 //        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256),
 //        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves, 11 = 64x48 / 6 waves (piece-granular mainloop_g; small M),
@@ -880,46 +894,46 @@ template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
     if (shape == 12) {         // 128 features x 192 tokens, 8 waves of 64 x 48, two blocks per CU (4 waves per SIMD)
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 3, 4>), grid, dim3(512), 0, stream, p);
+        GEMM_LAUNCH((gemm_g_kernel<EPI, 2, 4, 3, 4>), grid, dim3(512));
     } else if (shape == 11) {  // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384), 0, stream, p);   // 6 stages measured 6-8 % slower
+        GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384));   // 6 stages measured 6-8 % slower
     } else if (shape == 10) {  // 128 features x 192 tokens, 4 waves (64 x 96 each), two blocks per CU
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 2, 4, 6, 2>), grid, dim3(256), 0, stream, p);
+        GEMM_LAUNCH((gemm_g_kernel<EPI, 2, 4, 6, 2>), grid, dim3(256));
     } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
-        hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384), 0, stream, p);   // 3 stages 1-3 % and 5 stages 4-5 % slower
+        GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384));   // 3 stages 1-3 % and 5 stages 4-5 % slower
     } else if (shape == 8) {   // 96 x 96, 6 waves
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
             GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
         } else {
             const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 96) * splitk);
-            hipLaunchKernelGGL((gemm_g_kernel<EPI, 4, 3, 2, 3>), grid, dim3(384), 0, stream, p);
+            GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 3, 2, 3>), grid, dim3(384));
         }
     } else if (shape == 7) {
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
-        hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), 0, stream, p);
+        GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
     } else if (shape == 6) {
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4, 1>), grid, dim3(320), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 2, 4, 1>), grid, dim3(320), 0, stream, p);
+        if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 2, 4, 1>), grid, dim3(320));
+        else GEMM_LAUNCH((gemm_kernel<EPI, 3, 2, 4, 1>), grid, dim3(320));
     } else if (shape == 5) {
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4, 2>), grid, dim3(640), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4, 2>), grid, dim3(640), 0, stream, p);
+        if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 4, 4, 2>), grid, dim3(640));
+        else GEMM_LAUNCH((gemm_kernel<EPI, 3, 4, 4, 2>), grid, dim3(640));
     } else if (shape == 4) {
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 4, 0>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 3, 4, 4, 0>), grid, dim3(512), 0, stream, p);
+        if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 4, 4, 0>), grid, dim3(512));
+        else GEMM_LAUNCH((gemm_kernel<EPI, 3, 4, 4, 0>), grid, dim3(512));
     } else if (shape == 3) {
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 4, 2, 0>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 4, 2, 0>), grid, dim3(512), 0, stream, p);
+        if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 4, 2, 0>), grid, dim3(512));
+        else GEMM_LAUNCH((gemm_kernel<EPI, 4, 4, 2, 0>), grid, dim3(512));
     } else {
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
-        if (ns <= 2) hipLaunchKernelGGL((gemm_kernel<EPI, 2, 2, 4, 0>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<EPI, 4, 2, 4, 0>), grid, dim3(256), 0, stream, p);
+        if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 2, 4, 0>), grid, dim3(256));
+        else GEMM_LAUNCH((gemm_kernel<EPI, 4, 2, 4, 0>), grid, dim3(256));
     }
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;

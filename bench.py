@@ -9,8 +9,9 @@ all-gather).  Inputs are synthetic, generated on the CPU from fixed seeds and re
 timed region; weights are the repo's deterministic synthetic weights (no checkpoints exist offline).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (fc1 GEMM, gemm_kernel<EPI_GELU_TANH>), timed in situ with HIP events on the
-                 launch stream during real forwards (gtav_dit_profile), algorithmic FLOPs per launch / mean duration
+  roofline     — the dominant kernel (fc1 GEMM with the GELU epilogue, csrc/gemm.hip), timed in situ with HIP events on the
+                 launch stream during real forwards (gtav_dit_profile; for the GEMM classes the events are attached to the
+                 kernel's own dispatch, hipExtLaunchKernel), algorithmic FLOPs per launch / mean duration
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py, fp32 torch CPU kernels — the reference's own CPU path) on the
                  host cores, a bounded sample extrapolated to the clip (rank 0, N = 1 only)
 """
@@ -253,8 +254,9 @@ def main():
     ev_ms, ev_n = prof.pop("empty_event_pair")
     ev_over_ms = ev_ms / max(ev_n, 1)                  # cost of one HIP-event pair around nothing
     ms_fc1, n_fc1 = prof["gemm_fc1"]
-    # raw event-pair time: it includes ~2 us of marker overhead per launch (rocprofv3 shows the kernel itself ~2 us shorter,
-    # profiles/README.md), i.e. the roofline fraction below is conservative; the empty-pair time is reported for reference
+    # GEMM classes are timed with start/stop events attached to the kernel's own dispatch packet (hipExtLaunchKernel), i.e.
+    # the kernel's begin-to-end time as rocprofv3 reports it; the other classes use event pairs around the launch, which
+    # carry ~2 us of marker overhead each (the empty-pair time is reported for reference)
     avg_fc1_ms = ms_fc1 / max(n_fc1, 1)
     ach = flops_fc1 / (avg_fc1_ms * 1e-3) / 1e12
     traffic = None
@@ -262,10 +264,11 @@ def main():
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         traffic = tj.get("fc1_M%d" % M, {}).get("hbm_bytes_per_launch")
-    roofline = {"kernel": "gemm_kernel<EPI_GELU_TANH> (fc1 GEMM M=%d N=4096 K=1024, fp16 MFMA)" % M, "bound": "mfma",
+    roofline = {"kernel": "fc1 GEMM + GELU-tanh epilogue (csrc/gemm.hip, M=%d N=4096 K=1024, fp16 MFMA)" % M, "bound": "mfma",
                 "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "avg_launch_us": round(avg_fc1_ms * 1e3, 2), "launches_timed": int(n_fc1),
-                "flops_per_launch": flops_fc1, "empty_event_pair_us": round(ev_over_ms * 1e3, 2)}
+                "flops_per_launch": flops_fc1, "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
+                "empty_event_pair_us": round(ev_over_ms * 1e3, 2)}
     classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
     fwd_flops = dit_forward_flops(M, B * 5, 15, B)
     step_tflops = fwd_flops / (fwd_ms * 1e-3) / 1e12
