@@ -888,11 +888,14 @@ thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};
 
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
 //        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256),
-//        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves, 11 = 64x48 / 6 waves (piece-granular mainloop_g; small M),
+//        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves, 11 = 64x48 / 6 waves, 14 = 64x96 / 6 waves (piece-granular mainloop_g; small M),
 //        10 / 12 = 128x192 / 4 or 8 waves, two blocks per CU (mainloop_g; large M)
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
-    if (shape == 12) {         // 128 features x 192 tokens, 8 waves of 64 x 48, two blocks per CU (4 waves per SIMD)
+    if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
+        const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
+        GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 2, 3>), grid, dim3(384));
+    } else if (shape == 12) {  // 128 features x 192 tokens, 8 waves of 64 x 48, two blocks per CU (4 waves per SIMD)
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 2, 4, 3, 4>), grid, dim3(512));
     } else if (shape == 11) {  // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
@@ -985,6 +988,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         if (ok96 && cost(96, 96) < best) best = cost(96, 96), wm = 8;
         // skinny M (M = 144: the context-cached sampler step): 64 x 48 tiles put 144-192 blocks of 224 KB where the
         // 128 x 96 grid has 48-64 blocks of 448 KB
+        if (cost(64, 96) < best) best = cost(64, 96), wm = 14;   // M = 288-320 (g256 window step, batch-2 cached step)
         if (cost(64, 48) < best) best = cost(64, 48), wm = 11;
     }
     if (!g_force_wm && wm == 2 && cdiv(p.M, 192) * cdiv(p.N, 128) * splitk >= 320) {

@@ -27,6 +27,18 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 P_TOK, D_MODEL, DEPTH, HM = 144, 1024, 16, 4096
+# SURVEY.md §8(d) geometry presets.  native: the only geometry the reference's factories support (360x640 frames, VAE patch 20 ->
+# 16x18x32 latents, 144 DiT tokens per frame).  g256: the literal reading of BASELINE.json's "256x256" (VAE patch 16 -> 16x16x16
+# latents, 64 DiT tokens per frame, 256 VAE tokens) built through the reference's constructors with ViT-L/DiT-S widths.
+GEOM = {
+    "native": dict(frame=(360, 640), lat=(18, 32), vae_tokens=576, vae_gflop=(96.6, 191.6),
+                   dit=dict(), vae=dict()),
+    "g256": dict(frame=(256, 256), lat=(16, 16), vae_tokens=256, vae_gflop=(40.7, 80.9),
+                 dit=dict(input_h=16, input_w=16, patch_size=2, in_channels=16, hidden_size=1024, depth=16, num_heads=16,
+                          external_cond_dim=25),
+                 vae=dict(latent_dim=16, input_height=256, input_width=256, patch_size=16, enc_dim=1024, enc_depth=6, enc_heads=16,
+                          dec_dim=1024, dec_depth=12, dec_heads=16)),
+}
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_GBS = 8000.0
 
@@ -137,6 +149,8 @@ def main():
     ap.add_argument("--algo", choices=["window", "cached", "both"], default="both",
                     help="window = recompute the whole window every noise step (reference behaviour, headline value); "
                          "cached = exact context-K/V-cached variant; both = time both (value = window)")
+    ap.add_argument("--geometry", choices=["native", "g256"], default="native",
+                    help="native = 360x640 frames (the reference's factories; headline); g256 = 256x256 frames, SURVEY.md 8(d) preset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip VAE encode/decode (DiT loop only; not the headline)")
     ap.add_argument("--mode", choices=["generate", "train"], default="generate",
@@ -165,18 +179,33 @@ def main():
     B = args.batch_per_gpu
     total, n_prompt, steps = args.total_frames, args.n_prompt, args.noise_steps
     # ---- models with deterministic synthetic weights (every matrix non-zero, incl. adaLN) ----
-    dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
-    dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
+    global P_TOK
+    geo = GEOM[args.geometry]
+    (FH, FW), (LH, LW) = geo["frame"], geo["lat"]
+    P_TOK = (LH // 2) * (LW // 2)
+    if args.geometry == "native":
+        dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+        dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
+    else:
+        from gtav_amd.model.dit import DiT
+        dit = DiT(**geo["dit"], init_weights=False, max_batch=B)
+        dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(**geo["dit"]), seed=0))
     vae = None
     if not args.no_vae:
-        vae = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=min(32, max(4, B * 4)))
-        vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
+        nfc = min(32, max(4, B * 4))
+        if args.geometry == "native":
+            vae = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=nfc)
+            vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
+        else:
+            from gtav_amd.model.vae import AutoencoderKL
+            vae = AutoencoderKL(**geo["vae"], init_weights=False, max_frames_per_call=nfc)
+            vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(**geo["vae"]), seed=1))
 
     # ---- synthetic inputs, indexed by GLOBAL sample id so results do not depend on the sharding ----
     def sample_inputs(gid):
         g = torch.Generator().manual_seed(1000 + gid)
-        frames = torch.rand(n_prompt, 3, 360, 640, generator=g)
-        noise = torch.randn(total - n_prompt, 16, 18, 32, generator=g)
+        frames = torch.rand(n_prompt, 3, FH, FW, generator=g)
+        noise = torch.randn(total - n_prompt, 16, LH, LW, generator=g)
         return frames, noise
 
     gids = [rank * B + b for b in range(B)]
@@ -187,7 +216,7 @@ def main():
     if args.use_actions:
         actions = torch.zeros(B, total, 25, device=dev)
         actions[:, :, 3] = 1  # "W" for every frame (generate.py:159,181)
-    lat_fallback = torch.randn(B, n_prompt, 16, 18, 32, generator=torch.Generator().manual_seed(7)).to(dev) * 0.5
+    lat_fallback = torch.randn(B, n_prompt, 16, LH, LW, generator=torch.Generator().manual_seed(7)).to(dev) * 0.5
 
     def one_clip(cached):
         x0 = vae_encode(frames, vae, n_prompt) if vae is not None else lat_fallback
@@ -228,7 +257,7 @@ def main():
     # ---- roofline: in-situ HIP-event timing of every kernel class over real forwards ----
     roofline, classes = None, None
     g = torch.Generator().manual_seed(3)
-    xw = torch.randn(B, 5, 16, 18, 32, generator=g).to(dev)
+    xw = torch.randn(B, 5, 16, LH, LW, generator=g).to(dev)
     tw = torch.tensor([[15, 15, 15, 15, 500]] * B)
     aw = actions[:, :5].contiguous() if actions is not None else None
     for _ in range(2):
@@ -280,7 +309,7 @@ def main():
         cores = host_cores()
         torch.set_num_threads(cores)
         sd = dit.state_dict()
-        cfg = O.dit_s_2()
+        cfg = O.dit_s_2() if args.geometry == "native" else O.DiTConfig(**geo["dit"])
         xc = xw[:1].cpu()
         tc = tw[:1]
         with torch.no_grad():
@@ -295,12 +324,12 @@ def main():
             t_fwd = (time.perf_counter() - t0) / nf
             t_enc = t_dec = 0.0
             if vae is not None:
-                vsd, vcfg = vae.state_dict(), O.vit_l_20_shallow_encoder()
+                vsd, vcfg = vae.state_dict(), (O.vit_l_20_shallow_encoder() if args.geometry == "native" else O.VAEConfig(**geo["vae"]))
                 img = frames[0, :2].cpu() * 2 - 1
                 t0 = time.perf_counter()
                 O.vae_encode_moments(vsd, vcfg, img)
                 t_enc = (time.perf_counter() - t0) / 2
-                z = torch.randn(2, 576, 16)
+                z = torch.randn(2, geo["vae_tokens"], 16)
                 t0 = time.perf_counter()
                 O.vae_decode(vsd, vcfg, z)
                 t_dec = (time.perf_counter() - t0) / 2
@@ -311,7 +340,8 @@ def main():
                          (nf, t_fwd, t_enc, t_dec, (total - n_prompt) * (steps + 1), n_prompt, total)}
 
     if rank == 0:
-        cfg_name = "DiT-S/2 (608M) + ViT-L/20 VAE, native 360x640 frames -> 16x18x32 latents"
+        cfg_name = ("DiT-S/2 (608M) + ViT-L/20 VAE, native 360x640 frames -> 16x18x32 latents" if args.geometry == "native" else
+                    "DiT-S/2 widths on a 16x16 latent grid + ViT-L/16 VAE, g256 preset: 256x256 frames -> 16x16x16 latents (SURVEY.md 8(d))")
         line = {
             "metric": "generated frames/sec (32-frame clip, 100 noise steps)", "value": round(value, 4), "unit": "generated frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2),
@@ -321,7 +351,10 @@ def main():
                                    (2 if args.use_actions else 1, cfg_name, total, n_prompt, steps, B,
                                     ", action-conditioned" if args.use_actions else ", no actions"),
                        "global_batch": world * B, "algorithm": "window-recompute (reference behaviour)" if head == "window" else "ctx-cached",
-                       "parallelism": "batch-sharded x%d, all-gather of latents" % world, "vae_in_timed_region": vae is not None},
+                       "parallelism": "batch-sharded x%d, all-gather of latents" % world, "vae_in_timed_region": vae is not None,
+                       "geometry": args.geometry},
+            "all_frames_per_s": round(world * B * total * args.steps / el, 4),          # B * 32 / wall
+            "dit_forwards_per_s": round(world * (total - n_prompt) * (steps + 1) * args.steps / el, 2),   # batched forwards of B samples
             "roofline": roofline, "cpu_baseline": cpu,
             "dit_step": {"forward_ms_B%d_T5" % B: round(fwd_ms, 3), "executed_tflop_per_forward": round(fwd_flops / 1e12, 4),
                          "achieved_tflops": round(step_tflops, 1), "frac_of_mfma_peak": round(step_tflops / MFMA_PEAK_TFLOPS, 4),
