@@ -199,77 +199,74 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
     }
 }
 
-// block = D/4 threads: thread -> (head = tid / 16, d = 4 * (tid % 16)); grid = (b * P + p, query-frame group): with `split`
-// every query frame of a (b, p) column gets its own block, which loads only the K / V frames its causal mask admits — five
-// times as many independent blocks for the 144-column batch-1 step (one block per column left 112 of 256 CUs idle and
-// chained five softmaxes per thread).
-__global__ __launch_bounds__(512) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ kv,
-                                                            f16* __restrict__ O, int P, int D, int Tq, int t0, int Tmax, int sc1,
+// One thread per 8 consecutive features (16-byte loads / stores; 8 lanes per head), D/8 threads per (b, p) column and as many
+// columns per block as fit in 256 threads; grid = (column groups, query-frame group): with `split` every query frame of a column
+// gets its own block, which loads only the K / V frames its causal mask admits — five times as many independent blocks for the
+// 144-column batch-1 step (one block per column left 112 of 256 CUs idle and chained five softmaxes per thread).
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ kv,
+                                                            f16* __restrict__ O, int ncol, int P, int D, int Tq, int t0, int Tmax,
                                                             int split) {
-    const int bp = blockIdx.x;
+    const int tpc = D >> 3;                                     // threads per column
+    const int ci = threadIdx.x / tpc, lc = threadIdx.x - ci * tpc;
+    const int bp = blockIdx.x * ((int)blockDim.x / tpc) + ci;
+    if (bp >= ncol) return;                                     // whole 8-lane head groups leave together (tpc % 8 == 0)
     const int b = bp / P, p = bp - b * P;
-    const int c = threadIdx.x * 4;
+    const int c = lc * 8;
     const int tl_lo = split ? blockIdx.y : 0, tl_hi = split ? blockIdx.y + 1 : Tq;
     const int Tk = t0 + tl_hi;                    // frames 0 .. t0 + tl_hi - 1 are visible to the last query of this block
-    float kf[8][4], vf[8][4];
+    f16x8 k8[8], v8[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         if (t < Tk) {
             const f16* base = kv + (((size_t)b * Tmax + t) * P + p) * 2 * D;
-            const f16x4 k4 = *(const f16x4*)(base + c);
-            const f16x4 v4 = *(const f16x4*)(base + D + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                kf[t][e] = (float)k4[e];
-                vf[t][e] = (float)v4[e];
-            }
+            k8[t] = *(const f16x8*)(base + c);
+            v8[t] = *(const f16x8*)(base + D + c);
         }
     }
-    // every query row of this (b, p) is fetched up front, together with K / V (one memory round trip for the block)
-    f16x4 qall[8];
+    // every query row of this block is fetched up front, together with K / V (one memory round trip for the block)
+    f16x8 qall[8];
 #pragma unroll
     for (int tl = 0; tl < 8; ++tl)
-        if (tl >= tl_lo && tl < tl_hi) qall[tl] = *(const f16x4*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
+        if (tl >= tl_lo && tl < tl_hi) qall[tl] = *(const f16x8*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
 #pragma unroll
     for (int tl = 0; tl < 8; ++tl) {
         if (tl >= tl_hi) break;
         if (tl < tl_lo) continue;
         const int tq = t0 + tl;
         const size_t row = ((size_t)b * Tq + tl) * P + p;
-        const f16x4 q4 = qall[tl];
-        float qf[4];
+        float qf[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qf[e] = (float)q4[e];
+        for (int e = 0; e < 8; ++e) qf[e] = (float)qall[tl][e];
         float s[8];
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             s[t] = -INFINITY;
             if (t <= tq) {  // causal (model/attention.py:62-64), wave-uniform
-                float d = (qf[0] * kf[t][0] + qf[1] * kf[t][1]) + (qf[2] * kf[t][2] + qf[3] * kf[t][3]);
+                float d = ((qf[0] * (float)k8[t][0] + qf[1] * (float)k8[t][1]) + (qf[2] * (float)k8[t][2] + qf[3] * (float)k8[t][3])) +
+                          ((qf[4] * (float)k8[t][4] + qf[5] * (float)k8[t][5]) + (qf[6] * (float)k8[t][6] + qf[7] * (float)k8[t][7]));
                 d += __shfl_xor(d, 1, 64);
                 d += __shfl_xor(d, 2, 64);
                 d += __shfl_xor(d, 4, 64);
-                d += __shfl_xor(d, 8, 64);
                 s[t] = d * 0.125f;
                 mx = fmaxf(mx, s[t]);
             }
         }
-        float den = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float den = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (t <= tq) {
                 const float pr = expf(s[t] - mx);
                 den += pr;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += pr * vf[t][e];
+                for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v8[t][e];
             }
         }
         const float inv = 1.0f / den;
-        f16x4 o4;
+        f16x8 o8;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = (f16)(acc[e] * inv);
-        store_f16x4_paired<1>(O + tiled_off((int)row, c, D), o4, threadIdx.x, sc1);
+        for (int e = 0; e < 8; ++e) o8[e] = (f16)(acc[e] * inv);
+        *(f16x8*)(O + tiled_off((int)row, c, D)) = o8;
     }
 }
 
@@ -312,9 +309,10 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
     GTAV_REQUIRE(D % 256 == 0 && D <= 2048, "attn_temporal: D=%d must be a multiple of 256 and <= 2048", D);
     GTAV_REQUIRE(Tq > 0 && t0 >= 0 && t0 + Tq <= Tmax && Tmax <= 8, "attn_temporal: window t0=%d Tq=%d Tmax=%d (max 8)", t0, Tq, Tmax);
     static const int split_max = getenv("GTAV_ATTN_T_SPLIT_MAX") ? atoi(getenv("GTAV_ATTN_T_SPLIT_MAX")) : 1024;
-    const int split = (Tq > 1 && B * P < split_max) ? 1 : 0;   // few columns: one block per (column, query frame)
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3(B * P, split ? Tq : 1), dim3(D / 4), 0, stream, q, kv, O, P, D, Tq, t0, Tmax,
-                       g_attn_sc1, split);
+    const int split = (Tq > 1 && B * P < split_max) ? 1 : 0;   // few columns: one block per (column group, query frame)
+    const int tpc = D / 8, cpb = tpc >= 256 ? 1 : 256 / tpc;  // threads per column, columns per block
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3(cdiv(B * P, cpb), split ? Tq : 1), dim3(tpc * cpb), 0, stream, q, kv, O, B * P, P, D,
+                       Tq, t0, Tmax, split);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
