@@ -1,0 +1,62 @@
+"""Race screen for the GEMM block shapes (GPU): every shape runs the same problem `--reps` times, every output must be bitwise
+identical to the first run's and match fp32 math on the same fp16 operands.  An LDS-DMA read placed before the wait that retires
+it passes a single parity check whenever the copy happens to land first; repeated runs at several sizes are what catch it.
+  python tools/gemm_race_screen.py [--reps 200]"""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from gtav_amd import lib as L  # noqa: E402
+from helpers import dev, gemm, pad_weight_f16, rel_l2, to_tiled_f16, untile  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=200)
+    a = ap.parse_args()
+    lib = L.load()
+    cases = [(720, 4096, 1024), (5760, 1024, 1024), (144, 3072, 1024), (333, 512, 4096), (2880, 3072, 1024)]
+    bad = 0
+    for shape in (2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 14):
+        for (M, N, K) in cases:
+            g = torch.Generator().manual_seed(M + N + K)
+            x = (torch.randn(M, K, generator=g)).half()
+            w = torch.randn(N, K, generator=g) / math.sqrt(K)
+            b = torch.randn(N, generator=g)
+            xd, wd, bd = to_tiled_f16(x), pad_weight_f16(w), b.to(dev())
+            ref = x.float() @ w.half().float().t() + b
+            for epi in ((0, 2) if shape != 8 else (0,)):        # fp32 row-major and GELU tile-major epilogues
+                lib.gtav_op_gemm_set_wm(shape)
+                outs = []
+                first = None
+                ok = True
+                for r in range(a.reps):
+                    if epi == 0:
+                        out = torch.full((M, N), float("nan"), device=dev())
+                    else:
+                        out = torch.zeros(((M + 127) // 128 * 128, N), device=dev(), dtype=torch.float16)
+                    gemm(xd, wd, bd, M, N, K, epi, out, N)
+                    if first is None:
+                        first = out.clone()
+                        got = first.float().cpu() if epi == 0 else untile(first, M, N).float()
+                        want = ref if epi == 0 else torch.nn.functional.gelu(ref, approximate="tanh")
+                        err = rel_l2(got, want)
+                        ok = err < (2e-5 if epi == 0 else 6e-4)
+                    elif not torch.equal(out, first):
+                        ok = False
+                        break
+                lib.gtav_op_gemm_set_wm(0)
+                if not ok:
+                    bad += 1
+                print(f"shape {shape:2d} epi {epi} M={M:5d} N={N:5d} K={K:5d}: {'ok' if ok else 'MISMATCH'} (rel-L2 {err:.2e}, {a.reps} reps)")
+    print("race screen:", "clean" if bad == 0 else f"{bad} failing cases")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
