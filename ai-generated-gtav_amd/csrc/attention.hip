@@ -50,38 +50,36 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
         qpre[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
     }
 
-    // ---- stage K (swizzled) and Vt (padded), zero the padding; loads are issued in batches of 6 before the LDS
-    // writes so that a thread has all of them in flight at once (S = 144: one batch each) ----
+    // ---- stage K (swizzled) and Vt (padded), zero the padding.  K and Vt loads of a batch (6 + 6 per thread) are all issued
+    // before the first LDS write, so a block pays ONE memory round trip for S = 144 (K then Vt cost two) ----
     {
         const int nk = S_pad * 8;
-        for (int base = tid; base < nk; base += NT * 6) {
-            uint4 v[6];
+        const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
+        const int nv = 64 * vchunks;
+        const int nmax = nk > nv ? nk : nv;
+        for (int base = tid; base < nmax; base += NT * 6) {
+            uint4 kv[6], vv[6];
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const int idx = base + u * NT;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (idx < nk && (idx >> 3) < S) v[u] = *(const uint4*)(Kg + (size_t)(idx >> 3) * 64 + (idx & 7) * 8);
+                kv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nk && (idx >> 3) < S) kv[u] = *(const uint4*)(Kg + (size_t)(idx >> 3) * 64 + (idx & 7) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * NT;
+                vv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nv) {
+                    const int d = idx / vchunks, c = idx - d * vchunks;
+                    if (c * 8 < S) vv[u] = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
+                }
             }
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
                 const int idx = base + u * NT;
                 if (idx < nk) {
                     const int r = idx >> 3, c = idx & 7;
-                    *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = v[u];
-                }
-            }
-        }
-        const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
-        const int nv = 64 * vchunks;
-        for (int base = tid; base < nv; base += NT * 6) {
-            uint4 v[6];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * NT;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (idx < nv) {
-                    const int d = idx / vchunks, c = idx - d * vchunks;
-                    if (c * 8 < S) v[u] = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
+                    *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = kv[u];
                 }
             }
 #pragma unroll
@@ -89,7 +87,7 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
                 const int idx = base + u * NT;
                 if (idx < nv) {
                     const int d = idx / vchunks, c = idx - d * vchunks;
-                    *(uint4*)(Vs + d * vstride + c * 16) = v[u];
+                    *(uint4*)(Vs + d * vstride + c * 16) = vv[u];
                 }
             }
         }
@@ -132,29 +130,32 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
                     sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], sc[kt], 0, 0, 0);
                 }
             }
-            // mask padded keys, block max
+            // mask padded keys (only the last key block has any: wave-uniform branch), block max
+            if (key0 + 64 > S) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + kt * 16 + 4 * g + r;
+                        if (!(kt < nkt && key < S)) sc[kt][r] = -INFINITY;
+                    }
+            }
             float bmax = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + kt * 16 + 4 * g + r;
-                    float v = (kt < nkt && key < S) ? sc[kt][r] : -INFINITY;
-                    sc[kt][r] = v;
-                    bmax = fmaxf(bmax, v);
-                }
-            }
+                for (int r = 0; r < 4; ++r) bmax = fmaxf(bmax, sc[kt][r]);
             bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
             bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
             const float mnew = fmaxf(mrun, bmax);
-            const float alpha = exp2f((mrun - mnew) * kScaleLog2e);
+            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * kScaleLog2e);   // raw v_exp_f32: argument <= 0
             mrun = mnew;
             float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = exp2f((sc[kt][r] - mnew) * kScaleLog2e);
+                    const float pv = __builtin_amdgcn_exp2f((sc[kt][r] - mnew) * kScaleLog2e);
                     sc[kt][r] = pv;
                     psum += pv;
                 }

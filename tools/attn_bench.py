@@ -44,7 +44,7 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.iters
         mb = NB * H * S * 64 * 2 * 4 / 1e6
-        print(f"attn_spatial NB={NB:4d} heads={H} S={S}: {us:8.2f} us   {mb:7.1f} MB moved -> {mb / us / 1e3:5.2f} TB/s   "
+        print(f"attn_spatial NB={NB:4d} heads={H} S={S}: {us:8.2f} us   {mb:7.1f} MB moved -> {mb / us:5.2f} TB/s   "
               f"{4.0 * NB * H * S * S * 64 / us / 1e6:7.1f} TFLOP/s")
 
 
