@@ -200,10 +200,24 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
     }
 }
 
+// Sum over the 8 lanes of a head group with DPP moves (quad xor 1, quad xor 2, half-row mirror) instead of three
+// ds_bpermute-based shuffles: every lane of the group ends up with the group's total.
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 // One thread per 8 consecutive features (16-byte loads / stores; 8 lanes per head), D/8 threads per (b, p) column and as many
 // columns per block as fit in 256 threads; grid = (column groups, query-frame group): with `split` every query frame of a column
 // gets its own block, which loads only the K / V frames its causal mask admits — five times as many independent blocks for the
 // 144-column batch-1 step (one block per column left 112 of 256 CUs idle and chained five softmaxes per thread).
+// q.k uses v_dot2_f32_f16 (exact fp16 products, fp32 accumulation), the head reduction is DPP, exp is the raw v_exp_f32.
+// TM = compile-time bound on the number of frames (5 for the DiT's window, 8 otherwise): the frame loops are fully unrolled.
+template <int TM>
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ kv,
                                                             f16* __restrict__ O, int ncol, int P, int D, int Tq, int t0, int Tmax,
                                                             int split) {
@@ -215,52 +229,48 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     const int c = lc * 8;
     const int tl_lo = split ? blockIdx.y : 0, tl_hi = split ? blockIdx.y + 1 : Tq;
     const int Tk = t0 + tl_hi;                    // frames 0 .. t0 + tl_hi - 1 are visible to the last query of this block
-    f16x8 k8[8], v8[8];
+    union H8 { f16x8 v; f16x2 h[4]; };
+    H8 k8[TM], v8[TM];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < TM; ++t) {
         if (t < Tk) {
             const f16* base = kv + (((size_t)b * Tmax + t) * P + p) * 2 * D;
-            k8[t] = *(const f16x8*)(base + c);
-            v8[t] = *(const f16x8*)(base + D + c);
+            k8[t].v = *(const f16x8*)(base + c);
+            v8[t].v = *(const f16x8*)(base + D + c);
         }
     }
     // every query row of this block is fetched up front, together with K / V (one memory round trip for the block)
-    f16x8 qall[8];
+    H8 qall[TM];
 #pragma unroll
-    for (int tl = 0; tl < 8; ++tl)
-        if (tl >= tl_lo && tl < tl_hi) qall[tl] = *(const f16x8*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
+    for (int tl = 0; tl < TM; ++tl)
+        if (tl >= tl_lo && tl < tl_hi) qall[tl].v = *(const f16x8*)(q + (((size_t)b * Tq + tl) * P + p) * D + c);
 #pragma unroll
-    for (int tl = 0; tl < 8; ++tl) {
+    for (int tl = 0; tl < TM; ++tl) {
         if (tl >= tl_hi) break;
         if (tl < tl_lo) continue;
         const int tq = t0 + tl;
         const size_t row = ((size_t)b * Tq + tl) * P + p;
-        float qf[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[e] = (float)qall[tl][e];
-        float s[8];
+        float s[TM];
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < TM; ++t) {
             s[t] = -INFINITY;
             if (t <= tq) {  // causal (model/attention.py:62-64), wave-uniform
-                float d = ((qf[0] * (float)k8[t][0] + qf[1] * (float)k8[t][1]) + (qf[2] * (float)k8[t][2] + qf[3] * (float)k8[t][3])) +
-                          ((qf[4] * (float)k8[t][4] + qf[5] * (float)k8[t][5]) + (qf[6] * (float)k8[t][6] + qf[7] * (float)k8[t][7]));
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d += __shfl_xor(d, 4, 64);
-                s[t] = d * 0.125f;
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_fdot2(qall[tl].h[e], k8[t].h[e], d, false);
+                s[t] = group8_sum(d) * 0.125f;
                 mx = fmaxf(mx, s[t]);
             }
         }
         float den = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t = 0; t < TM; ++t) {
             if (t <= tq) {
-                const float pr = expf(s[t] - mx);
+                const float pr = __builtin_amdgcn_exp2f((s[t] - mx) * 1.4426950408889634f);   // argument <= 0
                 den += pr;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v8[t][e];
+                for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v8[t].v[e];
             }
         }
         const float inv = 1.0f / den;
@@ -312,8 +322,9 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
     static const int split_max = getenv("GTAV_ATTN_T_SPLIT_MAX") ? atoi(getenv("GTAV_ATTN_T_SPLIT_MAX")) : 1024;
     const int split = (Tq > 1 && B * P < split_max) ? 1 : 0;   // few columns: one block per (column group, query frame)
     const int tpc = D / 8, cpb = tpc >= 256 ? 1 : 256 / tpc;  // threads per column, columns per block
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3(cdiv(B * P, cpb), split ? Tq : 1), dim3(tpc * cpb), 0, stream, q, kv, O, B * P, P, D,
-                       Tq, t0, Tmax, split);
+    const dim3 grid(cdiv(B * P, cpb), split ? Tq : 1), block(tpc * cpb);
+    if (Tmax <= 5) hipLaunchKernelGGL(attn_temporal_kernel<5>, grid, block, 0, stream, q, kv, O, B * P, P, D, Tq, t0, Tmax, split);
+    else hipLaunchKernelGGL(attn_temporal_kernel<8>, grid, block, 0, stream, q, kv, O, B * P, P, D, Tq, t0, Tmax, split);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
