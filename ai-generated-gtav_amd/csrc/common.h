@@ -67,6 +67,22 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 // exact (erf) GELU: 0.5 x (1 + erf(x / sqrt(2)))
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
+// Wave-wide sum with DPP moves instead of six ds_bpermute shuffles (each of those is an LDS round trip on the critical path):
+// quad xor 1, quad xor 2, half-row mirror, row mirror leave every 16-lane row's total in all its lanes; row_bcast15 /
+// row_bcast31 then chain the four rows into lane 63, which is broadcast with v_readlane.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define GTAV_DPP_ADD(ctrl, rmask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, true))
+    GTAV_DPP_ADD(0xB1, 0xF);    // quad_perm [1,0,3,2]
+    GTAV_DPP_ADD(0x4E, 0xF);    // quad_perm [2,3,0,1]
+    GTAV_DPP_ADD(0x141, 0xF);   // row_half_mirror
+    GTAV_DPP_ADD(0x140, 0xF);   // row_mirror
+    GTAV_DPP_ADD(0x142, 0xA);   // row_bcast15 into rows 1 and 3
+    GTAV_DPP_ADD(0x143, 0xC);   // row_bcast31 into rows 2 and 3
+#undef GTAV_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

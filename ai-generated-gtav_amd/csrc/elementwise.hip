@@ -147,32 +147,52 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         bv = *(const f32x4*)(b + c);
     }
     if (PEND && act) {
-        f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // every load of the pending update is issued before the first add: the split-K slabs are independent, and a
+        // load-add-load-add chain costs one memory round trip per slab (the compiler does not hoist loads across the
+        // `sp < nsplit` tests).  Unused slab slots re-read slab 0 (an L1 hit) and are not added; the order of the adds
+        // (bias, slab 0, slab 1, ...) is unchanged.
         const float* pp = pd.parts + (size_t)m * pd.ld + c;
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp)
-            if (sp < pd.nsplit) y = y + *(const f32x4*)(pp + (size_t)sp * pd.slab_stride);
+        f32x4 g4 = f32x4{1.f, 1.f, 1.f, 1.f};
         if (pd.gate) {
             int gr = m / pd.rows_per_gate;
             if (pd.gate_rows) gr = pd.gate_rows[gr];
-            y = y * *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
+            g4 = *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
         }
+        f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 sl[8];
+        const int nchunk = pd.nsplit <= 2 ? 2 : pd.nsplit <= 4 ? 4 : 8;     // block-uniform
+        if (nchunk == 2) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) sl[sp] = *(const f32x4*)(pp + (size_t)(sp < pd.nsplit ? sp : 0) * pd.slab_stride);
+        } else if (nchunk == 4) {
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) sl[sp] = *(const f32x4*)(pp + (size_t)(sp < pd.nsplit ? sp : 0) * pd.slab_stride);
+        } else {
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) sl[sp] = *(const f32x4*)(pp + (size_t)(sp < pd.nsplit ? sp : 0) * pd.slab_stride);
+        }
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp)
+            if (sp < nchunk && sp < pd.nsplit) y = y + sl[sp];
+        if (pd.gate) y = y * g4;
         v = v + y;
         if (pd.flags & 1) store16_sc1(xr + c, v);
         else *(f32x4*)(xr + c) = v;
     }
-    float s = wave_sum((v[0] + v[1]) + (v[2] + v[3]));
+    float s = wave_sum_dpp((v[0] + v[1]) + (v[2] + v[3]));
     if (lane == 0) red[wid] = s;
     __syncthreads();
     float tot = 0.f;
-    for (int i = 0; i < nw; ++i) tot += red[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += i < nw ? red[i] : 0.f;     // red[] is read with two ds_read_b128, not a counted loop
     const float mean = tot / (float)D;
     const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-    float q = wave_sum(act ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f);
+    float q = wave_sum_dpp(act ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f);
     if (lane == 0) red[8 + wid] = q;
     __syncthreads();
     float tq = 0.f;
-    for (int i = 0; i < nw; ++i) tq += red[8 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tq += i < nw ? red[8 + i] : 0.f;
     const float rstd = 1.0f / sqrtf(tq / (float)D + 1e-6f);
     if (!act) return;
     const float dd[4] = {d0, d1, d2, d3};
