@@ -119,8 +119,13 @@ __device__ __forceinline__ void store_f16x4_paired(f16* dst, f16x4 o, int lane, 
     }
     union { f16x4 h; unsigned u[2]; } mine, other;
     mine.h = o;
-    other.u[0] = __shfl_xor(mine.u[0], XM, 64);
-    other.u[1] = __shfl_xor(mine.u[1], XM, 64);
+    if constexpr (XM == 1) {   // neighbour lane: a DPP quad permute [1,0,3,2] instead of an LDS-crossbar shuffle
+        other.u[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine.u[0], 0xB1, 0xF, 0xF, true);
+        other.u[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine.u[1], 0xB1, 0xF, 0xF, true);
+    } else {
+        other.u[0] = __shfl_xor(mine.u[0], XM, 64);
+        other.u[1] = __shfl_xor(mine.u[1], XM, 64);
+    }
     if (!(lane & XM)) store16_sc1(dst, u32x4{mine.u[0], mine.u[1], other.u[0], other.u[1]});
 }
 
