@@ -165,8 +165,8 @@ struct Profiler {
         }
         cls.resize(ev.size() / 2);
         cls[used / 2] = c;
-        if (c == PC_QKV || c == PC_OUT || c == PC_FC1 || c == PC_FC2) {
-            // GEMM classes: the events ride on the kernel's own dispatch packet (no marker packets around it)
+        if (c != PC_OTHER && c != PC_EMPTY) {
+            // single-kernel classes (GEMMs, LayerNorm, attention): the events ride on the kernel's own dispatch packet
             g_launch_ev[0] = ev[used];
             g_launch_ev[1] = ev[used + 1];
             attached = true;

@@ -308,9 +308,9 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
     static const int wide = getenv("GTAV_ATTN_S_WIDE") ? atoi(getenv("GTAV_ATTN_S_WIDE")) : 0;   // measured neutral at B = 8 (0.41 vs 0.42 ms per forward): off
     dim3 grid(NB * heads, qsplit);
     if (wide && cdiv(nqt, qsplit) > 4)
-        hipLaunchKernelGGL(attn_spatial_kernel<9>, grid, dim3(576), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
+        GTAV_LAUNCH(attn_spatial_kernel<9>, grid, dim3(576), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
     else
-        hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
+        GTAV_LAUNCH(attn_spatial_kernel<4>, grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -323,8 +323,8 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
     const int split = (Tq > 1 && B * P < split_max) ? 1 : 0;   // few columns: one block per (column group, query frame)
     const int tpc = D / 8, cpb = tpc >= 256 ? 1 : 256 / tpc;  // threads per column, columns per block
     const dim3 grid(cdiv(B * P, cpb), split ? Tq : 1), block(tpc * cpb);
-    if (Tmax <= 5) hipLaunchKernelGGL(attn_temporal_kernel<5>, grid, block, 0, stream, q, kv, O, B * P, P, D, Tq, t0, Tmax, split);
-    else hipLaunchKernelGGL(attn_temporal_kernel<8>, grid, block, 0, stream, q, kv, O, B * P, P, D, Tq, t0, Tmax, split);
+    if (Tmax <= 5) GTAV_LAUNCH(attn_temporal_kernel<5>, grid, block, 0, stream, q, kv, O, B * P, P, D, Tq, t0, Tmax, split);
+    else GTAV_LAUNCH(attn_temporal_kernel<8>, grid, block, 0, stream, q, kv, O, B * P, P, D, Tq, t0, Tmax, split);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

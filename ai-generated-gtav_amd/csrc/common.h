@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace gtav {
@@ -14,6 +15,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WAVE = 64;
+
+// ---- kernel launch with optional dispatch-attached timing events (profiler hook) ----
+// When g_launch_ev[0] is set (api.hip's Profiler, one class at a time), the next launch of this thread attaches the start /
+// stop events to its own dispatch packet (hipExtLaunchKernel) and clears the slot: in-situ kernel times then carry no
+// marker-packet overhead and agree with rocprofv3's kernel trace.
+extern thread_local hipEvent_t g_launch_ev[2];
+#define GTAV_LAUNCH(kern, grid, block, shmem, stream, ...)                                                              \
+    do {                                                                                                                \
+        if (gtav::g_launch_ev[0]) {                                                                                     \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, gtav::g_launch_ev[0], gtav::g_launch_ev[1], 0, __VA_ARGS__); \
+            gtav::g_launch_ev[0] = nullptr;                                                                             \
+        } else {                                                                                                        \
+            hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                                          \
+        }                                                                                                               \
+    } while (0)
 
 // ---- error plumbing (C-ABI functions never throw; they return an int and set this string) ----
 void set_error(const char* fmt, ...);

@@ -507,8 +507,8 @@ static int g_ln_rowblock_max = getenv("GTAV_LN_ROWBLOCK_MAX") ? atoi(getenv("GTA
         const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
         if (M <= g_ln_rowblock_max) { /* small M: one block per row */                                                \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
-            if (pend) hipLaunchKernelGGL((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
-            else hipLaunchKernelGGL((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
+            if (pend) GTAV_LAUNCH((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
+            else GTAV_LAUNCH((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
         } else if (pend) {                                                                                       \
             if (nv_ == 1) LN_LAUNCH_(MODE, true, 1, P0, P1, STRIDE, ROWS, RPM);                           \
             else if (nv_ == 2) LN_LAUNCH_(MODE, true, 2, P0, P1, STRIDE, ROWS, RPM);                      \

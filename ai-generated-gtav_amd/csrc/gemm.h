@@ -53,10 +53,6 @@ struct GemmParams {
                             // cos/sin of features 2k and 2k+1 are equal, rotary_embedding_torch.py:337)
 };
 
-// Profiler hook: when g_launch_ev[0] is set, the next GEMM launch of this thread attaches these start/stop events to its
-// dispatch (hipExtLaunchKernel) and clears the slot.
-extern thread_local hipEvent_t g_launch_ev[2];
-
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 // Split-K factor used for a residual GEMM of this shape (1 = no split): fills the 256 CUs when M is small.

@@ -873,18 +873,8 @@ int gemm_choose_splitk(int M, int N, int K) {
     return s;
 }
 
-// Kernel launch with optional dispatch-attached timing events (profiler): the start/stop events are filled from the
-// dispatch's own begin/end timestamps, so an in-situ measurement carries no marker-packet overhead (hip_ext.h).
-thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};
-#define GEMM_LAUNCH(kern, grid, block)                                                                        \
-    do {                                                                                                      \
-        if (g_launch_ev[0]) {                                                                                 \
-            hipExtLaunchKernelGGL(kern, grid, block, 0, stream, g_launch_ev[0], g_launch_ev[1], 0, p);       \
-            g_launch_ev[0] = nullptr;                                                                         \
-        } else {                                                                                              \
-            hipLaunchKernelGGL(kern, grid, block, 0, stream, p);                                              \
-        }                                                                                                     \
-    } while (0)
+thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};   // common.h GTAV_LAUNCH
+#define GEMM_LAUNCH(kern, grid, block) GTAV_LAUNCH(kern, grid, block, 0, stream, p)
 
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 4 = 128x256 / 8 waves, 5 = 128x256 / 8 compute + 2 loader waves,
 //        6 = 128x128 / 4 compute + 1 loader wave (two blocks per CU), 7 = 256x256 / 8 waves, phased K-tile (mainloop256),

@@ -10,8 +10,8 @@ timed region; weights are the repo's deterministic synthetic weights (no checkpo
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     — the dominant kernel (fc1 GEMM with the GELU epilogue, csrc/gemm.hip), timed in situ with HIP events on the
-                 launch stream during real forwards (gtav_dit_profile; for the GEMM classes the events are attached to the
-                 kernel's own dispatch, hipExtLaunchKernel), algorithmic FLOPs per launch / mean duration
+                 launch stream during real forwards (gtav_dit_profile; the events are attached to the kernel's own dispatch,
+                 hipExtLaunchKernel), algorithmic FLOPs per launch / mean duration
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py, fp32 torch CPU kernels — the reference's own CPU path) on the
                  host cores, a bounded sample extrapolated to the clip (rank 0, N = 1 only)
 """
@@ -283,9 +283,9 @@ def main():
     ev_ms, ev_n = prof.pop("empty_event_pair")
     ev_over_ms = ev_ms / max(ev_n, 1)                  # cost of one HIP-event pair around nothing
     ms_fc1, n_fc1 = prof["gemm_fc1"]
-    # GEMM classes are timed with start/stop events attached to the kernel's own dispatch packet (hipExtLaunchKernel), i.e.
-    # the kernel's begin-to-end time as rocprofv3 reports it; the other classes use event pairs around the launch, which
-    # carry ~2 us of marker overhead each (the empty-pair time is reported for reference)
+    # single-kernel classes (GEMMs, LayerNorm, attention) are timed with start/stop events attached to the kernel's own dispatch
+    # packet (hipExtLaunchKernel), i.e. the kernel's begin-to-end time as rocprofv3 reports it; only `other` (multi-kernel) uses
+    # event pairs around the launches, which carry ~2 us of marker overhead each (the empty-pair time is reported for reference)
     avg_fc1_ms = ms_fc1 / max(n_fc1, 1)
     ach = flops_fc1 / (avg_fc1_ms * 1e-3) / 1e12
     traffic = None
