@@ -210,6 +210,15 @@ struct Profiler {
         RET_IF((h)->prof.end(s));      \
     } while (0)
 
+// device error word -> message (common.h ERR_*)
+static int report_err_flag(int flag, const char* who) {
+    GTAV_REQUIRE(!(flag & ERR_TIMESTEP), "%s: a timestep outside [0, 999] was passed", who);
+    GTAV_REQUIRE(!(flag & ERR_NONFINITE), "%s: a NaN or inf was found in the input tensor", who);
+    GTAV_REQUIRE(!(flag & ERR_F16_SAT), "%s: an activation exceeded the fp16 range (|x| > 65504) and was saturated; results since the "
+                 "last check are finite but clipped (the reference runs this path in bf16, which has fp32 range)", who);
+    return 0;
+}
+
 // ================================================================================================
 // DiT
 // ================================================================================================
@@ -242,6 +251,9 @@ struct gtav_dit {
     int* mod_rows_dev = nullptr;   // [maxB * maxT] rows of the per-frame conditioning table used by the current step
     int* t_steps_dev = nullptr;    // [1024]
     struct { bool valid = false; int B = 0, F = 0, start = 0, cur = 0, n_steps = 0; const float* actions = nullptr; } prepared;
+    // which window the per-layer temporal K/V caches currently describe: written by a full-window (mode 0) sampler step,
+    // required by a context-cached (mode 1) step, invalidated by anything else that writes the caches (gtav_dit_forward)
+    struct { bool valid = false; int B = 0, F = 0, start = 0, cur = 0; const void* x = nullptr; } kvrec;
     // captured hipGraphs of the fused sampler step, keyed by (shape, mode, buffers)
     struct GraphKey {
         int B, F, T, mode;
@@ -252,6 +264,7 @@ struct gtav_dit {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;   // nullptr value = shape seen once (eager warm-up done), not yet captured
     bool use_graph = true;
+    int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
     hipStream_t cap_stream = nullptr;            // private stream the step is captured on (the caller's may be the null stream)
     ~gtav_dit() {
         for (auto& kv : graphs)
@@ -280,7 +293,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                             const float* mod, const int* mod_rows, float* v_out, hipStream_t s) {
     const int D = h->D, P = h->P, NB = B * Tq, M = NB * P;
     GTAV_REQUIRE(M <= h->Mmax, "forward: %d tokens exceed workspace (%d)", M, h->Mmax);
-    PROF(h, PC_OTHER, s, launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, s));
+    PROF(h, PC_OTHER, s, launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, h->err_flag, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kpe; g.W = h->w_pe; g.M = M; g.N = D; g.K = h->Kpe; g.bias = h->b_pe; g.out = h->resid; g.ldo = D;
@@ -295,8 +308,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
         q.splitk = gemm_choose_splitk(M, D, K);
-        static const int inplace_min_m = getenv("GTAV_RESID_INPLACE_MIN_M") ? atoi(getenv("GTAV_RESID_INPLACE_MIN_M")) : (1 << 30);
-        if (q.splitk == 1 && M >= inplace_min_m) {
+        if (q.splitk == 1 && M >= h->resid_inplace_min_m) {
             // experiment (off by default): gated residual update in the GEMM epilogue (no slab; the next LayerNorm only reads
             // resid).  Measured at B = 8: LN 1.46 -> 1.17 ms but out-proj 0.77 -> 1.26 ms per forward (read-modify-write in the epilogue).
             q.splitk = 0; q.out = h->resid; q.bias = bias; q.gate = gate; q.gate_stride = h->MODW; q.gate_rows = mod_rows;
@@ -317,10 +329,10 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         for (int hf = 0; hf < 2; ++hf) {
             const gtav_dit::Half& w = h->halves[l * 2 + hf];
             const float* mb = mod + (size_t)(l * 2 + hf) * 6 * D;
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, s));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
-            g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
+            g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
             if (hf == 0) {
                 g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
                 g.rope_cs = h->rope_s.cs_dev;
@@ -333,16 +345,16 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
             else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, s));
+            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
-            g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad;
+            g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
             PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
             RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D));
         }
     }
     const float* mf = mod + (size_t)h->L * 12 * D;
-    PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, s));
+    PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
     PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
@@ -354,7 +366,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
 extern "C" {
 
 const char* gtav_last_error(void) { return gtav::last_error(); }
-int gtav_abi_version(void) { return 1; }
+int gtav_abi_version(void) { return 2; }
 
 int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     GTAV_REQUIRE(c && out, "dit_create: null argument");
@@ -452,7 +464,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
     A_(a.alloc_t(&h->err_flag, 4)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
     A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
-    if (const char* e = getenv("GTAV_GRAPH")) h->use_graph = atoi(e) != 0;
+    h->use_graph = GTAV_ENV_INT("GTAV_GRAPH", 1) != 0;   // the shipped library reads no environment: gtav_dit_set_graph() is the switch
 #undef A_
     if (rc) {
         delete h;
@@ -535,6 +547,10 @@ int gtav_dit_forward(gtav_dit* h, const float* x, const int64_t* t, const float*
     GTAV_REQUIRE(B >= 1 && B <= h->maxB && T >= 1 && T <= h->maxT, "dit_forward: B=%d T=%d outside capacity (%d, %d)", B, T, h->maxB, h->maxT);
     GTAV_REQUIRE(!actions || h->A > 0, "dit_forward: model has no external_cond");
     hipStream_t s = (hipStream_t)stream;
+    // a plain forward overwrites the first B*T rows of the conditioning buffers (mod, E, HC, Sc) and the temporal K/V caches
+    // at t0 = 0: a table prepared by gtav_dit_prepare_frame and the context cached by a window step are gone after it
+    h->prepared.valid = false;
+    h->kvrec.valid = false;
     RET_IF(dit_cond(h, t, B * T, 1, nullptr, 0, actions, h->A, 0, s));
     return dit_forward_core(h, x, nullptr, B, T, 0, h->mod, nullptr, out, s);
 }
@@ -602,6 +618,14 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
                      "denoise_step: cond_step=%d but gtav_dit_prepare_frame was not called for this window", cond_step);
     else
         h->prepared.valid = false;  // the inline path overwrites the conditioning table
+    if (mode == 1) {
+        GTAV_REQUIRE(h->kvrec.valid && h->kvrec.B == B && h->kvrec.F == F && h->kvrec.start == start && h->kvrec.cur == cur &&
+                         h->kvrec.x == (const void*)x,
+                     "denoise_step: context-cached step (mode 1) on window [%d, %d] without a preceding full-window step (mode 0) "
+                     "on the same batch / window / latent buffer: the temporal K/V caches would be stale", start, cur);
+    } else {
+        h->kvrec.valid = true; h->kvrec.B = B; h->kvrec.F = F; h->kvrec.start = start; h->kvrec.cur = cur; h->kvrec.x = x;
+    }
     hipStream_t s = (hipStream_t)stream;
     StepParams sp;
     sp.first = start; sp.cur = cur; sp.t_ctx = t_ctx; sp.t_cur = t_cur; sp.is_final = is_final != 0;
@@ -681,8 +705,7 @@ int gtav_dit_check(gtav_dit* h, void* stream) {
     GTAV_CHECK_HIP(hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     GTAV_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, sizeof(int), (hipStream_t)stream));
-    GTAV_REQUIRE(flag == 0, "a timestep outside [0, 999] was passed to the DiT");
-    return 0;
+    return report_err_flag(flag, "DiT");
 }
 
 }  // extern "C"
@@ -702,6 +725,7 @@ struct gtav_vae {
     RopeTable rope_e, rope_d;
     f16 *xp, *xn, *q, *k, *vt, *ao, *hbuf, *zin;
     float *resid, *po, *parts;
+    int* err_flag = nullptr;
     size_t parts_rows = 0;
     bool finalized = false;
 };
@@ -727,22 +751,22 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         return 0;
     };
     for (auto& b : blocks) {
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, s));
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, h->err_flag, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_qkv; g.M = M; g.N = 3 * dim; g.K = dim; g.bias = b.b_qkv; g.D = dim; g.S = h->S;
-        g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cs = rope.cs_dev;
+        g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cs = rope.cs_dev; g.err_flag = h->err_flag;
         RET_IF(launch_gemm(g, EPI_QKV, s));
         RET_IF(launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s));
         RET_IF(resid_gemm(h->ao, dim, b.w_proj, dim, b.b_proj));
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, s));
+        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, h->err_flag, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
-        g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad;
+        g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad; g.err_flag = h->err_flag;
         RET_IF(launch_gemm(g, EPI_GELU_ERF, s));
         RET_IF(resid_gemm(h->hbuf, Hm_pad, b.w_fc2, Hm_pad, b.b_fc2));
     }
-    return launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, s);
+    return launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, h->err_flag, s);
 }
 
 extern "C" {
@@ -818,6 +842,7 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->resid, Mx * Dm)); A_(a.alloc_t(&h->po, Mx * h->Npred));
     h->parts_rows = (2 * Mx * Dm > (size_t)(8u << 20) ? 2 * Mx * Dm : (size_t)(8u << 20)) / Dm;   // in rows of Dmax floats; two slabs at the largest M
     A_(a.alloc_t(&h->parts, h->parts_rows * Dm));
+    A_(a.alloc_t(&h->err_flag, 4));
 #undef A_
     if (rc) {
         delete h;
@@ -867,7 +892,7 @@ int gtav_vae_encode(gtav_vae* h, const float* img, float in_scale, float in_shif
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_encode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int De = h->cfg.enc_dim, M = N * h->S;
-    RET_IF(launch_patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, s));
+    RET_IF(launch_patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, h->err_flag, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kp; g.W = h->w_patch; g.M = M; g.N = De; g.K = h->Kp; g.bias = h->b_patch; g.out = h->resid; g.ldo = De;
@@ -900,9 +925,24 @@ int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, floa
     return 0;
 }
 
+int gtav_vae_check(gtav_vae* h, void* stream) {
+    GTAV_REQUIRE(h, "vae_check: null handle");
+    int flag = 0;
+    GTAV_CHECK_HIP(hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    GTAV_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, sizeof(int), (hipStream_t)stream));
+    return report_err_flag(flag, "VAE");
+}
+
 // ------------------------------------------------------------------------------------------------
 // elementwise entry points
 // ------------------------------------------------------------------------------------------------
+int gtav_clamp_frames(float* x, int32_t B, int32_t F, int32_t first, int32_t n, float lo, float hi, void* stream) {
+    GTAV_REQUIRE(x && B >= 1 && first >= 0 && first <= F && n >= 1, "clamp_frames: bad arguments");
+    if (first == F) return 0;
+    GTAV_REQUIRE((int64_t)F * n < (int64_t)1 << 31, "clamp_frames: sample of %d x %d floats too large", F, n);
+    return launch_clamp_cols(x, B, F * n, first * n, F * n, lo, hi, (hipStream_t)stream);
+}
 int gtav_ddim_update(const float* x, const float* v, float* out, int32_t rows, int32_t n, const float* alpha_t,
                      const float* alpha_next, int32_t is_final, void* stream) {
     GTAV_REQUIRE(x && v && out && alpha_t && (alpha_next || is_final), "ddim_update: null argument");
@@ -959,10 +999,10 @@ int gtav_op_skinny_f32(const float* x, int32_t ldx, const float* w, const float*
 }
 int gtav_op_ln_modulate(const float* x, void* out, int32_t M, int32_t D, const float* shift, const float* scale,
                         int32_t mod_stride, int32_t rows_per_mod, void* stream) {
-    return launch_ln_modulate((float*)x, D, (f16*)out, D, M, D, shift, scale, mod_stride, nullptr, rows_per_mod, nullptr, (hipStream_t)stream);
+    return launch_ln_modulate((float*)x, D, (f16*)out, D, M, D, shift, scale, mod_stride, nullptr, rows_per_mod, nullptr, nullptr, (hipStream_t)stream);
 }
 int gtav_op_ln_affine(const float* x, void* out, int32_t M, int32_t D, const float* gamma, const float* beta, void* stream) {
-    return launch_ln_affine((float*)x, D, (f16*)out, D, M, D, gamma, beta, nullptr, (hipStream_t)stream);
+    return launch_ln_affine((float*)x, D, (f16*)out, D, M, D, gamma, beta, nullptr, nullptr, (hipStream_t)stream);
 }
 int gtav_op_attn_spatial(const void* q, const void* k, const void* vt, void* o, int32_t NB, int32_t heads, int32_t S, void* stream) {
     return launch_attn_spatial((const f16*)q, (const f16*)k, (const f16*)vt, (f16*)o, NB, heads, S, (hipStream_t)stream);
@@ -984,14 +1024,16 @@ int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const floa
     memset(&pd, 0, sizeof(pd));
     pd.parts = parts; pd.nsplit = g.splitk; pd.slab_stride = (size_t)M * N; pd.ld = N; pd.bias = bias; pd.gate = gate;
     pd.gate_stride = gate_stride; pd.rows_per_gate = rows_per_gate;
-    return launch_ln_modulate(resid, N, (f16*)out_f16, N, M, N, shift, scale, mod_stride, nullptr, rows_per_gate, &pd, (hipStream_t)stream);
+    return launch_ln_modulate(resid, N, (f16*)out_f16, N, M, N, shift, scale, mod_stride, nullptr, rows_per_gate, &pd, nullptr, (hipStream_t)stream);
 }
 int gtav_op_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int32_t npos, void* stream) {
     return launch_rope_interleave(cos_t, sin_t, cs, npos, (hipStream_t)stream);
 }
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K) { return gemm_choose_splitk(M, N, K); }
 void gtav_op_gemm_set_stages(int32_t ns) { gemm_set_stages(ns); }
-void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }
+#ifdef GTAV_EXPERIMENTS
+void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }   // libgtav_amd_exp.so only (csrc/experiments.h)
+#endif
 void gtav_op_gemm_set_wm(int32_t wm) { gemm_set_wm(wm); }
 
 int gtav_op_convert_f16(const float* src, int32_t lds, int32_t R, int32_t C, void* dst, int32_t Rp, int32_t Cp, int32_t tiled,

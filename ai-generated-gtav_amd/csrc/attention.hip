@@ -283,29 +283,33 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 
 }  // namespace
 
-static bool g_attn_attr_set = false;
-// output as paired 16-byte write-through stores (common.h store_f16x4_paired); GTAV_ATTN_SC1=1 enables it
-static int g_attn_sc1 = getenv("GTAV_ATTN_SC1") ? atoi(getenv("GTAV_ATTN_SC1")) : 0;   // measured neutral at B = 1 (attention re-reads nothing, writes little)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: one "already raised" bit per device ordinal, so a
+// second model on another GPU of the same process (model.to("cuda:1")) gets its opt-in too
+static unsigned long long g_attn_attr_devs = 0;
+// output as paired 16-byte write-through stores (common.h store_f16x4_paired); experiments build: GTAV_ATTN_SC1=1 enables it
+static int g_attn_sc1 = GTAV_ENV_INT("GTAV_ATTN_SC1", 0);   // measured neutral at B = 1 (attention re-reads nothing, writes little)
 
 int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream) {
     GTAV_REQUIRE(S > 0 && S % 8 == 0, "attn_spatial: S=%d must be a positive multiple of 8", S);
     const int S_pad = round_up(S, 32);
     const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
     GTAV_REQUIRE(lds <= 160 * 1024, "attn_spatial: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
-    if (!g_attn_attr_set) {
+    int devid = 0;
+    GTAV_CHECK_HIP(hipGetDevice(&devid));
+    if (!(g_attn_attr_devs >> (devid & 63) & 1)) {
         GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attn_attr_set = true;
+        g_attn_attr_devs |= 1ull << (devid & 63);
     }
     const int nqt = cdiv(S, 16);
     // enough blocks to fill 256 CUs when there are few (frame, head) pairs; each block re-stages K/Vt from L2
     int qsplit = 1;
     const int max_split = cdiv(nqt, 4);
-    static const int blocks_target = getenv("GTAV_ATTN_S_BLOCKS") ? atoi(getenv("GTAV_ATTN_S_BLOCKS")) : 512;
+    static const int blocks_target = GTAV_ENV_INT("GTAV_ATTN_S_BLOCKS", 512);
     while (NB * heads * qsplit < blocks_target && qsplit < max_split) ++qsplit;
     // experiment (GTAV_ATTN_S_WIDE=1): with more than 4 query tiles per block nine waves walk them side by side (S = 144,
     // many frames: 9 tiles in one round instead of 4 + 4 + 1) — each wave is a serial QK^T -> softmax -> PV chain
-    static const int wide = getenv("GTAV_ATTN_S_WIDE") ? atoi(getenv("GTAV_ATTN_S_WIDE")) : 0;   // measured neutral at B = 8 (0.41 vs 0.42 ms per forward): off
+    static const int wide = GTAV_ENV_INT("GTAV_ATTN_S_WIDE", 0);   // measured neutral at B = 8 (0.41 vs 0.42 ms per forward): off
     dim3 grid(NB * heads, qsplit);
     if (wide && cdiv(nqt, qsplit) > 4)
         GTAV_LAUNCH(attn_spatial_kernel<9>, grid, dim3(576), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
@@ -319,7 +323,7 @@ int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int 
                          hipStream_t stream) {
     GTAV_REQUIRE(D % 256 == 0 && D <= 2048, "attn_temporal: D=%d must be a multiple of 256 and <= 2048", D);
     GTAV_REQUIRE(Tq > 0 && t0 >= 0 && t0 + Tq <= Tmax && Tmax <= 8, "attn_temporal: window t0=%d Tq=%d Tmax=%d (max 8)", t0, Tq, Tmax);
-    static const int split_max = getenv("GTAV_ATTN_T_SPLIT_MAX") ? atoi(getenv("GTAV_ATTN_T_SPLIT_MAX")) : 1024;
+    static const int split_max = GTAV_ENV_INT("GTAV_ATTN_T_SPLIT_MAX", 1024);
     const int split = (Tq > 1 && B * P < split_max) ? 1 : 0;   // few columns: one block per (column group, query frame)
     const int tpc = D / 8, cpb = tpc >= 256 ? 1 : 256 / tpc;  // threads per column, columns per block
     const dim3 grid(cdiv(B * P, cpb), split ? Tq : 1), block(tpc * cpb);

@@ -1,18 +1,31 @@
 #!/bin/bash
-# Builds libgtav_amd.so (gfx950) in-tree. Usage: csrc/build.sh [extra hipcc flags]
+# Builds the HIP library (gfx950) in-tree.
+#   csrc/build.sh [extra hipcc flags]       -> ../libgtav_amd.so       the product: no env knobs, no result-changing switches
+#   csrc/build.sh exp [extra hipcc flags]   -> ../libgtav_amd_exp.so   -DGTAV_EXPERIMENTS, for tools/ only
+# Objects go to a private mktemp directory and the .so is linked to a temporary name and renamed onto its final path, so
+# concurrent builds (several ranks, two checkouts) never link each other's objects and nobody dlopens a half-written file.
 set -e
 cd "$(dirname "$0")"
 OUT=../libgtav_amd.so
-mkdir -p /tmp/gtav_build
+DEFS=""
+if [ "$1" = "exp" ]; then
+  shift
+  OUT=../libgtav_amd_exp.so
+  DEFS="-DGTAV_EXPERIMENTS"
+fi
+BUILD=$(mktemp -d "${TMPDIR:-/tmp}/gtav_build.XXXXXX")
+trap 'rm -rf "$BUILD"' EXIT
 pids=()
 for f in gemm skinny elementwise attention api; do
   extra=""
   # attention: keep MFMA accumulators in VGPRs — the softmax works on them every key block, and the AGPR form costs 56
   # v_accvgpr moves per 16 MFMAs there (the GEMMs touch their accumulators only in the epilogue and keep the default)
   [ $f = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed $extra "$@" -c $f.hip -o /tmp/gtav_build/$f.o &
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed $DEFS $extra "$@" -c $f.hip -o "$BUILD/$f.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT /tmp/gtav_build/{gemm,skinny,elementwise,attention,api}.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$BUILD/lib.so" "$BUILD"/{gemm,skinny,elementwise,attention,api}.o
+mv -f "$BUILD/lib.so" "$OUT.tmp.$$"
+mv -f "$OUT.tmp.$$" "$OUT"
 echo "built $(realpath $OUT)"

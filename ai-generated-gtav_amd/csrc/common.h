@@ -52,6 +52,18 @@ const char* last_error();
         }                                                                                 \
     } while (0)
 
+// ---- experiment knobs ---------------------------------------------------------------------------
+// The shipped library (build.sh) reads NO environment variables and carries no result-changing switches.  A second
+// build with -DGTAV_EXPERIMENTS (build.sh exp -> libgtav_amd_exp.so, used by tools/ only) compiles in the timing
+// experiments: GEMM debug bits (skip fills / skip MFMA: WRONG results), forced shapes, LayerNorm / attention variants.
+#ifdef GTAV_EXPERIMENTS
+#define GTAV_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define GTAV_DBG(p, bits) ((p).debug & (bits))
+#else
+#define GTAV_ENV_INT(name, dflt) (dflt)
+#define GTAV_DBG(p, bits) false
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
@@ -65,6 +77,25 @@ static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 __host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
     return ((size_t)(r >> 7) * (size_t)(K >> 6) + (size_t)(k >> 6)) * 8192 + (size_t)((r & 127) * 64) +
            (size_t)(((((k >> 3) & 7) ^ (r & 7)) << 3) + (k & 7));
+}
+
+// ---- fp32 -> fp16 with saturation -------------------------------------------------------------
+// The reference runs this path under bf16 autocast (fp32 exponent range); our inter-kernel activations are fp16, so a
+// plain conversion would turn |x| > 65504 into inf and the next GEMM into NaN.  Every fp16 store of an activation goes
+// through sat4(): one v_med3_f32 per value clamps to +-65504 and a running |x| maximum (two v_max3_f32 per four values)
+// lets the kernel raise a device flag (bit 1 of the handle's error word, reported by gtav_dit_check / gtav_vae_check)
+// when anything was clamped: results stay finite and the caller learns that the fp16 range was exceeded.
+constexpr float F16_MAX = 65504.0f;
+constexpr int ERR_TIMESTEP = 1, ERR_F16_SAT = 2, ERR_NONFINITE = 4;
+__device__ __forceinline__ f16x4 sat4(float a, float b, float c, float d, float& amax) {
+    amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);
+    amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(c), __builtin_fabsf(d)), amax);
+    return f16x4{(f16)__builtin_amdgcn_fmed3f(a, -F16_MAX, F16_MAX), (f16)__builtin_amdgcn_fmed3f(b, -F16_MAX, F16_MAX),
+                 (f16)__builtin_amdgcn_fmed3f(c, -F16_MAX, F16_MAX), (f16)__builtin_amdgcn_fmed3f(d, -F16_MAX, F16_MAX)};
+}
+// NaN-safe: a NaN input compares false and is not reported here (it stays a NaN in the output)
+__device__ __forceinline__ void sat_report(float amax, int* err_flag) {
+    if (err_flag && amax > F16_MAX) atomicOr(err_flag, ERR_F16_SAT);
 }
 
 // ---- small device math ------------------------------------------------------------------

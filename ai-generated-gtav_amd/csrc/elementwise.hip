@@ -94,26 +94,26 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx,
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-6f);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         if (c < D) {
-            f16x4 o;
+            float yv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (v[i][e] - mean) * rstd;
-                float y;
                 if (MODE == 0) {
                     const float sc = av[i][e] + 1e-6f;
-                    y = xh * (1.0f + sc) + bv[i][e];
+                    yv[e] = xh * (1.0f + sc) + bv[i][e];
                 } else {
-                    y = xh * av[i][e] + bv[i][e];
+                    yv[e] = xh * av[i][e] + bv[i][e];
                 }
-                o[e] = (f16)y;
             }
-            store_f16x4_paired<1>(out + tiled_off(m, c, D), o, lane, pd.flags & 2);
+            store_f16x4_paired<1>(out + tiled_off(m, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
         }
     }
+    sat_report(amax, pd.err_flag);
 }
 
 // ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS: the default at every M.  With a few hundred rows
@@ -196,25 +196,24 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
     const float rstd = 1.0f / sqrtf(tq / (float)D + 1e-6f);
     if (!act) return;
     const float dd[4] = {d0, d1, d2, d3};
-    f16x4 o;
+    float yv[4], amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float xh = dd[e] * rstd;
-        float y;
         if (MODE == 0) {
             const float sc = av[e] + 1e-6f;
-            y = xh * (1.0f + sc) + bv[e];
+            yv[e] = xh * (1.0f + sc) + bv[e];
         } else {
-            y = xh * av[e] + bv[e];
+            yv[e] = xh * av[e] + bv[e];
         }
-        o[e] = (f16)y;
     }
-    store_f16x4_paired<1>(out + tiled_off(m, c, D), o, lane, pd.flags & 2);
+    store_f16x4_paired<1>(out + tiled_off(m, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
+    sat_report(amax, pd.err_flag);
 }
 
 // ------------------------------------------------------------------------------------------
 __global__ void patchify_kernel(const float* __restrict__ img, const int* __restrict__ frame_index, int NB, int C, int H,
-                                int W, int p, f16* __restrict__ out, int ldo, float a, float b) {
+                                int W, int p, f16* __restrict__ out, int ldo, float a, float b, int* err_flag) {
     const int gh = H / p, gw = W / p, Kp = C * p * p;
     const size_t total = (size_t)NB * gh * gw * ldo;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -226,6 +225,11 @@ __global__ void patchify_kernel(const float* __restrict__ img, const int* __rest
             const int x = (int)(m % gw), y = (int)((m / gw) % gh), nb = (int)(m / ((size_t)gw * gh));
             const int f = frame_index ? frame_index[nb] : nb;
             val = a * img[(((size_t)f * C + c) * H + (y * p + ph)) * W + (x * p + pw)] + b;
+            // the model's inputs are where a NaN / inf can enter the fp16 pipeline (inside it every store saturates)
+            if (!(__builtin_fabsf(val) <= F16_MAX)) {
+                if (err_flag) atomicOr(err_flag, val != val || __builtin_isinf(val) ? ERR_NONFINITE : ERR_F16_SAT);
+                if (val == val) val = __builtin_amdgcn_fmed3f(val, -F16_MAX, F16_MAX);
+            }
         }
         out[tiled_off((int)m, k, ldo)] = (f16)val;
     }
@@ -253,6 +257,7 @@ __global__ void convert_pad_f16_kernel(const float* __restrict__ src, int lds, i
         const size_t r = idx / Cp;
         float v = 0.f;
         if (r < (size_t)R && c < C) v = src[r * lds + c] * scale;
+        if (v == v) v = __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);   // weights / latents beyond the fp16 range saturate
         dst[tiled ? tiled_off((int)r, c, Cp) : idx] = (f16)v;
     }
 }
@@ -489,12 +494,12 @@ inline int grid_for(size_t total, int block = 256) {
 
 }  // namespace
 
-// experiments: GTAV_LN_FLAGS (see LnPending::flags)
-static int g_ln_flags = getenv("GTAV_LN_FLAGS") ? atoi(getenv("GTAV_LN_FLAGS")) : 3;   // default: all stores written through (B = 1: LN 0.57 -> 0.54 ms per forward)
+// -DGTAV_EXPERIMENTS builds: GTAV_LN_FLAGS (see LnPending::flags)
+static int g_ln_flags = GTAV_ENV_INT("GTAV_LN_FLAGS", 3);   // default: all stores written through (B = 1: LN 0.57 -> 0.54 ms per forward)
 
 // One block per row at every M since the write-through stores: B = 8 (M = 5760) LN 1.71 -> 1.43 ms per forward against the
 // wave-per-row kernel, M = 11 520 / 46 080 neutral.  GTAV_LN_ROWBLOCK_MAX restores a threshold for experiments.
-static int g_ln_rowblock_max = getenv("GTAV_LN_ROWBLOCK_MAX") ? atoi(getenv("GTAV_LN_ROWBLOCK_MAX")) : (1 << 30);
+static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
 
 #define LN_LAUNCH_(MODE, PEND, NV, P0, P1, STRIDE, ROWS, RPM) \
     hipLaunchKernelGGL((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)
@@ -504,6 +509,7 @@ static int g_ln_rowblock_max = getenv("GTAV_LN_ROWBLOCK_MAX") ? atoi(getenv("GTA
         memset(&pd_, 0, sizeof(pd_));                                                                     \
         if (pend) pd_ = *pend;                                                                            \
         pd_.flags = g_ln_flags;                                                                           \
+        pd_.err_flag = err_flag;                                                                          \
         const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
         if (M <= g_ln_rowblock_max) { /* small M: one block per row */                                                \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
@@ -523,7 +529,7 @@ static int g_ln_rowblock_max = getenv("GTAV_LN_ROWBLOCK_MAX") ? atoi(getenv("GTA
     } while (0)
 
 int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
-                       int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, hipStream_t stream) {
+                       int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && rows_per_mod > 0 && ldo == D, "ln_modulate: D=%d must be %%64, <= 2048, ldo == D", D);
     GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
                  "ln_modulate: bad pending update");
@@ -533,7 +539,7 @@ int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const
 }
 
 int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
-                     const LnPending* pend, hipStream_t stream) {
+                     const LnPending* pend, int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && ldo == D, "ln_affine: D=%d must be %%64, <= 2048, ldo == D", D);
     GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
                  "ln_affine: bad pending update");
@@ -545,11 +551,11 @@ int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const f
 #undef LN_LAUNCH_
 
 int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo,
-                    float a, float b, hipStream_t stream) {
+                    float a, float b, int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(H % p == 0 && W % p == 0 && ldo >= C * p * p, "patchify: bad geometry");
     const size_t total = (size_t)NB * (H / p) * (W / p) * ldo;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, stream, img, frame_index, NB, C, H, W, p, out,
-                       ldo, a, b);
+                       ldo, a, b, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -27,7 +27,8 @@ struct GemmParams {
     int ldx;       // unused (kept for ABI stability of the struct users): K is the logical row length
     const f16* W;  // tile-major [round_up(N,128)][K]
     int M, N, K;   // K % 64 == 0
-    int debug;     // experiments only: bit 0 = skip the LDS fills after the prologue, bit 1 = skip LDS reads + MFMA
+    int debug;     // -DGTAV_EXPERIMENTS builds only: bit 0 = skip the LDS fills after the prologue, bit 1 = skip LDS reads + MFMA
+    int* err_flag; // device error word of the owning handle (bit ERR_F16_SAT is raised when an fp16 output saturated); may be null
     int out_sc1;   // set by launch_gemm: 16-byte output stores bypass-and-drop in L2 (large outputs)
     int splitk;    // EPI_PARTIAL only: number of K slices (grid = tiles * splitk); (K / 64) % splitk == 0
     const float* bias;  // [N] or nullptr
@@ -59,8 +60,10 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int gemm_choose_splitk(int M, int N, int K);
 // Pipeline depth override for experiments (0 = heuristic, else 2 or 4 LDS stages).
 void gemm_set_stages(int ns);
-void gemm_set_debug(int bits);
-// Block shape override for experiments (0 = heuristic, 2 = 128 x 128 / 4 waves, 4 = 128 x 256 / 8 waves).
+// Block shape override (0 = heuristic; shape numbers in gemm.hip launch_epi).  Every shape computes the same result.
 void gemm_set_wm(int wm);
+#ifdef GTAV_EXPERIMENTS
+void gemm_set_debug(int bits);   // timing experiments, WRONG results
+#endif
 
 }  // namespace gtav

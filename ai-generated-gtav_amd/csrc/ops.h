@@ -46,23 +46,24 @@ struct LnPending {
     const int* gate_rows;
     int rows_per_gate;
     int flags;   // set by the launcher: bit 0 = residual write-back as sc1 stores, bit 1 = fp16 output as paired 16-byte sc1 stores
+    int* err_flag;   // device error word (common.h ERR_F16_SAT is raised when the fp16 output saturated); may be null
 };
 
 // LayerNorm outputs are GEMM A-operands: fp16 TILE-MAJOR with logical row length D (buffer rows padded to 128).
 // LayerNorm(eps=1e-6, no affine) + adaLN modulate -> fp16  (model/dit.py:19-27,163-181)
 //   out[m] = LN(x[m]) * (1 + (scale[row] + 1e-6)) + shift[row],  row = rows ? rows[m / rows_per_mod] : m / rows_per_mod
 int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
-                       int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, hipStream_t stream);
+                       int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, int* err_flag, hipStream_t stream);
 // LayerNorm(eps=1e-6) with affine weight/bias -> fp16   (model/vae.py:139,146,174)
 int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
-                     const LnPending* pend, hipStream_t stream);
+                     const LnPending* pend, int* err_flag, hipStream_t stream);
 
 // Non-overlapping patch gather (im2col of a k = s = p conv):  img (NB, C, H, W) f32 -> A fp16 TILE-MAJOR, logical [M][ldo],
 // token m = (nb, gh, gw), column k = (c, ph, pw); value = a * img + b.  Columns [C p p, ldo) are zeroed.
 // `frame_index` (optional, length NB) picks frame f = frame_index[nb] out of the source buffer (frame stride =
 // C*H*W floats), which is how the sampler reads its sliding window in place.
 int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo,
-                    float a, float b, hipStream_t stream);
+                    float a, float b, int* err_flag, hipStream_t stream);
 // Inverse scatter of the projection output.  order 0: features (ph, pw, c) (DiT, model/dit.py:328-341);
 // order 1: features (c, ph, pw) (VAE, model/vae.py:279-304).  out (NB, C, H, W) f32 = a * y + b.
 int launch_unpatchify(const float* y, int ldy, float* img, int NB, int C, int H, int W, int p, int order, float a,

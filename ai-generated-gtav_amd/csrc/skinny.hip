@@ -66,11 +66,13 @@ __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict
 }  // namespace
 
 int skinny_init() {
-    static bool done = false;
-    if (done) return 0;
+    static unsigned long long done_devs = 0;   // the attribute is per device (see attention.hip)
+    int devid = 0;
+    GTAV_CHECK_HIP(hipGetDevice(&devid));
+    if (done_devs >> (devid & 63) & 1) return 0;
     GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
+    done_devs |= 1ull << (devid & 63);
     return 0;
 }
 

@@ -62,8 +62,12 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
     dev = model.device
     B, n_prompt = x_prompt.shape[:2]
     x = torch.empty((B, total_frames, *x_prompt.shape[2:]), device=dev, dtype=torch.float32)
-    x[:, :n_prompt] = x_prompt.to(dev, torch.float32)
-    x[:, n_prompt:] = noise_chunks.to(dev, torch.float32).clamp(-noise_abs_max, noise_abs_max)
+    x[:, :n_prompt] = x_prompt.to(dev, torch.float32)                          # copies only: torch is storage here
+    x[:, n_prompt:] = noise_chunks.to(dev, torch.float32)
+    fsz = x[0, 0].numel()
+    with torch.cuda.device(dev):                                               # generate.py:201-202 clamp, as a HIP kernel
+        _lib.check(_lib.load().gtav_clamp_frames(x.data_ptr(), B, total_frames, n_prompt, fsz, -float(noise_abs_max),
+                                                 float(noise_abs_max), _lib.current_stream()))
     act = actions.to(dev, torch.float32).contiguous() if actions is not None else None
     model.set_schedule(_alphas_cumprod(clamp_min))
     noise_range = torch.linspace(0, 999, noise_steps + 1)                      # generate.py:194 (float)
@@ -79,6 +83,41 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
                                 noise_idx <= 0, act, cached=cached, cond_step=step if hoist_cond else -1)
     model.check()
     return x
+
+
+def sample_inputs(gid: int, n_prompt: int, total_frames: int, frame_hw, latent_hw, latent_ch: int = 16, seed: int = 1000):
+    """Synthetic inputs of ONE sequence, a function of its GLOBAL sample id only (SURVEY.md §8(d),(e)): prompt frames
+    U[0,1) (n_prompt, 3, H, W) and the standard-normal initial noise of every generated frame (total - n_prompt, C, h, w),
+    drawn from a CPU generator seeded with seed + gid — never device RNG, so CPU-oracle and GPU runs, and any sharding
+    of the batch over ranks, see identical draws."""
+    g = torch.Generator().manual_seed(int(seed) + int(gid))
+    frames = torch.rand(n_prompt, 3, *frame_hw, generator=g)
+    noise = torch.randn(total_frames - n_prompt, latent_ch, *latent_hw, generator=g)
+    return frames, noise
+
+
+def shard_inputs(global_batch: int, rank: int, world: int, n_prompt: int, total_frames: int, frame_hw, latent_hw,
+                 latent_ch: int = 16, seed: int = 1000):
+    """Inputs of rank `rank`'s contiguous shard of a global batch (one process per GPU): returns
+    (global_ids, frames (b, n_prompt, 3, H, W), noise (b, total - n_prompt, C, h, w)) on the CPU.  Concatenating the
+    shards of all ranks in rank order gives exactly the world-size-1 batch (tests/test_host_cpu.py proves it under gloo)."""
+    lo, hi = shard_batch(global_batch, rank, world)
+    ins = [sample_inputs(g, n_prompt, total_frames, frame_hw, latent_hw, latent_ch, seed) for g in range(lo, hi)]
+    return list(range(lo, hi)), torch.stack([f for f, _ in ins]), torch.stack([n for _, n in ins])
+
+
+def generate_clip(dit, vae, frames: torch.Tensor, noise: torch.Tensor, total_frames: int, noise_steps: int,
+                  actions: Optional[torch.Tensor] = None, ctx_cache: bool = False, to_uint8: bool = True, gather: bool = True):
+    """One rank's whole clip (reference generate.py:main for its shard of the batch): VAE-encode the prompt frames,
+    run the denoising loop, all-gather the final latents over the ranks (the path's only collective, RCCL over xGMI
+    under the nccl backend) and decode this rank's own frames.  Returns (gathered latents, decoded local frames)."""
+    n_prompt = frames.shape[1]
+    x0 = vae_encode(frames.to(vae.device), vae, n_prompt)
+    x = generate_latents(dit, x0, total_frames, noise_steps, noise, actions, ctx_cache=ctx_cache)
+    xg = all_gather_latents(x) if gather else x
+    out = vae_decode_frames(x, vae, to_uint8=to_uint8)
+    vae.check()
+    return xg, out
 
 
 def shard_batch(B: int, rank: int, world: int):

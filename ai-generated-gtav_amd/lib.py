@@ -67,6 +67,8 @@ SIGNATURES = {
     "gtav_vae_get_weight": [_p, C.c_char_p, _p, _l, _p],
     "gtav_vae_encode": [_p, _p, _f, _f, _p, _i, _p],
     "gtav_vae_decode": [_p, _p, _f, _p, _f, _f, _i, _p],
+    "gtav_vae_check": [_p, _p],
+    "gtav_clamp_frames": [_p, _i, _i, _i, _i, _f, _f, _p],
     "gtav_ddim_update": [_p, _p, _p, _i, _i, _p, _p, _i, _p],
     "gtav_add_noise": [_p, _p, _p, _p, _i, _i, _f, _p],
     "gtav_vtarget": [_p, _p, _p, _p, _i, _i, _f, _p],
@@ -86,11 +88,10 @@ SIGNATURES = {
     "gtav_op_gemm_splitk_ln": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],
     "gtav_op_gemm_set_stages": [_i],
-    "gtav_op_gemm_set_debug": [_i],
     "gtav_op_gemm_set_wm": [_i],
 }
 _RESTYPES = {"gtav_last_error": C.c_char_p, "gtav_dit_destroy": None, "gtav_vae_destroy": None, "gtav_op_gemm_set_stages": None,
-             "gtav_op_gemm_set_debug": None, "gtav_op_gemm_set_wm": None}
+             "gtav_op_gemm_set_wm": None}
 
 _lib = None
 
@@ -108,6 +109,32 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+EXP_LIB_PATH = os.path.join(_HERE, "libgtav_amd_exp.so")
+
+
+def load_experiments(build_if_missing: bool = True) -> C.CDLL:
+    """tools/ only: the -DGTAV_EXPERIMENTS build (csrc/build.sh exp), which adds gtav_op_gemm_set_debug (timing runs with
+    skipped fills / MFMAs: WRONG results) and reads the GTAV_* environment knobs.  It becomes the library every gtav_amd
+    class of this process uses, so one process never mixes the two builds.  Never imported by the product or the tests."""
+    global _lib
+    if _lib is not None and getattr(_lib, "_gtav_experiments", False):
+        return _lib
+    if _lib is not None:
+        raise GtavError("load_experiments() must be called before anything loaded the product library")
+    if build_if_missing and not os.path.exists(EXP_LIB_PATH):
+        subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh"), "exp"], check=True)
+    lib = C.CDLL(EXP_LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    lib.gtav_op_gemm_set_debug.argtypes = [_i]
+    lib.gtav_op_gemm_set_debug.restype = None
+    lib._gtav_experiments = True
     _lib = lib
     return lib
 

@@ -235,6 +235,13 @@ class DiT(_HipModule):
             if self._schedule is not None:
                 self.set_schedule(self._schedule)
 
+    def reserve(self, max_batch: int, max_frames: Optional[int] = None, noise_steps: int = 0):
+        """Sizes the handle's HBM workspace once for the largest batch / window / per-frame conditioning table a run will use
+        (noise_steps + 1 row sets per generated frame), so that no later call has to rebuild the handle (which re-uploads the
+        weights and drops the captured hipGraphs)."""
+        T = max_frames or self._capacity_t
+        self._ensure(max_batch, T, cond_rows=max_batch * (T - 1 + noise_steps + 1) if noise_steps else 0)
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, external_cond: Optional[torch.Tensor] = None) -> torch.Tensor:
         """model/dit.py:343-376.  x (B,T,C,H,W), t (B,T) integer timesteps, external_cond (B,T,25) or None."""
         B, T, Cc, H, W = x.shape

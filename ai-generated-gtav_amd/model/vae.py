@@ -145,6 +145,12 @@ class AutoencoderKL(_HipModule):
                                              out_shift, n, _lib.current_stream()))
         return out
 
+    def check(self):
+        """Raises if an input held NaN/inf or an fp16 activation saturated since the last call (gtav_vae_check; synchronises)."""
+        if self._handle:
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().gtav_vae_check(self._handle, _lib.current_stream()))
+
     def autoencode(self, input, sample_posterior=True):
         """model/vae.py:340-347."""
         posterior = self.encode(input)

@@ -1,30 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: generated frames/s for a 32-frame clip with 100 noise steps (BASELINE.json metric).
 
-One "step" = one complete clip generation per GPU: VAE-encode 4 prompt frames, 28 generated frames x 101
-denoise steps through the DiT, all-gather of the latents across ranks (RCCL over xGMI when N > 1) and
-VAE-decode of the 32 frames.  N = 1 runs BASELINE configs[1] (DiT without actions, batch 1); for N > 1 each
-rank generates its own `--batch-per-gpu` samples (weak scaling, no data-path collective besides the final
-all-gather).  Inputs are synthetic, generated on the CPU from fixed seeds and resident in HBM before the
-timed region; weights are the repo's deterministic synthetic weights (no checkpoints exist offline).
+One "step" = one complete clip generation per GPU (gtav_amd.generate.generate_clip): VAE-encode 4 prompt frames, 28 generated
+frames x 101 denoise steps through the DiT, all-gather of the latents across ranks (RCCL over xGMI when N > 1) and VAE-decode of
+the 32 frames.  The headline line is BASELINE configs[1] (DiT without actions, batch 1 per GPU) at every N — weak scaling, the
+per-GPU work is the same at N = 1, 2, 4, 8, no data-path collective besides the final all-gather.  A second, bounded leg runs the
+batched configuration the north-star's roofline target refers to: batch 8 per GPU with action conditioning (`config2` at N = 1 =
+BASELINE configs[2]; `config3` at N > 1 = 8 N sequences sharded 8 per GPU, which is BASELINE configs[3] at N = 8).
+Inputs are synthetic, a function of the GLOBAL sample id (gtav_amd.generate.shard_inputs), generated on the CPU from fixed seeds
+and resident in HBM before the timed region; weights are the repo's deterministic synthetic weights (no checkpoints offline).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (fc1 GEMM with the GELU epilogue, csrc/gemm.hip), timed in situ with HIP events on the
-                 launch stream during real forwards (gtav_dit_profile; the events are attached to the kernel's own dispatch,
-                 hipExtLaunchKernel), algorithmic FLOPs per launch / mean duration
-  cpu_baseline — the CPU oracle (oracle/ref_cpu.py, fp32 torch CPU kernels — the reference's own CPU path) on the
-                 host cores, a bounded sample extrapolated to the clip (rank 0, N = 1 only)
+Launching: `python bench.py --gpus N` with WORLD_SIZE unset starts N rank processes itself (one per GPU, env rendezvous on
+127.0.0.1) BEFORE anything touches the GPU in this process, waits for them and exits with their status; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     — the dominant kernel (fc1 GEMM with the GELU epilogue, csrc/gemm.hip), timed in situ with HIP events attached to
+                 the kernel's own dispatch (hipExtLaunchKernel) during real forwards; algorithmic FLOPs per launch / mean duration
+  cpu_baseline — the CPU oracle (oracle/ref_cpu.py, fp32 torch CPU kernels — the reference's own CPU path) on the host cores, a
+                 bounded sample extrapolated to the clip (rank 0, N = 1 only)
+  config2/3    — the batch-8 action-conditioned leg: frames/s (window + context-cached), forward time, fc1 in situ, per-class ms
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 P_TOK, D_MODEL, DEPTH, HM = 144, 1024, 16, 4096
 # SURVEY.md §8(d) geometry presets.  native: the only geometry the reference's factories support (360x640 frames, VAE patch 20 ->
@@ -40,7 +47,6 @@ GEOM = {
                           dec_dim=1024, dec_depth=12, dec_heads=16)),
 }
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
-HBM_PEAK_GBS = 8000.0
 
 
 def dit_forward_flops(tokens, frames_q, frames_k_sum, B):
@@ -76,7 +82,74 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def bench_train(args, world, rank, dev, dist):
+# ------------------------------------------------------------------------------------------------------------------------
+# launcher: one process per GPU, started before this process touches the GPU
+# ------------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv, timeout=None):
+    """Starts n copies of this script as ranks 0..n-1 (env:// rendezvous on 127.0.0.1) and waits for them.  Nothing in this
+    process has initialised HIP (no torch.cuda call, torch is not even imported yet), so no exec-after-GPU-init hazard.
+    Returns the first non-zero exit status of a rank (the others are then terminated by PID), else 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    t0 = time.time()
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                if r != 0:
+                    rc = r
+        if timeout is not None and time.time() - t0 > timeout:
+            rc = 124
+        time.sleep(0.05)
+    for p in live:                       # a rank failed: stop the ranks WE started (exact PIDs), never by pattern
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--total-frames", type=int, default=32)
+    ap.add_argument("--noise-steps", type=int, default=100)
+    ap.add_argument("--n-prompt", type=int, default=4)
+    ap.add_argument("--use-actions", action="store_true", help="action-conditioned DiT for the headline leg")
+    ap.add_argument("--algo", choices=["window", "cached", "both"], default="both",
+                    help="window = recompute the whole window every noise step (reference behaviour, headline value); "
+                         "cached = exact context-K/V-cached variant; both = time both (value = window)")
+    ap.add_argument("--geometry", choices=["native", "g256"], default="native",
+                    help="native = 360x640 frames (the reference's factories; headline); g256 = 256x256 frames, SURVEY.md 8(d) preset")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip VAE encode/decode (DiT loop only; not the headline)")
+    ap.add_argument("--batched-clips", type=int, default=2,
+                    help="timed clips per algorithm of the bounded batch-8 + actions leg (config2 / config3); 0 disables it")
+    ap.add_argument("--batched-batch", type=int, default=8)
+    ap.add_argument("--mode", choices=["generate", "train"], default="generate",
+                    help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
+                         "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# rank body
+# ------------------------------------------------------------------------------------------------------------------------
+def bench_train(args, world, rank, dev, dist, torch):
     """configs[4]: forward + loss of train_dit.py `_shared_step` (configs/train_dit_actions.yaml: batch 16 per GPU, 4 prompt
     frames + 1 target, ddim_noise_steps 50, ctx_max_noise_idx 40, clamp_min 1e-6) on synthetic 360x640 clips.  A step = one
     batch per GPU: VAE-encode 80 frames -> noise -> one DiT forward (B, T=5) -> v-target MSE; the scalar loss is all-reduced."""
@@ -132,108 +205,108 @@ def bench_train(args, world, rank, dev, dist):
             "config": {"workload": "BASELINE configs[4]: train_dit.py forward+loss, batch %d per GPU, DiT-S/2 + VAE encode of %d frames" % (B, 5 * B),
                        "global_batch": world * B, "parallelism": "data-parallel x%d (forward only; loss all-reduce)" % world},
             "achieved_tflops_per_gpu": round(flops * args.steps / el / 1e12, 1)}))
-    if world > 1:
-        dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
-    ap.add_argument("--total-frames", type=int, default=32)
-    ap.add_argument("--noise-steps", type=int, default=100)
-    ap.add_argument("--n-prompt", type=int, default=4)
-    ap.add_argument("--use-actions", action="store_true", help="BASELINE configs[2]: action-conditioned DiT")
-    ap.add_argument("--algo", choices=["window", "cached", "both"], default="both",
-                    help="window = recompute the whole window every noise step (reference behaviour, headline value); "
-                         "cached = exact context-K/V-cached variant; both = time both (value = window)")
-    ap.add_argument("--geometry", choices=["native", "g256"], default="native",
-                    help="native = 360x640 frames (the reference's factories; headline); g256 = 256x256 frames, SURVEY.md 8(d) preset")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-vae", action="store_true", help="skip VAE encode/decode (DiT loop only; not the headline)")
-    ap.add_argument("--mode", choices=["generate", "train"], default="generate",
-                    help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
-                         "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline)")
-    args = ap.parse_args()
-
+def rank_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if have < world or not torch.cuda.is_available():
+        sys.stderr.write(f"bench.py rank {rank}/{world}: needs {world} GPUs, this host has {have}; there is no CPU fallback for the product path\n")
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus
+    try:
+        if args.mode == "train":
+            bench_train(args, world, rank, dev, dist, torch)
+        else:
+            bench_generate(args, world, rank, dev, dist, torch)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
-    import gtav_amd.weights as W
-    from gtav_amd.generate import all_gather_latents, generate_latents, vae_decode_frames, vae_encode
-    from gtav_amd.model.dit import DiT_models
-    from gtav_amd.model.vae import VAE_models
 
-    if args.mode == "train":
-        return bench_train(args, world, rank, dev, dist)
-    B = args.batch_per_gpu
-    total, n_prompt, steps = args.total_frames, args.n_prompt, args.noise_steps
-    # ---- models with deterministic synthetic weights (every matrix non-zero, incl. adaLN) ----
+def traffic_for(M):
+    """HBM bytes per fc1 launch from the committed rocprofv3 --pmc passes (profiles/traffic.json, written by tools/gemm_traffic.sh
+    from the torch-free driver tools/gemm_pmc).  The file records the sha of csrc/gemm.hip it was measured on: a different kernel
+    source means the number is stale and `traffic` is reported as null instead."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/traffic.json missing"
+    tj = json.load(open(tpath))
+    sha = hashlib.sha256(open(os.path.join(ROOT, "ai-generated-gtav_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
+    if tj.get("gemm_hip_sha16") != sha:
+        return None, "profiles/traffic.json was measured on another build of csrc/gemm.hip (stale)"
+    ent = tj.get("fc1_M%d" % M)
+    return (ent or {}).get("hbm_bytes_per_launch"), tj.get("source", "")
+
+
+def bench_generate(args, world, rank, dev, dist, torch):
     global P_TOK
+    import gtav_amd.weights as W
+    from gtav_amd.generate import generate_clip, shard_inputs
+    from gtav_amd.model.dit import DiT, DiT_models
+    from gtav_amd.model.vae import AutoencoderKL, VAE_models
+
+    B = args.batch_per_gpu
+    Bb = args.batched_batch if (args.batched_clips > 0 and args.geometry == "native") else 0   # batch of the config2 / config3 leg
+    total, n_prompt, steps = args.total_frames, args.n_prompt, args.noise_steps
     geo = GEOM[args.geometry]
     (FH, FW), (LH, LW) = geo["frame"], geo["lat"]
     P_TOK = (LH // 2) * (LW // 2)
+    # ---- models with deterministic synthetic weights (every matrix non-zero, incl. adaLN) ----
+    Bmax = max(B, Bb)
     if args.geometry == "native":
-        dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+        dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=Bmax)
         dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
     else:
-        from gtav_amd.model.dit import DiT
-        dit = DiT(**geo["dit"], init_weights=False, max_batch=B)
+        dit = DiT(**geo["dit"], init_weights=False, max_batch=Bmax)
         dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(**geo["dit"]), seed=0))
+    dit.reserve(Bmax, 5, steps)      # one workspace for both legs: nothing is rebuilt inside a timed region
     vae = None
     if not args.no_vae:
-        nfc = min(32, max(4, B * 4))
+        nfc = min(32, max(4, Bmax * 4))
         if args.geometry == "native":
             vae = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=nfc)
             vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
         else:
-            from gtav_amd.model.vae import AutoencoderKL
             vae = AutoencoderKL(**geo["vae"], init_weights=False, max_frames_per_call=nfc)
             vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(**geo["vae"]), seed=1))
 
-    # ---- synthetic inputs, indexed by GLOBAL sample id so results do not depend on the sharding ----
-    def sample_inputs(gid):
-        g = torch.Generator().manual_seed(1000 + gid)
-        frames = torch.rand(n_prompt, 3, FH, FW, generator=g)
-        noise = torch.randn(total - n_prompt, 16, LH, LW, generator=g)
-        return frames, noise
+    def leg_inputs(b, use_actions, seed):
+        # synthetic inputs are a function of the GLOBAL sample id: any sharding of the batch sees the same sequences
+        _, frames, noise = shard_inputs(world * b, rank, world, n_prompt, total, (FH, FW), (LH, LW), seed=seed)
+        actions = None
+        if use_actions:
+            actions = torch.zeros(b, total, 25, device=dev)
+            actions[:, :, 3] = 1  # "W" for every frame (generate.py:159,181)
+        return frames.to(dev), noise.to(dev), actions
 
-    gids = [rank * B + b for b in range(B)]
-    ins = [sample_inputs(g) for g in gids]
-    frames = torch.stack([f for f, _ in ins]).to(dev)
-    noise = torch.stack([n for _, n in ins]).to(dev)
-    actions = None
-    if args.use_actions:
-        actions = torch.zeros(B, total, 25, device=dev)
-        actions[:, :, 3] = 1  # "W" for every frame (generate.py:159,181)
-    lat_fallback = torch.randn(B, n_prompt, 16, LH, LW, generator=torch.Generator().manual_seed(7)).to(dev) * 0.5
+    def one_clip(inp, cached, nsteps):
+        frames, noise, actions = inp
+        if vae is None:
+            from gtav_amd.generate import all_gather_latents, generate_latents
+            lat = torch.randn(frames.shape[0], n_prompt, 16, LH, LW, generator=torch.Generator().manual_seed(7)).to(dev) * 0.5
+            return all_gather_latents(generate_latents(dit, lat, total, nsteps, noise, actions, ctx_cache=cached)), None
+        return generate_clip(dit, vae, frames, noise, total, nsteps, actions, ctx_cache=cached)
 
-    def one_clip(cached):
-        x0 = vae_encode(frames, vae, n_prompt) if vae is not None else lat_fallback
-        x = generate_latents(dit, x0, total, steps, noise, actions, ctx_cache=cached)
-        xg = all_gather_latents(x)
-        out = vae_decode_frames(x, vae) if vae is not None else x
-        return xg, out
-
-    def timed(cached, nsteps, nwarm):
+    def timed(inp, cached, nclips, nwarm, short_warm=False):
         for _ in range(nwarm):
-            one_clip(cached)
+            one_clip(inp, cached, 2 if short_warm else steps)   # short warm-up: same shapes / graph keys, 3 forwards per frame
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(nsteps):
-            one_clip(cached)
+        for _ in range(nclips):
+            one_clip(inp, cached, steps)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -244,63 +317,90 @@ def main():
             el = t.item()
         return el
 
-    results = {}
+    def profile_forward(b, actions):
+        """in-situ per-class kernel times over real forwards of (b, T = 5): dispatch-attached HIP events (gtav_dit_profile)"""
+        g = torch.Generator().manual_seed(3)
+        xw = torch.randn(b, 5, 16, LH, LW, generator=g).to(dev)
+        tw = torch.tensor([[15, 15, 15, 15, 500]] * b)
+        aw = actions[:, :5].contiguous() if actions is not None else None
+        for _ in range(2):
+            dit(xw, tw, aw)
+        torch.cuda.synchronize()
+        dit.profile(True)
+        nprof = 6
+        for _ in range(nprof):
+            dit(xw, tw, aw)
+        torch.cuda.synchronize()
+        prof = dit.profile_read()
+        dit.profile(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nfw = 10
+        for _ in range(nfw):
+            dit(xw, tw, aw)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t0) / nfw * 1e3
+        M = b * 5 * P_TOK
+        flops_fc1 = 2.0 * M * HM * D_MODEL
+        ev_ms, ev_n = prof.pop("empty_event_pair")
+        ms_fc1, n_fc1 = prof["gemm_fc1"]
+        avg_fc1_ms = ms_fc1 / max(n_fc1, 1)
+        ach = flops_fc1 / (avg_fc1_ms * 1e-3) / 1e12
+        traffic, tsrc = traffic_for(M)
+        roofline = {"kernel": "fc1 GEMM + GELU-tanh epilogue (csrc/gemm.hip, M=%d N=4096 K=1024, fp16 MFMA)" % M, "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(avg_fc1_ms * 1e3, 2), "launches_timed": int(n_fc1),
+                    "flops_per_launch": flops_fc1, "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
+                    "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2)}
+        classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
+        # per GEMM class: achieved TFLOP/s from its algorithmic FLOPs (2 M N K per launch)
+        gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": flops_fc1,
+                 "gemm_fc2": flops_fc1}
+        for k, fl in gflop.items():
+            ms, n = prof[k]
+            if n:
+                classes[k]["us_per_launch"] = round(ms / n * 1e3, 2)
+                classes[k]["tflops"] = round(fl / (ms / n * 1e-3) / 1e12, 1)
+        fwd_flops = dit_forward_flops(M, b * 5, 15, b)
+        step_tflops = fwd_flops / (fwd_ms * 1e-3) / 1e12
+        dit_step = {"forward_ms_B%d_T5" % b: round(fwd_ms, 3), "executed_tflop_per_forward": round(fwd_flops / 1e12, 4),
+                    "achieved_tflops": round(step_tflops, 1), "frac_of_mfma_peak": round(step_tflops / MFMA_PEAK_TFLOPS, 4),
+                    "kernel_classes": classes}
+        return roofline, dit_step, (xw, tw)
+
+    def algo_report(b, results, nclips):
+        out = {}
+        for algo, e in results.items():
+            fl = clip_flops(b, n_prompt, total, steps, 5, algo == "cached") * world
+            out["algo_" + algo] = {"generated_frames_per_s": round(world * b * (total - n_prompt) * nclips / e, 4),
+                                   "ms_per_clip": round(e / nclips * 1e3, 1), "executed_pflop_per_clip": round(fl / 1e15, 4),
+                                   "achieved_tflops_per_gpu": round(fl / world * nclips / e / 1e12, 1)}
+        return out
+
+    # ---- headline leg: batch B per GPU (configs[1] by default) ----
+    inp = leg_inputs(B, args.use_actions, seed=1000)
     algos = ["window", "cached"] if args.algo == "both" else [args.algo]
-    for algo in algos:
-        el = timed(algo == "cached", args.steps, args.warmup)
-        results[algo] = el
+    results = {algo: timed(inp, algo == "cached", args.steps, args.warmup) for algo in algos}
     head = "window" if "window" in results else algos[0]
     el = results[head]
     gen_frames = world * B * (total - n_prompt)
     value = gen_frames * args.steps / el
+    roofline, dit_step, (xw, tw) = profile_forward(B, inp[2])
 
-    # ---- roofline: in-situ HIP-event timing of every kernel class over real forwards ----
-    roofline, classes = None, None
-    g = torch.Generator().manual_seed(3)
-    xw = torch.randn(B, 5, 16, LH, LW, generator=g).to(dev)
-    tw = torch.tensor([[15, 15, 15, 15, 500]] * B)
-    aw = actions[:, :5].contiguous() if actions is not None else None
-    for _ in range(2):
-        dit(xw, tw, aw)
-    torch.cuda.synchronize()
-    dit.profile(True)
-    nprof = 6
-    t0 = time.perf_counter()
-    for _ in range(nprof):
-        dit(xw, tw, aw)
-    torch.cuda.synchronize()
-    prof = dit.profile_read()
-    dit.profile(False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nfw = 10
-    for _ in range(nfw):
-        dit(xw, tw, aw)
-    torch.cuda.synchronize()
-    fwd_ms = (time.perf_counter() - t0) / nfw * 1e3
-    M = B * 5 * P_TOK
-    flops_fc1 = 2.0 * M * HM * D_MODEL
-    ev_ms, ev_n = prof.pop("empty_event_pair")
-    ev_over_ms = ev_ms / max(ev_n, 1)                  # cost of one HIP-event pair around nothing
-    ms_fc1, n_fc1 = prof["gemm_fc1"]
-    # single-kernel classes (GEMMs, LayerNorm, attention) are timed with start/stop events attached to the kernel's own dispatch
-    # packet (hipExtLaunchKernel), i.e. the kernel's begin-to-end time as rocprofv3 reports it; only `other` (multi-kernel) uses
-    # event pairs around the launches, which carry ~2 us of marker overhead each (the empty-pair time is reported for reference)
-    avg_fc1_ms = ms_fc1 / max(n_fc1, 1)
-    ach = flops_fc1 / (avg_fc1_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per fc1 launch from rocprofv3 --pmc passes (profiles/README.md)
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        traffic = tj.get("fc1_M%d" % M, {}).get("hbm_bytes_per_launch")
-    roofline = {"kernel": "fc1 GEMM + GELU-tanh epilogue (csrc/gemm.hip, M=%d N=4096 K=1024, fp16 MFMA)" % M, "bound": "mfma",
-                "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "avg_launch_us": round(avg_fc1_ms * 1e3, 2), "launches_timed": int(n_fc1),
-                "flops_per_launch": flops_fc1, "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
-                "empty_event_pair_us": round(ev_over_ms * 1e3, 2)}
-    classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
-    fwd_flops = dit_forward_flops(M, B * 5, 15, B)
-    step_tflops = fwd_flops / (fwd_ms * 1e-3) / 1e12
+    # ---- batched leg: batch 8 per GPU, action-conditioned (configs[2] at N = 1, configs[3]-shaped at N > 1), bounded ----
+    batched = None
+    if Bb > 0 and Bb != B:
+        binp = leg_inputs(Bb, True, seed=5000)
+        bres = {algo: timed(binp, algo == "cached", args.batched_clips, 1, short_warm=True) for algo in algos}
+        broof, bstep, _ = profile_forward(Bb, binp[2])
+        bel = bres["window" if "window" in bres else algos[0]]
+        batched = {"workload": "BASELINE configs[%d]: batch %d per GPU x %d GPU(s) = %d sequences, action-conditioned, %d frames (%d prompt), "
+                               "%d noise steps, VAE inside the timed region" % (2 if world == 1 else 3, Bb, world, world * Bb, total, n_prompt, steps),
+                   "clips_timed": args.batched_clips, "warmup": "1 clip with 2 noise steps (same shapes and hipGraph keys)",
+                   "value": round(world * Bb * (total - n_prompt) * args.batched_clips / bel, 4), "unit": "generated frames/s",
+                   "roofline": broof, "dit_step": bstep}
+        batched.update(algo_report(Bb, bres, args.batched_clips))
+        del binp
 
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1) ----
     cpu = None
@@ -325,7 +425,7 @@ def main():
             t_enc = t_dec = 0.0
             if vae is not None:
                 vsd, vcfg = vae.state_dict(), (O.vit_l_20_shallow_encoder() if args.geometry == "native" else O.VAEConfig(**geo["vae"]))
-                img = frames[0, :2].cpu() * 2 - 1
+                img = inp[0][0, :2].cpu() * 2 - 1
                 t0 = time.perf_counter()
                 O.vae_encode_moments(vsd, vcfg, img)
                 t_enc = (time.perf_counter() - t0) / 2
@@ -346,27 +446,28 @@ def main():
             "metric": "generated frames/sec (32-frame clip, 100 noise steps)", "value": round(value, 4), "unit": "generated frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 (fp32 accumulate/residual)",
-            "data": "synthetic (seeded CPU-generated prompt frames + noise, hash-seeded random weights incl. adaLN)",
+            "data": "synthetic (seeded CPU-generated prompt frames + noise by global sample id, hash-seeded random weights incl. adaLN)",
             "config": {"workload": "BASELINE configs[%d]: %s, %d frames (%d prompt), %d noise steps, batch %d per GPU%s" %
                                    (2 if args.use_actions else 1, cfg_name, total, n_prompt, steps, B,
                                     ", action-conditioned" if args.use_actions else ", no actions"),
                        "global_batch": world * B, "algorithm": "window-recompute (reference behaviour)" if head == "window" else "ctx-cached",
-                       "parallelism": "batch-sharded x%d, all-gather of latents" % world, "vae_in_timed_region": vae is not None,
-                       "geometry": args.geometry},
+                       "parallelism": "batch-sharded x%d (one process per GPU), one all-gather of latents per clip" % world,
+                       "vae_in_timed_region": vae is not None, "geometry": args.geometry},
             "all_frames_per_s": round(world * B * total * args.steps / el, 4),          # B * 32 / wall
             "dit_forwards_per_s": round(world * (total - n_prompt) * (steps + 1) * args.steps / el, 2),   # batched forwards of B samples
-            "roofline": roofline, "cpu_baseline": cpu,
-            "dit_step": {"forward_ms_B%d_T5" % B: round(fwd_ms, 3), "executed_tflop_per_forward": round(fwd_flops / 1e12, 4),
-                         "achieved_tflops": round(step_tflops, 1), "frac_of_mfma_peak": round(step_tflops / MFMA_PEAK_TFLOPS, 4),
-                         "kernel_classes": classes},
+            "roofline": roofline, "cpu_baseline": cpu, "dit_step": dit_step,
         }
-        for algo, e in results.items():
-            fl = clip_flops(B, n_prompt, total, steps, 5, algo == "cached") * world
-            line["algo_" + algo] = {"generated_frames_per_s": round(gen_frames * args.steps / e, 4), "ms_per_clip": round(e / args.steps * 1e3, 1),
-                                    "executed_pflop_per_clip": round(fl / 1e15, 4), "achieved_tflops_per_gpu": round(fl / world * args.steps / e / 1e12, 1)}
+        line.update(algo_report(B, results, args.steps))
+        if batched is not None:
+            line["config2" if world == 1 else "config3"] = batched
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank_main(args)
 
 
 if __name__ == "__main__":

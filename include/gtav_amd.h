@@ -9,8 +9,22 @@
  * Conventions: every function returns 0 on success and a non-zero code on failure (message via
  * gtav_last_error()); nothing throws across the ABI.  All pointers named *_dev are device (HBM)
  * pointers owned by the caller (torch storage); handles own their weights and workspace.  `stream`
- * is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue work; they never
- * synchronise, allocate or free, so they are hipGraph-capturable.  Handles are not thread-safe.
+ * is a hipStream_t passed as void* (NULL = default stream).  Handles are not thread-safe and belong to the
+ * device that was current when they were created.
+ *
+ * What allocates / synchronises (everything else only enqueues kernels on `stream` and is hipGraph-capturable):
+ *   gtav_*_create            hipMalloc + hipMemset of weights and workspace (synchronous)
+ *   gtav_*_destroy           hipFree, destroys captured graphs and the private capture stream
+ *   gtav_*_finalize          synchronises `stream` twice (host-side table construction and upload in between)
+ *   gtav_dit_set_schedule    synchronous hipMemcpy of 1000 floats
+ *   gtav_dit_prepare_frame   synchronises `stream`, then a synchronous hipMemcpy of the host timestep array
+ *   gtav_dit_denoise_step    the first replayed call of a new (shape, buffers) key creates a private non-blocking stream
+ *                            (once per handle), captures the step on it and instantiates a hipGraph (host work only, nothing
+ *                            executes during capture); later calls are one hipGraphLaunch.  gtav_dit_set_graph(h, 0) selects
+ *                            plain launches, which never allocate
+ *   gtav_dit_forward         with gtav_dit_profile enabled only: creates events and synchronises at the end of the forward
+ *   gtav_dit_check / gtav_vae_check   copy the device error word back and synchronise `stream`
+ * The library reads no environment variables.
  */
 #ifndef GTAV_AMD_H
 #define GTAV_AMD_H
@@ -68,7 +82,9 @@ int gtav_dit_set_schedule(gtav_dit* h, const float* alphas_cumprod_host, int32_t
  * mode 0: recompute the whole window (what the reference does on every step).
  * mode 1: context-cached step — only frame `cur` is pushed through the network, context K/V of every
  *         temporal layer come from the cache left by the last mode-0 call on the same window
- *         (exact: context activations do not depend on frame `cur`).
+ *         (exact: context activations do not depend on frame `cur`).  The handle records which
+ *         (B, F, start, cur, x_dev) the caches describe; a mode-1 call for anything else, or after a
+ *         gtav_dit_forward (which overwrites the caches), fails instead of attending to stale K/V.
  * actions (B, F, external_cond_dim) or NULL.  v_out (B, C, H, W) optional: v_pred of frame `cur`.
  * cond_step: -1 computes the conditioning c = t_emb(t) + action and its adaLN projections inside the step (as
  *   DiT.forward does, model/dit.py:359-366); >= 0 takes them from the table built by gtav_dit_prepare_frame. */
@@ -78,12 +94,13 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x_dev, int32_t B, int32_t F, int32
 /* The conditioning does not depend on x: for one generated frame (window [start, cur]) the adaLN table of every noise
  * step is computed at once — context rows with t_ctx, n_steps row sets for frame `cur` with t_steps_host[s] — so the
  * 0.8 GB of fp32 conditioning weights are streamed once per frame instead of once per step.  Same arithmetic, same
- * results; needs max_cond_rows >= B * (cur - start + n_steps). */
+ * results; needs max_cond_rows >= B * (cur - start + n_steps).  A gtav_dit_forward or a cond_step = -1 step overwrites
+ * the table: later cond_step >= 0 calls fail until prepare_frame is called again. */
 int gtav_dit_prepare_frame(gtav_dit* h, int32_t B, int32_t F, int32_t start, int32_t cur, int32_t t_ctx,
                            const int32_t* t_steps_host, int32_t n_steps, const float* actions_dev, void* stream);
 
-/* The fused step replays a captured hipGraph per (shape, buffers) key by default (env GTAV_GRAPH=0 or this call
- * switch to plain launches; results are identical). */
+/* The fused step replays a captured hipGraph per (shape, buffers) key by default; this call switches to plain
+ * launches (results are identical). */
 int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
 
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
@@ -95,7 +112,10 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
 int gtav_dit_profile(gtav_dit* h, int32_t enable);
 int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class);
 
-/* Raises an error if any timestep seen since the last call was outside [0, 999] (synchronises). */
+/* Reads and clears the handle's device error word (synchronises): fails if, since the last call, a timestep was outside
+ * [0, 999], an input held a NaN/inf, or an fp16 activation store saturated (|x| > 65504 is clamped to +-65504, never
+ * inf: the reference runs bf16, which has fp32 range; a checkpoint with outlier channels is reported instead of
+ * silently producing NaN). */
 int gtav_dit_check(gtav_dit* h, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -129,6 +149,9 @@ int gtav_vae_encode(gtav_vae* h, const float* img_dev, float in_scale, float in_
 int gtav_vae_decode(gtav_vae* h, const float* z_dev, float z_scale, float* img_dev, float out_scale, float out_shift,
                     int32_t N, void* stream);
 
+/* Same as gtav_dit_check for the VAE handle (NaN/inf input pixels, fp16 saturation). */
+int gtav_vae_check(gtav_vae* h, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Sampler / training elementwise math on caller-owned buffers
  * ---------------------------------------------------------------------------------------------- */
@@ -145,6 +168,9 @@ int gtav_vtarget(const float* x_dev, const float* noise_dev, const float* alpha_
  * out_dev must hold 1 + rows floats. */
 int gtav_mse(const float* a_dev, int64_t a_stride, const float* b_dev, int64_t b_stride, int32_t rows, int32_t n,
              float* out_dev, void* stream);
+/* generate.py:201-202: x (B, F, n) f32, frames [first, F) of every sample are clamped to [lo, hi] in place
+ * (`torch.clamp(chunk, -noise_abs_max, +noise_abs_max)` on the initial noise of the generated frames). */
+int gtav_clamp_frames(float* x_dev, int32_t B, int32_t F, int32_t first, int32_t n, float lo, float hi, void* stream);
 /* generate.py:238-244 tail: uint8 = clamp(img * 255, 0, 255) with img (N,3,H,W) f32 -> (N,H,W,3) u8. */
 int gtav_frames_to_u8(const float* img_dev, uint8_t* out_dev, int32_t N, int32_t H, int32_t W, void* stream);
 /* generate.py:56-65: latents (N,C,h,w) = scale * mean, from moments (N, h*w, 2*latent) (first `latent` channels). */
@@ -184,11 +210,10 @@ int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16
                            int32_t gate_stride, int32_t rows_per_gate, void* out_f16_dev, const float* shift_dev,
                            const float* scale_dev, int32_t mod_stride, void* stream);
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K);
-/* Experiments: force the GEMM pipeline depth (0 = heuristic, 2 or 4 LDS stages). */
+/* Force the GEMM pipeline depth (0 = heuristic, 2 or 4 LDS stages) / block shape (0 = heuristic; 2, 3, 7, 8, 9, 11, 12, 14:
+ * csrc/gemm.hip launch_epi).  Every choice computes the same result; the parity tests use these to cover each kernel.
+ * (Timing experiments that change results exist only in the separate -DGTAV_EXPERIMENTS build, csrc/experiments.h.) */
 void gtav_op_gemm_set_stages(int32_t ns);
-/* Experiments (results become WRONG): bit 0 skips the LDS fills after the prologue, bit 1 skips LDS reads + MFMA. */
-void gtav_op_gemm_set_debug(int32_t bits);
-/* Experiments: force the GEMM block shape (0 = heuristic, 2 = 128x128 tile / 4 waves, 4 = 128x256 tile / 8 waves). */
 void gtav_op_gemm_set_wm(int32_t wm);
 /* fp32 [R][C] -> fp16 [Rp][Cp] zero padded; tiled != 0 writes the GEMM's tile-major operand layout (128 x 64 tiles,
  * csrc/common.h tiled_off; Rp % 128 == 0, Cp % 64 == 0).  All fp16 GEMM operands (x_f16_dev, w_f16_dev) and the fp16

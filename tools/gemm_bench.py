@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--splitk", type=int, default=0, help="split-K factor for the partial-slab GEMMs (0 = heuristic)")
     ap.add_argument("--wm", type=int, nargs="+", default=[0], help="block shapes to sweep: 0 heuristic, 2 = 128x128/4 waves, 4 = 128x256/8 waves")
     a = ap.parse_args()
-    lib = L.load()
+    lib = L.load_experiments()   # libgtav_amd_exp.so: the debug bits below exist only in that build
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     shapes = [("qkv", 3072, 1024, 5), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]
