@@ -1033,6 +1033,7 @@ int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K) { return gemm_ch
 void gtav_op_gemm_set_stages(int32_t ns) { gemm_set_stages(ns); }
 #ifdef GTAV_EXPERIMENTS
 void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }   // libgtav_amd_exp.so only (csrc/experiments.h)
+void gtav_op_gemm_set_stamps(void* buf_dev, int32_t max_blocks) { gemm_set_stamps((unsigned long long*)buf_dev, max_blocks); }
 #endif
 void gtav_op_gemm_set_wm(int32_t wm) { gemm_set_wm(wm); }
 

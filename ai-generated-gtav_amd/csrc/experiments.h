@@ -9,6 +9,8 @@ extern "C" {
 /* bit 0: skip the LDS fills after the prologue; bit 1: skip LDS reads + MFMA (results become WRONG: timing only);
  * bit 3: plain instead of write-through (sc1) output stores; bit 4: unstaged QKV epilogue (bits 3, 4 keep results). */
 void gtav_op_gemm_set_debug(int32_t bits);
+/* Per-block timeline of the following GEMM launches: 8 x uint64 per block (csrc/gemm.h gemm_set_stamps); NULL = off. */
+void gtav_op_gemm_set_stamps(void* buf_dev, int32_t max_blocks);
 #ifdef __cplusplus
 }
 #endif

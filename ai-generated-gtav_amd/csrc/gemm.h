@@ -28,6 +28,7 @@ struct GemmParams {
     const f16* W;  // tile-major [round_up(N,128)][K]
     int M, N, K;   // K % 64 == 0
     int debug;     // -DGTAV_EXPERIMENTS builds only: bit 0 = skip the LDS fills after the prologue, bit 1 = skip LDS reads + MFMA
+    unsigned long long* stamps;   // -DGTAV_EXPERIMENTS builds only: per-block timeline stamps (tools/gemm_stamps.py), else null
     int* err_flag; // device error word of the owning handle (bit ERR_F16_SAT is raised when an fp16 output saturated); may be null
     int out_sc1;   // set by launch_gemm: 16-byte output stores bypass-and-drop in L2 (large outputs)
     int splitk;    // EPI_PARTIAL only: number of K slices (grid = tiles * splitk); (K / 64) % splitk == 0
@@ -64,6 +65,9 @@ void gemm_set_stages(int ns);
 void gemm_set_wm(int wm);
 #ifdef GTAV_EXPERIMENTS
 void gemm_set_debug(int bits);   // timing experiments, WRONG results
+// per-block timeline: 8 x u64 per block {s_memtime at entry, first K-tile landed, main loop done, epilogue done (end);
+// s_memrealtime at entry and end (100 MHz); XCC id; 0}; buf must hold 8 * grid u64 (null switches it off)
+void gemm_set_stamps(unsigned long long* buf, int max_blocks);
 #endif
 
 }  // namespace gtav

@@ -134,6 +134,8 @@ def load_experiments(build_if_missing: bool = True) -> C.CDLL:
         fn.restype = _RESTYPES.get(name, C.c_int)
     lib.gtav_op_gemm_set_debug.argtypes = [_i]
     lib.gtav_op_gemm_set_debug.restype = None
+    lib.gtav_op_gemm_set_stamps.argtypes = [_p, _i]
+    lib.gtav_op_gemm_set_stamps.restype = None
     lib._gtav_experiments = True
     _lib = lib
     return lib

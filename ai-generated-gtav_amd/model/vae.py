@@ -70,7 +70,11 @@ class AutoencoderKL(_HipModule):
         """Distribution-identical restatement of model/vae.py:239-256 (xavier-uniform linears, zero biases,
         LayerNorm weight 1 / bias 0)."""
         for k, shp in self._shapes().items():
-            if k.endswith(".bias"):
+            if k == "patch_embed.proj.bias":
+                # the only bias `_init_weights` does not reach (a Conv2d): it keeps torch's default U(+-1/sqrt(fan_in))
+                b = 1.0 / (3 * self.patch_size ** 2) ** 0.5
+                v = (torch.rand(shp) * 2 - 1) * b
+            elif k.endswith(".bias"):
                 v = torch.zeros(shp)
             elif "norm" in k and k.endswith(".weight"):
                 v = torch.ones(shp)

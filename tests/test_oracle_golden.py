@@ -165,3 +165,77 @@ def test_g3_full_vae():
         assert rel(mom[..., :16], g["mean"]) < TOL
         dec = O.vae_decode(sd, cfg, z)
         assert rel(dec[:, :, ::4, ::4], g["decoded_stride4"]) < TOL and rel(dec[:, :, 100], g["decoded_row100"]) < TOL
+
+
+@pytest.mark.slow
+def test_g7_harness_encode_rollout_decode_bytes():
+    """G7 (reference generate.vae_encode -> denoise_step rollout -> decode tail, BASELINE config 1): pins the oracle's harness
+    restatements `vae_encode_frames`, `generate_latents`, `vae_decode_latents` (oracle/ref_cpu.py:424-456) and the dummy clip,
+    including the uint8 tail: bytes equal to the reference except where fp32 summation-order noise (<= 2e-5 relative) moves a
+    value across a truncation boundary — at most a handful of pixels, each by 1."""
+    g = gold("g7_harness.safetensors")
+    vsd = W.synth_state_dict(W.vae_param_shapes(), seed=1)
+    vcfg = O.vit_l_20_shallow_encoder()
+    kw = dict(input_h=18, input_w=32, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+    sd = W.synth_state_dict(W.dit_param_shapes(**kw), seed=31)
+    cfg = O.DiTConfig(**kw)
+    clip = O.dummy_clip()
+    assert torch.equal(clip[None, :1, :, ::8, ::8], g["prompt_frames"])
+    fn = lambda x, t, a: O.dit_forward(sd, cfg, x, t, a)
+    with torch.no_grad():
+        x0 = O.vae_encode_frames(vsd, vcfg, clip[None, :1])
+        assert rel(x0, g["latents_prompt"]) < TOL
+        lat = O.generate_latents(fn, x0, 4, 10, g["noise"], g["actions"])
+        assert rel(lat, g["latents_final"]) < 1e-4
+        u8 = O.vae_decode_latents(vsd, vcfg, g["latents_final"])
+    assert u8.dtype == torch.uint8 and u8.shape == (1, 4, 360, 640, 3)
+    d = (u8[:, :, ::4, ::4].int() - g["frames_u8_stride4"].int()).abs()
+    assert d.max().item() <= 1 and int((d > 0).sum()) <= 20, int((d > 0).sum())
+    assert (u8[:, :, 100].int() - g["frames_u8_row100"].int()).abs().max().item() <= 1
+
+
+def test_initialize_weights_statistics():
+    """a13: DiT.initialize_weights (model/dit.py:295-326) — N(0, 0.02) Linear weights, zero biases, t-MLP std 0.01, the adaLN
+    modulation of every block ZEROED (blocks are the identity at init), final adaLN std 0.01, final linear std 0.001;
+    AutoencoderKL.initialize_weights (model/vae.py:239-256) — xavier-uniform Linears, zero biases, LayerNorm (1, 0)."""
+    from gtav_amd.model.dit import DiT
+    from gtav_amd.model.vae import AutoencoderKL
+    torch.manual_seed(0)
+    m = DiT(input_h=8, input_w=16, hidden_size=256, depth=2, num_heads=4)          # init_weights=True is the default
+    sd = m.state_dict()
+
+    def std_of(k):
+        return sd[k].std().item()
+
+    for k, v in sd.items():
+        if k.endswith(".bias"):
+            assert v.abs().max().item() == 0, k
+    for i in range(2):
+        for h in "st":
+            assert sd[f"blocks.{i}.{h}_adaLN_modulation.1.weight"].abs().max().item() == 0
+            assert abs(std_of(f"blocks.{i}.{h}_attn.to_qkv.weight") - 0.02) < 0.001
+            assert abs(std_of(f"blocks.{i}.{h}_mlp.fc1.weight") - 0.02) < 0.001
+            assert abs(sd[f"blocks.{i}.{h}_mlp.fc2.weight"].mean().item()) < 1e-3
+    assert abs(std_of("t_embedder.mlp.0.weight") - 0.01) < 0.001 and abs(std_of("t_embedder.mlp.2.weight") - 0.01) < 0.001
+    assert abs(std_of("final_layer.adaLN_modulation.1.weight") - 0.01) < 0.001
+    assert abs(std_of("final_layer.linear.weight") - 0.001) < 0.0002
+    assert abs(std_of("x_embedder.proj.weight") - 0.02) < 0.002 and abs(std_of("external_cond.weight") - 0.02) < 0.002
+    # with the adaLN gates zeroed every block is the identity: zeroing a block's QKV / fc1 weights cannot change the output
+    # (SURVEY.md a13 probe) — checked on the oracle with this very state dict
+    cfg = O.DiTConfig(input_h=8, input_w=16, hidden_size=256, depth=2, num_heads=4)
+    g = torch.Generator().manual_seed(1)
+    x, t = torch.randn(1, 2, 16, 8, 16, generator=g), torch.tensor([[15, 400]])
+    sd0 = {k: v for k, v in sd.items() if not k.endswith("rotary_emb.freqs")}
+    sd1 = dict(sd0)
+    sd1["blocks.0.s_attn.to_qkv.weight"] = torch.zeros_like(sd0["blocks.0.s_attn.to_qkv.weight"])
+    sd1["blocks.1.t_mlp.fc1.weight"] = torch.zeros_like(sd0["blocks.1.t_mlp.fc1.weight"])
+    with torch.no_grad():
+        assert torch.equal(O.dit_forward(sd0, cfg, x, t, None), O.dit_forward(sd1, cfg, x, t, None))
+    v = AutoencoderKL(latent_dim=16, input_height=64, input_width=96, patch_size=8, enc_dim=128, enc_depth=1, enc_heads=2, dec_dim=128,
+                      dec_depth=1, dec_heads=2)
+    vs = v.state_dict()
+    w = vs["encoder.0.mlp.fc1.weight"]                        # (512, 128): xavier bound sqrt(6 / (128 + 512))
+    bound = (6.0 / (128 + 512)) ** 0.5
+    assert w.abs().max().item() <= bound and abs(w.std().item() - bound / 3 ** 0.5) < 0.003
+    assert torch.equal(vs["encoder.0.norm1.weight"], torch.ones(128)) and vs["encoder.0.norm1.bias"].abs().max().item() == 0
+    assert vs["predictor.bias"].abs().max().item() == 0

@@ -51,10 +51,61 @@ def one_hot_actions(B, T, g):
     return a
 
 
+SMALL_DIT_NATIVE = dict(input_h=18, input_w=32, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+
+
+@torch.no_grad()
+def g7_harness(rd, rv, ref_denoise_step, ref_schedule):
+    """G7: BASELINE config 1 end to end through the reference's own harness functions — dummy-ramp first frame
+    (dummy_dataset.py:15-36) -> generate.vae_encode (generate.py:50-66, full-size ViT-L/20 VAE) -> 4-frame / 10-step rollout
+    with train_dit.denoise_step (generate.py:186-220; small DiT on the native 18x32 latent grid, action "W") -> decode tail
+    (generate.py:238-244: vae.decode(x / s), (x + 1) / 2, clamp(x * 255, 0, 255).byte()).  Stored: inputs, latents after the
+    encode and after the rollout, the float frames before the byte conversion and the uint8 frames, both spatially decimated
+    (the full tensors are 11 MB; every 4th row / column keeps all 576 patches and every in-patch row phase)."""
+    from dummy_dataset import ImageDataset as RefDummy
+    import generate as ref_generate                      # module level is import-safe; main() needs CUDA and is not called
+    from einops import rearrange
+    vsd = W.synth_state_dict(W.vae_param_shapes(), seed=1)
+    vae = load_into(rv.VAE_models["vit-l-20-shallow-encoder"](), vsd)
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT_NATIVE), seed=31)
+    dit = load_into(rd.DiT(**SMALL_DIT_NATIVE), sd)
+    clip = RefDummy(split="test")[0]["video"]            # (5, 3, 360, 640) blue -> red ramp
+    n_prompt, total, steps = 1, 4, 10
+    prompt = clip[None, :n_prompt].contiguous()          # --start_frame convention: the first frame is the prompt
+    x = ref_generate.vae_encode(prompt, vae, n_prompt)   # (1, 1, 16, 18, 32)
+    lat_prompt = x.clone()
+    g = torch.Generator().manual_seed(77)
+    noise = torch.randn(1, total - n_prompt, 16, 18, 32, generator=g)
+    actions = torch.zeros(1, total, 25)
+    actions[:, :, 3] = 1                                  # generate.py:159,181
+    ac = torch.cumprod(1.0 - ref_schedule(1000, clamp_min=0.0001).float(), dim=0)[:, None, None, None]   # generate.py:195-198
+    nr = torch.linspace(0, 999, steps + 1)                # generate.py:194
+    for i in range(n_prompt, total):
+        chunk = torch.clamp(noise[:, i - n_prompt: i - n_prompt + 1], -20, 20)
+        x = torch.cat([x, chunk], dim=1)
+        start = max(0, i + 1 - dit.max_frames)
+        for noise_idx in reversed(range(0, steps + 1)):
+            xp, _ = ref_denoise_step(dit, x, actions, noise_idx, 15, nr, ac, start_frame=start, dtype=torch.bfloat16)
+            x[:, -1:] = xp[:, -1:]
+    lat_final = x.clone()
+    z = rearrange(x, "b t c h w -> (b t) (h w) c")
+    img = (vae.decode(z / 0.07843137255) + 1) / 2
+    img = rearrange(img, "(b t) c h w -> b t h w c", t=total)
+    u8 = torch.clamp(img * 255, 0, 255).byte()
+    inside = ((img * 255 > 0) & (img * 255 < 255)).float().mean().item()
+    print(f"g7: {inside * 100:.1f} % of the float pixels are strictly inside (0, 255); u8 mean {u8.float().mean():.1f}")
+    save("g7_harness.safetensors", {"prompt_frames": prompt[:, :, :, ::8, ::8].clone(), "noise": noise, "actions": actions,
+                                    "latents_prompt": lat_prompt, "latents_final": lat_final,
+                                    "frames_f32_stride4": img[:, :, ::4, ::4].clone(), "frames_u8_stride4": u8[:, :, ::4, ::4].clone(),
+                                    "frames_u8_row100": u8[:, :, 100].clone()})
+
+
 @torch.no_grad()
 def main():
     os.makedirs(OUT, exist_ok=True)
     rd, rv, ref_denoise_step, ref_schedule = ref_shim.import_reference()
+    if "--only-g7" in sys.argv:
+        return g7_harness(rd, rv, ref_denoise_step, ref_schedule)
     from model.rotary_embedding_torch import RotaryEmbedding
     from dummy_dataset import ImageDataset as RefDummy
     from web_dataset import actions_to_one_hot as ref_one_hot
@@ -202,6 +253,8 @@ def main():
     post = fv.encode(img)
     z = torch.randn(2, 576, 16, generator=g)
     dec = fv.decode(z)
+    del fv, fvsd
+    g7_harness(rd, rv, ref_denoise_step, ref_schedule)
     save("g3_full_vae.safetensors", {"mean": post.mean, "logvar": post.logvar, "z": z, "decoded_stride4": dec[:, :, ::4, ::4].clone(),
                                      "decoded_row100": dec[:, :, 100].clone()})
 
