@@ -308,9 +308,11 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
         q.splitk = gemm_choose_splitk(M, D, K);
-        if (q.splitk == 1 && M >= h->resid_inplace_min_m) {
-            // experiment (off by default): gated residual update in the GEMM epilogue (no slab; the next LayerNorm only reads
-            // resid).  Measured at B = 8: LN 1.46 -> 1.17 ms but out-proj 0.77 -> 1.26 ms per forward (read-modify-write in the epilogue).
+        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m)) {
+            // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
+            // read-modify-write hides under the other wave group's main loop, and without split-K slabs the next LayerNorm only
+            // reads resid.  (With the one-shot kernels the same epilogue was a loss: B = 8 out-proj 0.77 -> 1.26 ms per forward;
+            // resid_inplace_min_m keeps that experiment reachable in the experiments build.)
             q.splitk = 0; q.out = h->resid; q.bias = bias; q.gate = gate; q.gate_stride = h->MODW; q.gate_rows = mod_rows;
             q.rows_per_gate = P;
             PROF(h, cls, s, launch_gemm(q, EPI_RESID, s));
@@ -742,6 +744,12 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = dim; q.K = K; q.out = h->parts; q.ldo = dim;
+        if (gemm_pp_ok(M, dim, K, EPI_RESID)) {   // large M: in-place residual epilogue of the ping-pong kernel (see dit_forward_core)
+            q.out = h->resid; q.bias = bias;
+            RET_IF(launch_gemm(q, EPI_RESID, s));
+            have_pend = false;
+            return 0;
+        }
         q.splitk = gemm_choose_splitk(M, dim, K);
         GTAV_REQUIRE((size_t)q.splitk * M * dim <= h->parts_rows * (size_t)h->Dmax, "split-K slabs exceed workspace");
         RET_IF(launch_gemm(q, EPI_PARTIAL, s));

@@ -105,9 +105,9 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // 0.5 (1 + tanh u) == sigmoid(2u) == 1 / (1 + 2^(-2 u log2 e)): one v_exp_f32 + one v_rcp_f32 (1 ulp each; the
 // result is rounded to fp16 right after), exact limits at both tails (2^+inf -> rcp(inf) = 0, 2^-inf -> 1).
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    const float u = k0 * (x + k1 * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(-2.0f * 1.4426950408889634f * u);
+    // -2 log2(e) u = x (a + b x^2) with the constants folded: 3 multiplies / FMAs ahead of the two transcendentals instead of 5
+    const float a = -2.0f * 1.4426950408889634f * 0.7978845608028654f, b = a * 0.044715f;
+    const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, b, a));
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
@@ -147,7 +147,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // fabric write each and slower than plain ones (MI355X_MICROARCH.md, stores of each flavour).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_sc1(void* dst, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    // the trailing s_nop 1 is part of the instruction's contract: the store reads its four data registers over several cycles
+    // after issue, hipcc pads that hazard only for stores IT emits, and without the wait states the next VALU instruction may
+    // overwrite the last data dword before the last 16 lanes have read it (seen in round 2 as one wrong fp16 per 16-byte chunk in
+    // lanes 48-63, a few times per million stores: cdna_hip_programming.md 5.7 "Stores")
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store16_sc1(void* dst, f32x4 v) {
     union { f32x4 f; u32x4 u; } cv;

@@ -57,6 +57,9 @@ struct GemmParams {
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+// True when launch_gemm would run this shape on the persistent ping-pong kernel (large M): residual GEMMs then use the in-place
+// EPI_RESID epilogue (hidden under the other wave group's main loop) instead of split-K slabs.
+bool gemm_pp_ok(int M, int N, int K, int epi);
 // Split-K factor used for a residual GEMM of this shape (1 = no split): fills the 256 CUs when M is small.
 int gemm_choose_splitk(int M, int N, int K);
 // Pipeline depth override for experiments (0 = heuristic, else 2 or 4 LDS stages).

@@ -19,6 +19,7 @@
 #include "gemm.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <hip/hip_ext.h>
 
 namespace gtav {
@@ -35,6 +36,17 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Direct-to-LDS load in the scalar-base form: address = sbase (wave-uniform, an SGPR pair) + voff (32-bit per-lane offset) —
+// no 64-bit per-lane pointer and no vector address arithmetic per K-step.  hipcc does not emit this form for the builtin, so it
+// is inline asm; M0 (the LDS destination base of the DMA) is written in the same statement and restored (cdna_hip_programming.md
+// 5.7).  The statement has no VGPR destination; completion is counted by hand (vmcnt) like every other fill.
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
+
 __device__ __forceinline__ void store16q_sc1(void* dst, uint4 v) { store16_sc1(dst, u32x4{v.x, v.y, v.z, v.w}); }
 
 // fp32 x4 -> fp16 x4, saturating (common.h sat4): amax collects the largest magnitude seen by this lane
@@ -45,17 +57,19 @@ __device__ __forceinline__ uint2 pack4(float& amax, float a, float b, float c, f
 }
 
 #ifdef GTAV_EXPERIMENTS
-#define GTAV_STAMP(var) do { if (p.stamps) var = __builtin_amdgcn_s_memtime(); } while (0)
+// s_memrealtime (100 MHz, one counter for the whole chip) orders the phases of different blocks; s_memtime (shader cycles) is
+// a per-XCD counter with unrelated offsets and only gives this block's own cycle count (-> its clock)
+#define GTAV_STAMP(var) do { if (p.stamps) var = __builtin_amdgcn_s_memrealtime(); } while (0)
 struct BlockStamps {
-    unsigned long long t[4] = {0, 0, 0, 0}, r0 = 0;
+    unsigned long long t[4] = {0, 0, 0, 0}, c0 = 0;
     __device__ __forceinline__ void begin(const GemmParams& p) {
-        if (p.stamps) { t[0] = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+        if (p.stamps) { t[0] = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime(); }
     }
     __device__ __forceinline__ void end(const GemmParams& p) {
         if (p.stamps && threadIdx.x == 0) {
-            t[3] = __builtin_amdgcn_s_memtime();
+            t[3] = __builtin_amdgcn_s_memrealtime();
             unsigned long long* d = p.stamps + (size_t)blockIdx.x * 8;
-            d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3]; d[4] = r0; d[5] = __builtin_amdgcn_s_memrealtime();
+            d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3]; d[4] = c0; d[5] = __builtin_amdgcn_s_memtime();
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             d[6] = xcc & 0xF; d[7] = 0;
@@ -84,9 +98,9 @@ struct BlockStamps {
 // next tile AFTER its MFMAs instead of before: a wave's direct-to-LDS loads back-pressure its in-order instruction
 // stream at the ~63 GB/s/CU fill rate (profiles/round1/v5_gemm_8wave_microbench.txt: fills-only and MFMA-only loops
 // cost the same and used to add up), so the partners' fill and MFMA phases now run beside each other.
-template <bool TR, int NS, int WM, int FJ>
+template <bool TR, int NS, int WM, int FJ, typename AfterPrologue>
 __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
-                                         f32x4 (&acc)[4][FJ], BlockStamps& bs) {
+                                         f32x4 (&acc)[4][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
     constexpr int NWAVE = 2 * WM;
     constexpr int TMB = WM * 16 * FJ;                  // tokens per block tile
     constexpr int XT = TMB / 128;                      // 128-row X tiles per stage
@@ -131,6 +145,7 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
 
     const int npro = nkt < NS - 1 ? nkt : NS - 1;
     for (int t = 0; t < npro; ++t) stage(t);
+    after_prologue();   // register loads the epilogue wants early (bias): behind the first fills, not in front of them
     for (int t = 0; t < nkt; ++t) {
         // tiles newer than t already issued: min(NS - 2, nkt - 1 - t), G loads each
         const int rem = nkt - 1 - t;
@@ -186,9 +201,9 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
 // WAR: W slots of parity p are last read in phase 2 (prefetched) of K-tile t and refilled in phases 1-2 of t+1, after
 // barrier (a); X slots are last read in phase 1 and refilled after barrier (b).  RAW: a half-tile is read only after the
 // issuing waves' counted vmcnt and a barrier (MI355X_MICROARCH.md: LDS-DMA ordering).
-template <bool TR>
+template <bool TR, typename AfterPrologue>
 __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
-                                            f32x4 (&acc)[8][4], BlockStamps& bs) {
+                                            f32x4 (&acc)[8][4], BlockStamps& bs, AfterPrologue after_prologue) {
     constexpr int PAR = 4 * TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,6 +245,7 @@ __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    after_prologue();
     const bool fills = !GTAV_DBG(p, 1);
     GTAV_STAMP(bs.t[1]);
     for (int t = 0; t < nkt; ++t) {
@@ -303,9 +319,9 @@ __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int
 // 256 CUs and every block fills 512 KB through a ~65 GB/s per-CU LDS-DMA path; 128 x 96 / 96 x 96 tiles give 256 blocks of
 // 448 / 384 KB.  2 x WM waves; every wave issues G pieces per stage (the last waves repeat the final piece when the
 // piece count does not divide evenly: same bytes to the same place), NS-stage ring with counted vmcnt as in mainloop().
-template <bool TR, int NS, int FI, int FJ, int WM>
+template <bool TR, int NS, int FI, int FJ, int WM, typename AfterPrologue>
 __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
-                                           f32x4 (&acc)[FI][FJ], BlockStamps& bs) {
+                                           f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
     constexpr int NWAVE = 2 * WM;
     constexpr int WPC = 4 * FI, XPC = 2 * FJ * WM, NP = WPC + XPC;   // pieces per stage
     constexpr int G = (NP + NWAVE - 1) / NWAVE;
@@ -345,19 +361,20 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
     const bool late = w >= 4;                           // second wave of a SIMD: fills after its MFMAs
     const int npro = nkt < NS - 1 ? nkt : NS - 1;
     for (int t = 0; t < npro; ++t) stage(t);
-    for (int t = 0; t < nkt; ++t) {
+    after_prologue();   // register loads the epilogue wants early (bias): behind the first fills, not in front of them
+    // wait until this wave's share of tile t has landed (tiles newer than t already issued: min(NS - 2, rem), G loads each),
+    // drain this wave's LDS reads, barrier: tile t is visible to everyone and nobody reads tile t - 1 any more
+    auto sync = [&](int t) {
         const int rem = nkt - 1 - t;
-        // tiles newer than t already issued: min(NS - 2, rem), G loads each
         if (NS >= 6 && rem >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * G) : "memory");
         else if (NS >= 5 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * G) : "memory");
         else if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
         else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (t == 0) GTAV_STAMP(bs.t[1]);
-        const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
-        if (refill && !late) stage(t + NS - 1);
+    };
+    auto rd = [&](int t, f16x8 (&wf)[2][FI], f16x8 (&xf)[2][FJ]) {
         const char* b = smem + (t % NS) * STAGE_BYTES;
-        f16x8 wf[2][FI], xf[2][FJ];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
@@ -365,6 +382,8 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
 #pragma unroll
             for (int j = 0; j < FJ; ++j) xf[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
         }
+    };
+    auto mm = [&](const f16x8 (&wf)[2][FI], const f16x8 (&xf)[2][FJ]) {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -374,9 +393,50 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
                     if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                 }
-        if (refill && late) {
-            asm volatile("" ::: "memory");
-            stage(t + NS - 1);
+    };
+    if constexpr (NS >= 3) {
+        // Small-M shapes (one block per CU, 1.5 waves per SIMD): nothing else on the SIMD covers a wave's LDS-read latency, and
+        // with reads and MFMAs of the same K-step in one iteration every K-step exposed it four times (the compiler interleaves
+        // 4 reads / wait / 4 MFMAs: ~0.58 us per K-step at M = 720, profiles/round2 stamps).  One-step software pipeline instead:
+        // iteration t issues the fragment reads of tile t into one register set and runs the MFMAs of tile t - 1 from the other,
+        // so the reads are in flight under 16-24 MFMAs.  Tile t - 1's stage is refilled after barrier t: every wave drained its
+        // reads of it (lgkmcnt(0)) before that barrier.  Two register sets, loop unrolled by two for static indexing.
+        f16x8 wA[2][FI], xA[2][FJ], wB[2][FI], xB[2][FJ];
+        auto step = [&](int t, f16x8 (&wr)[2][FI], f16x8 (&xr)[2][FJ], const f16x8 (&wm_)[2][FI], const f16x8 (&xm_)[2][FJ]) {
+            sync(t);
+            const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
+            if (refill && !late) stage(t + NS - 1);
+            rd(t, wr, xr);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMA block (hipcc would sink them)
+            if (t > 0 && !GTAV_DBG(p, 2)) mm(wm_, xm_);
+            if (refill && late) {
+                asm volatile("" ::: "memory");
+                stage(t + NS - 1);
+            }
+        };
+        int t = 0;
+        for (; t + 1 < nkt; t += 2) {
+            step(t, wA, xA, wB, xB);
+            step(t + 1, wB, xB, wA, xA);
+        }
+        if (t < nkt) {
+            step(t, wA, xA, wB, xB);
+            if (!GTAV_DBG(p, 2)) mm(wA, xA);
+        } else if (!GTAV_DBG(p, 2)) {
+            mm(wB, xB);
+        }
+    } else {
+        for (int t = 0; t < nkt; ++t) {
+            sync(t);
+            const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
+            if (refill && !late) stage(t + NS - 1);
+            f16x8 wf[2][FI], xf[2][FJ];
+            rd(t, wf, xf);
+            mm(wf, xf);
+            if (refill && late) {
+                asm volatile("" ::: "memory");
+                stage(t + NS - 1);
+            }
         }
     }
 }
@@ -418,7 +478,7 @@ __device__ __forceinline__ void tile_map(const GemmParams& p, int& n0, int& m0, 
 // stores scattered over 16 rows per wave-instruction.  tab[] holds the per-token destination coordinates (one integer
 // division per token instead of one per lane and token).
 template <int FI, int FJ, int WM>
-__device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], char* smem, int n0, int m0, bool tr) {
+__device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, bool tr) {
     constexpr int TM = WM * 16 * FJ, TNB = 32 * FI;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
@@ -474,8 +534,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
             for (int i = 0; i < FI; ++i) {
                 const int nl = 16 * FI * wn + 16 * i + 4 * g;
                 const int n = n0 + nl;
-                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n < p.N) bv = *(const f32x4*)(p.bias + n);
+                const f32x4 bv = pbias[i];
                 const bool rope = n < 2 * p.D;
                 const int d = n & 63;                    // D % 64 == 0: the offset inside the head
 #pragma unroll
@@ -535,8 +594,21 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
 
 // Epilogue shared by every block shape.  The block tile is TNB = 32 FI features x TM = 16 FJ WM tokens; wave (wn, wm) owns
 // features 16 FI wn .. and tokens 16 FJ wm ..; acc[i][j] is the 16 x 16 MFMA tile (feature group i, token group j).
+// The bias of the non-transposed epilogues is fetched BEFORE the main loop (prefetch_bias): its L2 / HBM round trip used to
+// sit at the head of every epilogue.
+template <int EPI, int FI, int WM>
+__device__ __forceinline__ void prefetch_bias(const GemmParams& p, int n0, f32x4 (&pbias)[FI]) {
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
+        pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_PARTIAL && p.bias && n < p.N && threadIdx.x < 128 * WM) pbias[i] = *(const f32x4*)(p.bias + n);
+    }
+}
+
 template <int EPI, int FI, int FJ, int WM>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], char* smem, int n0, int m0, int ks, bool tr) {
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr) {
     constexpr int TM = WM * 16 * FJ;
     constexpr int CT = FI / 2;                      // 64-feature sub-tiles per block tile row
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -554,8 +626,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
                 const int nl = 16 * FI * wn + 16 * i + 4 * g;           // feature inside the block tile (4 consecutive)
-                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (p.bias && n0 + nl < p.N) bv = *(const f32x4*)(p.bias + n0 + nl);
+                const f32x4 bv = pbias[i];
                 const int c = nl & 63;                              // feature inside the 64-wide sub-tile (= 16 i + 4 g)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
@@ -588,7 +659,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     if constexpr (EPI == EPI_QKV) {
         // block-uniform: 8-token groups of a V^T row must not straddle attention items
         if (!GTAV_DBG(p, 16) && (p.qkv_mode == QKV_TEMPORAL || p.S % 8 == 0)) {
-            qkv_staged<FI, FJ, WM>(p, acc, smem, n0, m0, tr);
+            qkv_staged<FI, FJ, WM>(p, acc, pbias, smem, n0, m0, tr);
             return;
         }
     }
@@ -645,8 +716,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     for (int i = 0; i < FI; ++i) {
         const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
         if (n >= p.N) continue;
-        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PARTIAL && p.bias) bv = *(const f32x4*)(p.bias + n);
+        const f32x4 bv = pbias[i];
         int which = 0, nn = n, head = 0, d = 0;
         if constexpr (EPI == EPI_QKV) {
             which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
@@ -728,14 +798,16 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 :
 
     bool tr = false;
     if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+    f32x4 pbias[4];
+    auto pf = [&]() { prefetch_bias<EPI, 4, WM>(p, n0, pbias); };
     if constexpr (EPI == EPI_QKV) {
-        if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs);
-        else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs);
+        if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     } else {
-        mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs);
+        mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPI, 4, FJ, WM>(p, acc, smem, n0, m0, ks, tr);
+    epilogue<EPI, 4, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
 
@@ -752,18 +824,29 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool tr = false;
+    f32x4 pbias[8];
+    auto pf = [&]() { prefetch_bias<EPI, 8, 4>(p, n0, pbias); };
+    auto nopf = []() {};
     if constexpr (EPI == EPI_QKV) {
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-        if (tr) mainloop256<true>(p, smem, n0, m0, kt0, nkt, acc, bs);
-        else mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs);
+        if (tr) mainloop256<true>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+        else mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+        pf();   // the QKV variant is at the 256-register limit: fetch after the main loop
     } else {
-        mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs);
+        mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPI, 8, 4, 4>(p, acc, smem, n0, m0, ks, tr);
+    epilogue<EPI, 8, 4, 4>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
 
+// Experiment of round 2, NOT kept — de-phasing the two co-resident blocks of a CU (shape 12, large M).  The per-block timeline
+// (tools/gemm_stamps.py, profiles/round2/stamps_lockstep.txt) shows the 512 blocks of a residency round in lockstep: prologue 2 us,
+// main loop 21.6 us, epilogue 6.1 us, all at the same time on every CU.  Making the second block to arrive on a CU (a ticket from a
+// per-CU counter indexed by XCC id / HW_ID) wait 3-16 us did shift its phases (stamps_dephased.txt) but bought nothing: fc1 at
+// M = 5760 59.4 us without, 60.5-65.4 us with; M = 11 520 115.7 vs 113.1-115.7 (profiles/round2/dephase_sweep.txt).  A block does not
+// run faster while its partner idles — its K-step is bound by its own barrier-synchronised fill / read / MFMA chain, not by a fill
+// rate shared with the partner — so an offset only moves the idle time.  The same measurement explains the ping-pong kernel below.
 template <int EPI, int NS, int FI, int FJ, int WM>
 __global__ __launch_bounds__(128 * WM, (WM == 2 || (WM == 4 && NS == 2)) ? 2 : 1) void gemm_g_kernel(GemmParams p) {
     constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
@@ -782,17 +865,345 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 || (WM == 4 && NS == 2)) ? 2 : 1
 #pragma unroll
         for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool tr = false;
+    f32x4 pbias[FI];
+    auto pf = [&]() { prefetch_bias<EPI, FI, WM>(p, n0, pbias); };
     if constexpr (EPI == EPI_QKV) {
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-        if (tr) mainloop_g<true, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs);
-        else mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs);
+        if (tr) mainloop_g<true, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        else mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     } else {
-        mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs);
+        mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPI, FI, FJ, WM>(p, acc, smem, n0, m0, ks, tr);
+    epilogue<EPI, FI, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent ping-pong GEMM for large M (shape 16): one 1024-thread block per CU, two groups of 8 waves.
+//
+// What the stamps of round 2 showed for the two-blocks-per-CU shape at M = 5760 (profiles/round2/stamps_*.txt): the 512
+// resident blocks run in LOCKSTEP — every block is in its prologue (2 us), main loop (21.6 us at half the CU's fill rate
+// each) and epilogue (6.1 us: GELU / RoPE VALU + staging + stores) at the same time, so the co-resident block never hides
+// anything: 8 of every 30 us the MFMA pipe and the L2->LDS path of the whole chip idle.  Here the overlap is built in:
+//   * the block is persistent and walks its tiles (blockIdx + i * gridDim of an XCD-aware order) — 128 features x 192 tokens
+//     each, the per-wave 64 x 48 sub-tile and fragment reads of shape 12;
+//   * group (i & 1) runs the MAIN loop of tile i (all the LDS-DMA fills, fragment reads and MFMAs) while the other group runs
+//     the EPILOGUE of tile i - 1 out of its accumulators: one 16 x 16 accumulator tile per K-step slot, straight from registers
+//     to memory (pairs of lanes exchange halves for 16-byte stores; no LDS staging, so no LDS or barrier of its own), and in
+//     its last NS - 1 slots issues the first fills of tile i + 1, which it will compute next: the LDS ring never drains
+//     between tiles, a tile's prologue latency and its epilogue are both under the other group's MFMAs;
+//   * one s_barrier per K-step, shared by all 16 waves: MAIN waves arrive after their counted vmcnt / lgkmcnt(0) (tile data
+//     landed, previous stage no longer read), EPILOGUE waves arrive bare.  Ring slot of K-step k of tile i = (i P + k) % NS.
+// 16 waves per CU = 4 per SIMD = 128 VGPRs per lane: 48 accumulator + 56 fragment registers fit (shape 12's budget).
+// Because the epilogue is free, the residual GEMMs use the in-place gated residual epilogue here (EPI_RESID: x += gate (acc +
+// bias), a read-modify-write whose loads are issued one slot ahead) instead of split-K slabs: the LayerNorm that follows
+// reads and writes 35 MB instead of 83-106 MB at M = 5760.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PP_FI = 4, PP_FJ = 3, PP_WM = 4, PP_G = 5, PP_NT = PP_FI * PP_FJ;
+constexpr int PP_WPC = 16, PP_NP = 40, PP_STAGE = PP_NP * 1024, PP_TN = 128, PP_TM = 192;
+
+__device__ __forceinline__ void pp_tile_of(const GemmParams& p, int v, int tiles_m, int tiles_n, int& n0, int& m0) {
+    const int T = tiles_m * tiles_n;
+    const int xcd = v & 7, qq = T >> 3, rr = T & 7;
+    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (v >> 3);
+    int gn = tiles_n >= 8 ? tiles_n >> 3 : 1;
+    const int group = tiles_m * gn;
+    const int ng = tile_id / group, rem = tile_id - ng * group;
+    const int n_first = ng * gn;
+    if (n_first + gn > tiles_n) gn = tiles_n - n_first;
+    const int tile_m = rem / gn, tile_n = n_first + (rem - tile_m * gn);
+    n0 = tile_n * PP_TN;
+    m0 = tile_m * PP_TM;
+}
+
+// 16-byte store of the fp16x4 of lanes (l, l ^ 16): the MFMA tile's lane groups g and g ^ 1 hold adjacent 4-element runs
+__device__ __forceinline__ void pp_store_pair(f16* dst, uint2 mine, int lane, bool sc1, bool ok) {
+    const unsigned o0 = __shfl_xor(mine.x, 16, 64), o1 = __shfl_xor(mine.y, 16, 64);
+    if (ok && !(lane & 16)) {
+        if (sc1) store16_sc1(dst, u32x4{mine.x, mine.y, o0, o1});
+        else *(uint4*)dst = uint4{mine.x, mine.y, o0, o1};
+    }
+}
+
+template <int EPI, int NS>
+__global__ __launch_bounds__(1024, 1) void gemm_pp_kernel(GemmParams p) {
+    constexpr int FI = PP_FI, FJ = PP_FJ, G = PP_G, NT = PP_NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 3, wg = w & 7, wn = wg & 1, wm = wg >> 1;
+    const int li = lane & 15, g = lane >> 4;
+    const int P = p.K / TK;
+    const int tiles_m = (p.M + PP_TM - 1) / PP_TM, tiles_n = (p.N + PP_TN - 1) / PP_TN;
+    const int T = tiles_m * tiles_n;
+    const int nt = (T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block (grid <= T)
+    const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
+    const bool late = wg >= 4;
+
+    // ---- fills: 40 one-KiB pieces per K-step (16 of W, 24 of X), 5 per MAIN wave; sources located per piece (mainloop_g).
+    // Address of a piece = operand base + k * 16 KiB (SGPRs) + a 32-bit per-lane offset set once per tile (glds16_s) ----
+    unsigned soff[G];
+    const unsigned smem0 = lds_offset(smem);
+    auto setup = [&](int n0, int m0) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = wg * G + i;
+            const bool isw = q < PP_WPC;
+            const int row = isw ? n0 + 8 * q : m0 + 8 * (q - PP_WPC);
+            int rt = row >> 7;
+            const int lim = isw ? last_wt : last_rt;
+            rt = rt < lim ? rt : lim;                    // ragged edges re-read a valid tile (results are masked)
+            soff[i] = (unsigned)rt * (unsigned)(P * TILE_BYTES) + (unsigned)(((row & 127) >> 3) * 1024 + lane * 16);
+        }
+    };
+    auto stage = [&](int slot, int k) {
+        const unsigned base = smem0 + slot * PP_STAGE + wg * (G * 1024);
+        const char* wk = (const char*)p.W + (size_t)k * TILE_BYTES;
+        const char* xk = (const char*)p.X + (size_t)k * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < G; ++i) glds16_s(wg * G + i < PP_WPC ? wk : xk, soff[i], base + i * 1024);
+    };
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = (16 * FI * wn + li) * 128 + ch;
+        xoff[s] = PP_WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
+    }
+
+    f32x4 acc[FI][FJ];
+    float amax = 0.f;
+    int en0 = 0, em0 = 0;          // tile whose accumulators this group holds
+    bool etr = false;
+
+#ifdef GTAV_EXPERIMENTS
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (grp == 0) {                // prologue of the first tile
+        int n0, m0;
+        pp_tile_of(p, blockIdx.x, tiles_m, tiles_n, n0, m0);
+        setup(n0, m0);
+        const int npro = P < NS - 1 ? P : NS - 1;
+        for (int k = 0; k < npro; ++k) stage(k % NS, k);
+    }
+
+    for (int i = 0; i <= nt; ++i) {
+        const bool has_main = i < nt;
+        const int base_slot = (int)(((long long)i * P) % NS);
+        if ((i & 1) == grp) {
+            if (!has_main) continue;
+            // =========================================== MAIN loop of tile i ===========================================
+            int n0, m0;
+            pp_tile_of(p, blockIdx.x + i * gridDim.x, tiles_m, tiles_n, n0, m0);
+            bool tr = false;
+            if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+            en0 = n0; em0 = m0; etr = tr;
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // two copies of the K loop (operands swapped for the transposed V tiles) instead of a per-MFMA select
+            auto main_loop = [&](auto trc) {
+                constexpr bool TR = decltype(trc)::value;
+                int slot = base_slot;
+                for (int k = 0; k < P; ++k) {
+                    const int rem = P - 1 - k;
+                    // this wave's share of K-step k has landed (younger fills of this wave: min(NS - 2, rem) K-steps of G)
+                    if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
+                    else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    const bool refill = k + NS - 1 < P;      // the last NS - 1 slots belong to the next tile (filled by the other group)
+                    int fslot = slot + NS - 1;
+                    fslot = fslot >= NS ? fslot - NS : fslot;
+                    if (refill && !late) stage(fslot, k + NS - 1);
+                    const char* b = smem + slot * PP_STAGE;
+                    // all 14 fragment reads of the K-step go out before its first MFMA (one LDS round trip per K-step instead of the
+                    // eight read / wait / 3-MFMA groups hipcc forms at this register budget)
+                    f16x8 wf[2][FI], xf[2][FJ];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                        for (int a = 0; a < FI; ++a) wf[s][a] = *(const f16x8*)(b + woff[s] + a * 16 * 128);
+#pragma unroll
+                        for (int c = 0; c < FJ; ++c) xf[s][c] = *(const f16x8*)(b + xoff[s] + c * 16 * 128);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int a = 0; a < FI; ++a)
+#pragma unroll
+                            for (int c = 0; c < FJ; ++c) {
+                                if (TR) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][c], wf[s][a], acc[a][c], 0, 0, 0);
+                                else acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][a], xf[s][c], acc[a][c], 0, 0, 0);
+                            }
+                    if (refill && late) {
+                        asm volatile("" ::: "memory");
+                        stage(fslot, k + NS - 1);
+                    }
+                    slot = slot + 1 == NS ? 0 : slot + 1;
+                }
+            };
+            if (tr) main_loop(std::true_type{});
+            else main_loop(std::false_type{});
+#ifdef GTAV_EXPERIMENTS
+            if (p.stamps && wg == 0 && lane == 0 && i < 5) p.stamps[(size_t)blockIdx.x * 8 + 2 + i] = __builtin_amdgcn_s_memrealtime();   // end of MAIN(i)
+#endif
+        } else {
+            // ================= EPILOGUE of tile i - 1 (this group's accumulators) + first fills of tile i + 1 =================
+            const bool do_epi = i >= 1, do_pref = i + 1 < nt;
+            // (the fill pointers of tile i + 1 are set up at its first prefetch slot, not here: ten VGPRs less through the epilogue)
+            auto prefetch = [&](int e, int pbase_, int pfirst_) {
+                if (e == pfirst_) {
+                    int pn0, pm0;
+                    pp_tile_of(p, blockIdx.x + (i + 1) * gridDim.x, tiles_m, tiles_n, pn0, pm0);
+                    setup(pn0, pm0);
+                }
+                int ps = pbase_ + (e - pfirst_);
+                ps = ps >= NS ? ps - NS : ps;
+                stage(ps, e - pfirst_);
+            };
+            const int pbase = (int)(((long long)(i + 1) * P) % NS);      // ring slot of K-step 0 of tile i + 1
+            const int pfirst = P - (NS - 1);                              // slot index in this phase at which tile i + 1's step 0 may be issued
+            const int n0 = en0, m0 = em0;
+            // ---- per-token destination coordinates of this wave's FJ token columns (integer divisions: once per tile) ----
+            int tok_a[FJ], tok_b[FJ];          // tok_b: token inside its frame (spatial, = RoPE position) / window frame (temporal RoPE position)
+            bool tok_ok[FJ];
+#pragma unroll
+            for (int c = 0; c < FJ; ++c) {
+                const int m = m0 + 16 * FJ * wm + 16 * c + (etr ? 4 * g : li);
+                tok_ok[c] = m < p.M;
+                const int mm = tok_ok[c] ? m : p.M - 1;
+                tok_a[c] = 0; tok_b[c] = 0;
+                if constexpr (EPI == EPI_QKV) {
+                    const int fr = mm / p.S;
+                    if (p.qkv_mode == QKV_SPATIAL) {
+                        tok_a[c] = fr; tok_b[c] = mm - fr * p.S;
+                    } else {
+                        const int bb = fr / p.Tq, tfr = p.t0 + (fr - bb * p.Tq);
+                        tok_a[c] = (bb * p.Tmax + tfr) * p.S + (mm - fr * p.S); tok_b[c] = tfr;
+                    }
+                } else if constexpr (EPI == EPI_RESID) {
+                    int row = p.gate ? mm / p.rows_per_gate : 0;
+                    if (p.gate && p.gate_rows) row = p.gate_rows[row];
+                    tok_a[c] = row;
+                }
+            }
+            // one accumulator tile per slot; the loads a tile needs (residual row, gate, bias, RoPE) are issued one slot ahead
+            f32x4 ld0 = f32x4{0.f, 0.f, 0.f, 0.f}, ld1 = ld0, ld2 = ld0;      // for the tile processed in THIS slot
+            f32x4 nx0 = ld0, nx1 = ld0, nx2 = ld0;                            // for the next one
+            auto issue_loads = [&](int e, f32x4& r0, f32x4& r1, f32x4& r2) {
+                const int a = e / FJ, c = e - a * FJ;
+                const int m = m0 + 16 * FJ * wm + 16 * c + li;
+                const int n = n0 + 16 * FI * wn + 16 * a + 4 * g;
+                r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; r2 = r0;
+                if (etr) {
+                    if (p.bias) { const int nf = n0 + 16 * FI * wn + 16 * a + li; r0[0] = nf < p.N ? p.bias[nf] : 0.f; }
+                    return;
+                }
+                if (n >= p.N || !tok_ok[c]) return;
+                if (p.bias) r0 = *(const f32x4*)(p.bias + n);
+                if constexpr (EPI == EPI_RESID) {
+                    r1 = *(const f32x4*)((const float*)p.out + (size_t)m * p.ldo + n);
+                    if (p.gate) r2 = *(const f32x4*)(p.gate + (size_t)tok_a[c] * p.gate_stride + n);
+                } else if constexpr (EPI == EPI_QKV) {
+                    if (n < 2 * p.D) r1 = *(const f32x4*)(p.rope_cs + tok_b[c] * 64 + (n & 63));
+                }
+            };
+            auto epi_tile = [&](int e, const f32x4& r0, const f32x4& r1, const f32x4& r2) {
+                const int a = e / FJ, c = e - a * FJ;
+                const f32x4 av = acc[a][c];
+                // every lane runs the pair exchange of pp_store_pair (cross-lane reads need both lanes active); only the store is
+                // predicated.  A pair (g, g ^ 1) shares its token(s) / feature group, so `ok` is the same in both lanes.
+                if (etr) {
+                    // D[row = token][col = feature] (spatial V): the lane owns tokens m .. m + 3 of feature n -> V^T [feature][token]
+                    const int n = n0 + 16 * FI * wn + 16 * a + li;
+                    const int heads = p.D >> 6, nn = n - 2 * p.D;
+                    const uint2 pk = pack4(amax, av[0] + r0[0], av[1] + r0[0], av[2] + r0[0], av[3] + r0[0]);
+                    const bool ok = tok_ok[c] && n < p.N;
+                    f16* dst = p.v + ((size_t)(tok_a[c] * heads + (nn >> 6)) * 64 + (nn & 63)) * p.S + tok_b[c];
+                    pp_store_pair(dst, pk, lane, p.out_sc1, ok);
+                    return;
+                }
+                const int m = m0 + 16 * FJ * wm + 16 * c + li;
+                const int n = n0 + 16 * FI * wn + 16 * a + 4 * g;
+                const bool ok = n < p.N && tok_ok[c];         // a pair covers 8 consecutive features: N % 8 == 0
+                f32x4 v = av + r0;
+                if constexpr (EPI == EPI_RESID) {
+                    if (ok) {
+                        float* dst = (float*)p.out + (size_t)m * p.ldo + n;
+                        const f32x4 x = p.gate ? r1 + r2 * v : r1 + v;
+                        if (p.out_sc1) store16_sc1(dst, x);
+                        else *(f32x4*)dst = x;
+                    }
+                } else if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
+                    uint2 pk;
+                    if constexpr (EPI == EPI_GELU_TANH) pk = pack4(amax, gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+                    else pk = pack4(amax, gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
+                    pp_store_pair((f16*)p.out + (ok ? tiled_off(m, n, p.ldo) : 0), pk, lane, p.out_sc1, ok);
+                } else if constexpr (EPI == EPI_QKV) {
+                    const int which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
+                    const int nn = n - which * p.D;
+                    if (which < 2) {
+                        f32x4 r;
+                        r[0] = v[0] * r1[0] - v[1] * r1[1];
+                        r[1] = v[1] * r1[0] + v[0] * r1[1];
+                        r[2] = v[2] * r1[2] - v[3] * r1[3];
+                        r[3] = v[3] * r1[2] + v[2] * r1[3];
+                        v = r;
+                    }
+                    const uint2 pk = pack4(amax, v[0], v[1], v[2], v[3]);
+                    f16* dst;
+                    if (p.qkv_mode == QKV_SPATIAL) {
+                        const int heads = p.D >> 6;
+                        dst = (which == 0 ? p.q : p.k) + ((size_t)(tok_a[c] * heads + (nn >> 6)) * p.S + tok_b[c]) * 64 + (nn & 63);
+                    } else if (which == 0) {
+                        dst = p.q + (size_t)(tok_ok[c] ? m : 0) * p.D + nn;
+                    } else {
+                        dst = p.k + (size_t)tok_a[c] * 2 * p.D + (which == 2 ? p.D : 0) + nn;
+                    }
+                    pp_store_pair(dst, pk, lane, p.out_sc1, ok);
+                }
+            };
+            // the residual epilogue's read-modify-write loads are issued one slot ahead; the others (bias / RoPE rows: L2 hits) are
+            // loaded in their own slot — the epilogue has slack (12 tiles in >= 14 slots) and the QKV variant has no registers to spare
+            constexpr bool AHEAD = EPI == EPI_RESID;
+            if (do_epi && AHEAD) issue_loads(0, ld0, ld1, ld2);
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                if (has_main) asm volatile("s_barrier" ::: "memory");
+                if (do_epi) {
+                    if constexpr (AHEAD) {
+                        if (e + 1 < NT) issue_loads(e + 1, nx0, nx1, nx2);
+                        epi_tile(e, ld0, ld1, ld2);
+                        ld0 = nx0; ld1 = nx1; ld2 = nx2;
+                    } else {
+                        issue_loads(e, ld0, ld1, ld2);
+                        epi_tile(e, ld0, ld1, ld2);
+                    }
+                }
+                if (has_main && do_pref && e >= pfirst) prefetch(e, pbase, pfirst);
+            }
+            if (has_main) {
+                for (int e = NT; e < P; ++e) {
+                    asm volatile("s_barrier" ::: "memory");
+                    if (do_pref && e >= pfirst) prefetch(e, pbase, pfirst);
+                }
+            }
+        }
+    }
+    if constexpr (EPI != EPI_RESID) sat_report(amax, p.err_flag);
+#ifdef GTAV_EXPERIMENTS
+    // timeline (tools/gemm_stamps.py --pp): [0] entry, [2 + i] end of the MAIN loop of this block's i-th tile (i < 5), [7] end of the
+    // last epilogue (written by the group that ran it), [1] = number of tiles
+    if (p.stamps && wg == 0 && lane == 0 && grp == ((nt - 1) & 1)) {
+        p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[(size_t)blockIdx.x * 8 + 1] = nt;
+    }
+#endif
+}
+
 
 }  // namespace
 
@@ -829,8 +1240,61 @@ thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};   // common.h GTAV_
 //        8 = 96x96 / 6 waves, 9 = 128x96 / 6 waves, 11 = 64x48 / 6 waves, 14 = 64x96 / 6 waves (piece-granular mainloop_g; small M),
 //        12 = 128x192 / 8 waves, two blocks per CU (mainloop_g; large M).
 // (Shapes 4, 5, 6, 10 of round 1 — 128x256, loader-wave variants, 4-wave 128x192 — measured slower and were removed.)
+// ---- persistent ping-pong kernel (shape 16) ----
+static int g_num_cus[64] = {0};
+static int device_cus(int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    *dev_out = dev;
+    if (!g_num_cus[dev & 63]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cus[dev & 63] = n;
+    }
+    return g_num_cus[dev & 63];
+}
+// Round-2 measurement (profiles/round2/pp_stamps_v1.txt): correct and bit-identical to the one-shot kernels, the overlap works (MAIN
+// phases run back to back), but with only 8 of the 16 waves computing, a K-step costs 1.15-1.25 us against 0.68 us of fill time: the
+// barrier-synchronised waves serialise into fill / read / MFMA phases, where two independent co-resident blocks interleave them.
+// fc1 at M = 5760: 71-76 us against 57 us for shape 12.  Not selected by the heuristic (GTAV_PP=1 in the experiments build or a
+// forced shape 16 run it); the de-phased shape 12 above gets the same overlap with 16 computing waves.
+static int g_pp_enable = GTAV_ENV_INT("GTAV_PP", 0);
+bool gemm_pp_ok(int M, int N, int K, int epi) {
+    if (!(epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_QKV || epi == EPI_RESID)) return false;
+    if (K % TK != 0 || K / TK < 14 || M % 8 != 0 || N % 8 != 0) return false;
+    // worth it when most CUs get a tile and, beyond one tile per CU, the epilogue of one tile hides under the next tile's main
+    // loop (otherwise the one-shot kernels with smaller tiles cover the chip better)
+    return g_pp_enable && cdiv(M, PP_TM) * cdiv(N, PP_TN) >= 224;
+}
+template <int EPI>
+static int launch_pp(const GemmParams& p, hipStream_t stream) {
+    constexpr int NS = 3;
+    static unsigned long long attr_devs = 0;   // per instantiation, per device (hipFuncSetAttribute is a per-device setting)
+    int dev = 0;
+    const int cus = device_cus(&dev);
+    GTAV_REQUIRE(cus > 0, "gemm: no current device");
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * PP_STAGE));
+        attr_devs |= 1ull << (dev & 63);
+    }
+    const int T = cdiv(p.M, PP_TM) * cdiv(p.N, PP_TN);
+    const dim3 grid(T < cus ? T : cus);
+    GTAV_LAUNCH((gemm_pp_kernel<EPI, NS>), grid, dim3(1024), NS * PP_STAGE, stream, p);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
+    if (shape == 16) {
+        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_QKV || EPI == EPI_RESID) {
+            GTAV_REQUIRE(gemm_pp_ok(p.M, p.N, p.K, EPI) || (p.K / TK >= 12 && p.M % 8 == 0 && p.N % 8 == 0),
+                         "gemm: the ping-pong kernel needs K >= 768, M %% 8 == 0, N %% 8 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
+            return launch_pp<EPI>(p, stream);
+        } else {
+            GTAV_REQUIRE(false, "gemm: the ping-pong kernel (shape 16) has no epilogue %d", (int)EPI);
+        }
+    }
     if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 2, 3>), grid, dim3(384));
@@ -926,6 +1390,8 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         // below ~320 tiles the 512 block slots are too unevenly filled (fc2 at M = 5760: 240 tiles, 65.7 -> 73.1 us).
         wm = 12;   // 8 waves of 64 x 48 (four per SIMD with the co-resident block): QKV 60.3 -> 54.8, fc1 62.1 -> 59.4 vs the 4-wave form (shape 10)
     }
+    // large M: the persistent ping-pong kernel (epilogue and next tile's prologue under the other wave group's MFMAs)
+    if (!g_force_wm && splitk == 1 && gemm_pp_ok(p.M, p.N, p.K, epi) && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL && p.S % 8 != 0)) wm = 16;
     GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");
     // 256 x 256 tiles (shape 7) halve the fill bytes per FLOP but run one block per CU, so a tile's epilogue (a 32 MB
     // store burst per round of 256 tiles) is not hidden by a co-resident block: they win only where the K loop is long

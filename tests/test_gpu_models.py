@@ -119,8 +119,11 @@ def test_denoise_step_mirror_and_fused_and_cached():
         m.denoise_step_(xd, 1, n - 1, 15, t_cur, t_next, noise_idx <= 0, a.to(dev()))
         assert rel_l2(xd[:, -1], xr[:, -1]) < TOL_SMALL
         assert torch.equal(xd[:, :-1].cpu(), x[:, :-1])
-        # context-cached step reproduces the window step (same kernels, same rows)
+        # context-cached step reproduces the window step (same kernels, same rows).  It needs the K/V caches of a full-window
+        # step on the SAME buffer (the handle refuses anything else): run one, restore the frame it updated, then the cached step
         xc = x.to(dev()).contiguous()
+        m.denoise_step_(xc, 1, n - 1, 15, t_cur, t_next, noise_idx <= 0, a.to(dev()))
+        xc[:, -1] = x[:, -1].to(dev())
         m.denoise_step_(xc, 1, n - 1, 15, t_cur, t_next, noise_idx <= 0, a.to(dev()), cached=True)
         assert rel_l2(xc[:, -1], xd[:, -1]) < 1e-5
 

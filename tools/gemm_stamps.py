@@ -1,7 +1,7 @@
 """Per-block timeline of the GEMM kernels (experiments build only): where does a launch spend its time?
 
-Every block records s_memtime at entry, when its first K-tile has landed (prologue), at the end of the main loop and at the
-end of the epilogue, plus s_memrealtime (100 MHz) at entry / end and its XCC id (csrc/gemm.hip BlockStamps).  This tool
+Every block records s_memrealtime (100 MHz, chip-wide) at entry, when its first K-tile has landed (prologue), at the end of the
+main loop and at the end of the epilogue, plus s_memtime (shader cycles, per-XCD counter) at entry / end and its XCC id (csrc/gemm.hip BlockStamps).  This tool
 launches one GEMM per DiT shape, reads the stamps back and prints, per launch: the kernel's event time, the spread of block
 start times, the per-phase durations (median / p90) and how the blocks' epilogues overlap other blocks' main loops.
 
@@ -85,11 +85,10 @@ def main():
                 lib.gtav_op_gemm_set_stamps(None, 0)
                 s = rows[-1]
                 nb = s.shape[0]
-                t0, t1, t2, t3, r0, r1, xcc = (s[:, i] for i in range(7))
-                span_cyc = float(t3.max() - t0.min())
-                span_us = float(r1.max() - r0.min()) / 100.0
-                cyc_per_us = span_cyc / max(span_us, 1e-9)
-                f = lambda c: c.double() / cyc_per_us       # cycles -> us
+                t0, t1, t2, t3, c0, c1, xcc = (s[:, i] for i in range(7))     # t*: s_memrealtime (100 MHz); c*: s_memtime (cycles)
+                span_us = float(t3.max() - t0.min()) / 100.0
+                cyc_per_us = float(torch.median((c1 - c0).double() / (t3 - t0).clamp_min(1).double())) * 100.0
+                f = lambda c: c.double() / 100.0            # 10 ns ticks -> us
                 start = f(t0 - t0.min())
                 pro, main_, epi_, tot = f(t1 - t0), f(t2 - t1), f(t3 - t2), f(t3 - t0)
                 # overlap: fraction of a block's epilogue interval during which at least one OTHER block is inside its main loop is not
