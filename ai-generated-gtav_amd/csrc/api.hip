@@ -974,6 +974,12 @@ int gtav_moments_to_latents(const float* mom, float* lat, int32_t N, int32_t hw,
                             void* stream) {
     return launch_moments_to_latents(mom, lat, N, hw, latent, mom_ch, scale, (hipStream_t)stream);
 }
+int gtav_strip_to_frames(const uint8_t* strip, int32_t H, int32_t W, int32_t n_frames, float* out, int32_t OH, int32_t OW, void* stream) {
+    return launch_resize_aa(strip, 1, out, n_frames, H, W, OH, OW, (hipStream_t)stream);
+}
+int gtav_resize_frames(const float* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream) {
+    return launch_resize_aa(src, 0, dst, N, H, W, OH, OW, (hipStream_t)stream);
+}
 int gtav_latents_to_tokens(const float* lat, float* z, int32_t N, int32_t hw, int32_t latent, void* stream) {
     return launch_latents_to_tokens(lat, z, N, hw, latent, (hipStream_t)stream);
 }

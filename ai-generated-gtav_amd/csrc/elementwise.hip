@@ -485,6 +485,61 @@ __global__ void latents_to_tokens_kernel(const float* __restrict__ lat, float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Frame ingest (web_dataset.py:41-57,105-107 / hf_dataset.py:22-41 / generate.py:150-153): ToTensor (u8 / 255, HWC -> CHW),
+// SplitImages (n frames side by side along W) and Resize((OH, OW)) — bilinear with antialiasing as torch's
+// F.interpolate(mode="bilinear", antialias=True, align_corners=False), which torchvision's tensor Resize calls: per axis
+//   scale = in / out, support = max(scale, 1), centre = scale (i + 0.5), taps j in [int(centre - support + 0.5), int(centre + support
+//   + 0.5)) clipped to the image, weight = max(0, 1 - |j + 0.5 - centre| / max(scale, 1)), normalised to sum 1.
+// Up-scaling (the dataset's 270 x 480 -> 360 x 640) degenerates to plain bilinear with at most 2 x 2 taps.  One thread per output
+// pixel evaluates the separable filter directly (sum_y wy sum_x wx); HBM-bound, coalesced along ox.
+// U8SRC: source is a uint8 HWC strip (H, n W, 3) holding n frames; else float NCHW (n, 3, H, W).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aa_taps(int i, float scale, int in_size, int& lo, int& cnt, float& centre, float& inv) {
+    const float support = scale >= 1.0f ? scale : 1.0f;
+    centre = scale * ((float)i + 0.5f);
+    inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    lo = (int)(centre - support + 0.5f);
+    lo = lo < 0 ? 0 : lo;
+    int hi = (int)(centre + support + 0.5f);
+    hi = hi > in_size ? in_size : hi;
+    cnt = hi - lo;
+}
+__device__ __forceinline__ float aa_w(int j, float centre, float inv) {
+    float x = ((float)j - centre + 0.5f) * inv;
+    x = x < 0.f ? -x : x;
+    return x < 1.0f ? 1.0f - x : 0.0f;
+}
+template <bool U8SRC>
+__global__ void resize_aa_kernel(const void* __restrict__ src, float* __restrict__ dst, int n, int H, int W, int OH, int OW, float in_scale) {
+    const size_t total = (size_t)n * 3 * OH * OW;
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH), c = (int)((idx / ((size_t)OW * OH)) % 3);
+        const int f = (int)(idx / ((size_t)OW * OH * 3));
+        int y0, ny, x0, nx;
+        float cy, iy, cx, ix;
+        aa_taps(oy, sy, H, y0, ny, cy, iy);
+        aa_taps(ox, sx, W, x0, nx, cx, ix);
+        float wxs = 0.f;
+        for (int j = 0; j < nx; ++j) wxs += aa_w(x0 + j, cx, ix);
+        float acc = 0.f, wys = 0.f;
+        for (int a = 0; a < ny; ++a) {
+            const float wy = aa_w(y0 + a, cy, iy);
+            wys += wy;
+            float row = 0.f;
+            for (int j = 0; j < nx; ++j) {
+                float v;
+                if (U8SRC) v = (float)((const uint8_t*)src)[((size_t)(y0 + a) * ((size_t)n * W) + (size_t)f * W + (x0 + j)) * 3 + c];
+                else v = ((const float*)src)[(((size_t)f * 3 + c) * H + (y0 + a)) * W + (x0 + j)];
+                row += aa_w(x0 + j, cx, ix) * v;
+            }
+            acc += wy * row;
+        }
+        dst[idx] = acc / (wxs * wys) * in_scale;
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;
@@ -696,6 +751,14 @@ int launch_frames_to_u8(const float* img, uint8_t* out, int N, int H, int W, hip
 int launch_moments_to_latents(const float* mom, float* lat, int N, int hw, int latent, int mom_ch, float scale, hipStream_t stream) {
     hipLaunchKernelGGL(moments_to_latents_kernel, dim3(grid_for((size_t)N * hw * latent)), dim3(256), 0, stream, mom, lat, N, hw,
                        latent, mom_ch, scale);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_resize_aa(const void* src, int src_is_u8_strip, float* dst, int n, int H, int W, int OH, int OW, hipStream_t stream) {
+    GTAV_REQUIRE(src && dst && n >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1, "resize: bad arguments");
+    const size_t total = (size_t)n * 3 * OH * OW;
+    if (src_is_u8_strip) hipLaunchKernelGGL(resize_aa_kernel<true>, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, n, H, W, OH, OW, 1.0f / 255.0f);
+    else hipLaunchKernelGGL(resize_aa_kernel<false>, dim3(grid_for(total)), dim3(256), 0, stream, src, dst, n, H, W, OH, OW, 1.0f);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

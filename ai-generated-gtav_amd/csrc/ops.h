@@ -82,6 +82,9 @@ int launch_clamp_cols(float* buf, int M, int ld, int c0, int c1, float lo, float
 int launch_frames_to_u8(const float* img, uint8_t* out, int N, int H, int W, hipStream_t stream);
 int launch_moments_to_latents(const float* mom, float* lat, int N, int hw, int latent, int mom_ch, float scale, hipStream_t stream);
 int launch_latents_to_tokens(const float* lat, float* z, int N, int hw, int latent, hipStream_t stream);
+// Frame ingest: antialiased bilinear resize to (OH, OW) of n frames, either from a uint8 HWC strip (H, n*W, 3) with /255 (ToTensor +
+// SplitImages + Resize of the dataset step) or from float NCHW (n, 3, H, W).  dst (n, 3, OH, OW) f32.
+int launch_resize_aa(const void* src, int src_is_u8_strip, float* dst, int n, int H, int W, int OH, int OW, hipStream_t stream);
 // fp32 strided copy with padding (used to build concatenated fp32 weights): dst[r][c0 + c] = src[r][c]
 int launch_copy_f32(const float* src, int lds, int R, int C, float* dst, int ldd, int c0, hipStream_t stream);
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);

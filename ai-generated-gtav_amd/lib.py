@@ -76,6 +76,8 @@ SIGNATURES = {
     "gtav_frames_to_u8": [_p, _p, _i, _i, _i, _p],
     "gtav_moments_to_latents": [_p, _p, _i, _i, _i, _i, _f, _p],
     "gtav_latents_to_tokens": [_p, _p, _i, _i, _i, _p],
+    "gtav_strip_to_frames": [_p, _i, _i, _i, _p, _i, _i, _p],
+    "gtav_resize_frames": [_p, _p, _i, _i, _i, _i, _i, _p],
     "gtav_op_gemm_f16": [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "gtav_op_gemm_qkv": [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     "gtav_op_rope_interleave": [_p, _p, _p, _i, _p],

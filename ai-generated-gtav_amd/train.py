@@ -59,3 +59,74 @@ def forward_loss(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], ta
         vp_last = v_pred[:, -1]
         _lib.check(L.gtav_mse(vp_last.data_ptr(), v_pred.stride(0), v_target.data_ptr(), n, B, n, out.data_ptr(), stream))
     return out[:1], v_pred, v_target.reshape(B, 1, *x_curr.shape[2:])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Inference helpers of the trainer (reference train_dit.py:352-552): decode_frames, predict, predict_noise.  Same kernels as the
+# generation harness; the trainer's constants differ from generate.py's: schedule clamp_min 1e-6, the
+# stabilisation level is noise_range[1] of the TRAINING range (19 for ddim_noise_steps = 50), inference range as .long().
+# Random draws are arguments (the reference draws them from the global RNG), so parity runs inject identical noise.
+# ------------------------------------------------------------------------------------------------------------------------
+def stabilization_level(ddim_noise_steps: int = 50) -> int:
+    """train_dit.py:309-327: noise_range = linspace(0, 999, steps + 1).long(); stabilization_level = noise_range[1]."""
+    return int(torch.linspace(0, 999, ddim_noise_steps + 1).long()[1])
+
+
+@torch.inference_mode()
+def decode_frames(vae, latents: torch.Tensor) -> torch.Tensor:
+    """train_dit.py:352-368: latents (B, t, C, h, w) -> uint8 video (B, t, H, W, 3)."""
+    from .generate import vae_decode_frames
+    return vae_decode_frames(latents, vae, to_uint8=True)
+
+
+@torch.inference_mode()
+def predict(dit, vae, frames: torch.Tensor, actions: Optional[torch.Tensor], new_frame_noise: torch.Tensor, num_frames: int = 32,
+            n_prompt_frames: int = 4, ddim_noise_steps: int = 50, ddim_noise_steps_inference: int = 50, noise_abs_max: float = 20.0,
+            decode: bool = True):
+    """train_dit.py:370-466 `predict`: first sample of the batch, prompt = its first n_prompt_frames, actions padded with "W"
+    (index 3) up to num_frames, autoregressive generation with the trainer's constants.  new_frame_noise (1, num_frames -
+    n_prompt_frames, C, h, w): the standard-normal draw of every generated frame.  Returns (latents (1, num_frames, C, h, w), uint8
+    video (1, num_frames, H, W, 3) or None)."""
+    from .generate import generate_latents
+    frames = frames[:1, :n_prompt_frames]
+    act = None
+    if actions is not None:
+        act = actions[:1].to(torch.float32)
+        if act.shape[1] < num_frames:
+            pad = torch.zeros((1, num_frames - act.shape[1], act.shape[2]), dtype=act.dtype, device=act.device)
+            pad[:, :, 3] = 1                                                  # drive straight (train_dit.py:386-390)
+            act = torch.cat([act, pad], dim=1)
+    x = encode_frames(vae, frames.to(vae.device))
+    lat = generate_latents(dit, x, num_frames, ddim_noise_steps_inference, new_frame_noise, act,
+                           stabilization_level=stabilization_level(ddim_noise_steps), noise_abs_max=noise_abs_max, clamp_min=1e-6)
+    return lat, (decode_frames(vae, lat) if decode else None)
+
+
+@torch.inference_mode()
+def predict_noise(dit, vae, frames: torch.Tensor, actions: Optional[torch.Tensor], ctx_noise: torch.Tensor, new_frame_noise: torch.Tensor,
+                  ddim_noise_steps: int = 50, ddim_noise_steps_inference: int = 50, noise_abs_max: float = 20.0):
+    """train_dit.py:468-552 `predict_noise`: encode every frame of the first clip, noise the context frames at level
+    stabilization_level - 1 (train_dit.py:498), replace the last frame by clamped noise and denoise it.
+    ctx_noise (1, n - 1, C, h, w), new_frame_noise (1, 1, C, h, w).  Returns (latents, x_noisy before denoising, x after)."""
+    from .generate import generate_latents
+    dev = dit.device
+    L = _lib.load()
+    latents = encode_frames(vae, frames[:1].to(vae.device)).to(dev)
+    n = latents.shape[1]
+    lvl = stabilization_level(ddim_noise_steps)
+    ac = _alphas_cumprod(1e-6)
+    ctx = latents[:, :-1].contiguous()
+    x_ctx = torch.empty_like(ctx)
+    alpha = ac[lvl - 1].reshape(1).repeat(n - 1).to(dev).contiguous()
+    nz = ctx_noise.to(dev, torch.float32).contiguous()
+    fsz = ctx[0, 0].numel()
+    with torch.cuda.device(dev):
+        _lib.check(L.gtav_add_noise(ctx.data_ptr(), nz.data_ptr(), alpha.data_ptr(), x_ctx.data_ptr(), n - 1, fsz, float(noise_abs_max),
+                                    _lib.current_stream()))
+    act = actions[:1].to(torch.float32) if actions is not None else None
+    x = generate_latents(dit, x_ctx, n, ddim_noise_steps_inference, new_frame_noise, act, stabilization_level=lvl,
+                         noise_abs_max=noise_abs_max, clamp_min=1e-6)
+    x_old = torch.cat([x_ctx, new_frame_noise.to(dev, torch.float32)], dim=1).contiguous()      # the sequence before denoising
+    with torch.cuda.device(dev):
+        _lib.check(L.gtav_clamp_frames(x_old.data_ptr(), 1, n, n - 1, fsz, -float(noise_abs_max), float(noise_abs_max), _lib.current_stream()))
+    return latents, x_old, x

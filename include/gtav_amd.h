@@ -176,6 +176,13 @@ int gtav_frames_to_u8(const float* img_dev, uint8_t* out_dev, int32_t N, int32_t
 /* generate.py:56-65: latents (N,C,h,w) = scale * mean, from moments (N, h*w, 2*latent) (first `latent` channels). */
 int gtav_moments_to_latents(const float* moments_dev, float* lat_dev, int32_t N, int32_t hw, int32_t latent,
                             int32_t mom_ch, float scale, void* stream);
+/* Dataset step (web_dataset.py:41-57,105-107, hf_dataset.py:22-41): a decoded strip image uint8 (H, n_frames*W, 3) — five 270x480 frames
+ * side by side in the GTAV dataset — becomes frames (n_frames, 3, OH, OW) f32 in [0,1]: ToTensor (/255, HWC->CHW), SplitImages,
+ * Resize((OH,OW)) bilinear with antialiasing (torch F.interpolate(..., antialias=True), what torchvision's tensor Resize calls). */
+int gtav_strip_to_frames(const uint8_t* strip_dev, int32_t H, int32_t W, int32_t n_frames, float* out_dev, int32_t OH, int32_t OW,
+                         void* stream);
+/* generate.py:150-153 prompt path: float frames (N,3,H,W) -> (N,3,OH,OW), same filter. */
+int gtav_resize_frames(const float* src_dev, float* dst_dev, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream);
 /* generate.py:238: (N,C,h,w) latents -> (N, h*w, C) decoder input. */
 int gtav_latents_to_tokens(const float* lat_dev, float* z_dev, int32_t N, int32_t hw, int32_t latent, void* stream);
 

@@ -490,9 +490,80 @@ def train_forward_loss(dit_fn: Callable, latents: Tensor, actions: Optional[Tens
     return loss, v_pred, v_target, x_noisy, t
 
 
+def trainer_predict_latents(dit_fn: Callable, vae_sd, vcfg: VAEConfig, frames: Tensor, actions: Optional[Tensor],
+                            new_frame_noise: Tensor, num_frames: int, n_prompt_frames: int = 4, ddim_noise_steps: int = 50,
+                            ddim_noise_steps_inference: int = 50, max_frames: int = 5, noise_abs_max: float = 20.0) -> Tensor:
+    """train_dit.py:370-466 `predict` up to the latents (the decode tail is `vae_decode_latents`): trainer constants — schedule
+    clamp_min 1e-6 (:292), stabilization_level = noise_range[1] of the training range (:327), long() inference range (:315)."""
+    frames = frames[:1, :n_prompt_frames]
+    if actions is not None:
+        actions = actions[:1]
+        if actions.shape[1] < num_frames:
+            pad = torch.zeros((1, num_frames - actions.shape[1], actions.shape[2]))
+            pad[:, :, 3] = 1
+            actions = torch.cat([actions, pad], dim=1)
+    x = vae_encode_frames(vae_sd, vcfg, frames)
+    lvl = int(noise_range_train(ddim_noise_steps)[1])
+    nri = noise_range_train(ddim_noise_steps_inference)
+    ac = alphas_cumprod_table(1e-6)[:, None, None, None]
+    for i in range(n_prompt_frames, num_frames):
+        chunk = torch.clamp(new_frame_noise[:, i - n_prompt_frames: i - n_prompt_frames + 1], -noise_abs_max, noise_abs_max)
+        x = torch.cat([x, chunk], dim=1)
+        start = max(0, i + 1 - max_frames)
+        for noise_idx in reversed(range(0, ddim_noise_steps_inference + 1)):
+            x_pred, _ = denoise_step(dit_fn, x, actions, noise_idx, lvl, nri, ac, start)
+            x[:, -1:] = x_pred[:, -1:]
+    return x
+
+
+def trainer_predict_noise(dit_fn: Callable, vae_sd, vcfg: VAEConfig, frames: Tensor, actions: Optional[Tensor], ctx_noise: Tensor,
+                          new_frame_noise: Tensor, ddim_noise_steps: int = 50, ddim_noise_steps_inference: int = 50,
+                          max_frames: int = 5, noise_abs_max: float = 20.0):
+    """train_dit.py:468-552 `predict_noise`: returns (latents, x_noisy before denoising, x_noisy after)."""
+    latents = vae_encode_frames(vae_sd, vcfg, frames[:1])
+    n = latents.shape[1]
+    lvl = int(noise_range_train(ddim_noise_steps)[1])
+    nri = noise_range_train(ddim_noise_steps_inference)
+    ac = alphas_cumprod_table(1e-6)[:, None, None, None]
+    x_noisy = latents.clone()
+    cn = torch.clamp(ctx_noise, -noise_abs_max, noise_abs_max)
+    t_ctx = torch.full((1, n - 1), lvl - 1, dtype=torch.long)                       # train_dit.py:495-501
+    a = ac[t_ctx]
+    x_noisy[:, :-1] = a.sqrt() * x_noisy[:, :-1] + (1 - a).sqrt() * cn
+    x_noisy[:, -1:] = torch.clamp(new_frame_noise, -noise_abs_max, noise_abs_max)
+    if actions is not None:
+        actions = actions[:1]
+    start = max(0, n - max_frames)
+    x_old = x_noisy.clone()
+    for noise_idx in reversed(range(0, ddim_noise_steps_inference + 1)):
+        x_pred, _ = denoise_step(dit_fn, x_noisy, actions, noise_idx, lvl, nri, ac, start)
+        x_noisy[:, -1:] = x_pred[:, -1:]
+    return latents, x_old, x_noisy
+
+
 # ----------------------------------------------------------------------------------------------
 # synthetic inputs (dummy_dataset.py:15-36, web_dataset.py:22-38)
 # ----------------------------------------------------------------------------------------------
+def resize_frames(x: Tensor, size=(360, 640)) -> Tensor:
+    """torchvision.transforms.Resize(size) on a float tensor (..., H, W) (web_dataset.py:107, hf_dataset.py:32, generate.py:151):
+    torchvision.transforms.functional.resize -> torch.nn.functional.interpolate(mode="bilinear", align_corners=False,
+    antialias=True).  torchvision is absent from the image (parity unpinned for this row): this calls the same ATen kernel
+    torchvision would; for the dataset's up-scaling (270x480 -> 360x640) antialiasing is a no-op."""
+    lead = x.shape[:-3]
+    y = F.interpolate(x.reshape(-1, *x.shape[-3:]).float(), size=tuple(size), mode="bilinear", align_corners=False, antialias=True)
+    return y.reshape(*lead, *y.shape[-3:])
+
+
+def strip_to_clip(strip_u8_hwc: Tensor, n_frames=5, size=(360, 640)) -> Tensor:
+    """web_dataset.py:41-57,105-107 / hf_dataset.py:30-33: Compose([ToTensor(), SplitImages(), Resize(size)]) on a decoded strip
+    image (H, n*W, 3) uint8: -> (n, 3, size[0], size[1]) float in [0, 1]."""
+    img = strip_u8_hwc.permute(2, 0, 1).float() / 255.0                    # ToTensor
+    c, h, wt = img.shape
+    w = wt // n_frames
+    clip = img.reshape(c, h, n_frames, w).permute(2, 0, 1, 3)              # SplitImages: "c h (n w) -> n c h w"
+    return resize_frames(clip, size)
+
+
 def dummy_clip(height=360, width=640, n=5) -> Tensor:
     """dummy_dataset.py:15-25: n constant-colour frames blue->red, (n,3,H,W) in [0,1]."""
     blue, red = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([1.0, 0.0, 0.0])

@@ -555,3 +555,78 @@ def test_stale_state_guards():
         m.denoise_step_(x2, 0, n - 1, 15, 0, 0, True, a, cached=True)                      # another latent buffer
     with pytest.raises(GtavError, match="stale"):
         m.denoise_step_(x, 1, n - 1, 15, 0, 0, True, a, cached=True)                       # another window
+
+
+SMALL_VAE_8x12 = dict(SMALL_VAE)                              # 64 x 96 frames, patch 8 -> 8 x 12 latents
+SMALL_DIT_8x12 = dict(input_h=8, input_w=12, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+
+
+def test_trainer_predict_and_predict_noise():
+    """§8(f)4 inference helpers of the trainer (train_dit.py:352-552): `predict` (prompt -> autoregressive rollout with the trainer's
+    constants: clamp_min 1e-6, stabilisation level 19, "W" padding of the actions -> uint8 video) and `predict_noise` (context noised
+    at level - 1, last frame denoised) against the oracle with injected draws."""
+    from gtav_amd.train import predict, predict_noise, stabilization_level
+    assert stabilization_level(50) == 19
+    vsd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE_8x12), seed=5)
+    v = AutoencoderKL(**SMALL_VAE_8x12, init_weights=False)
+    v.load_state_dict(vsd)
+    vcfg = O.VAEConfig(**SMALL_VAE_8x12)
+    m, sd, cfg = _mk_dit(SMALL_DIT_8x12, seed=17, max_batch=1)
+    dit_fn = lambda xx, tt, aa: O.dit_forward(sd, cfg, xx, tt, aa)
+    g = torch.Generator().manual_seed(21)
+    frames = torch.rand(2, 5, 3, 64, 96, generator=g)
+    acts = torch.zeros(2, 5, 25)
+    acts[:, -1, 1] = 1
+    nz = torch.randn(1, 3, 16, 8, 12, generator=g) * 6
+    with torch.no_grad():
+        ref = O.trainer_predict_latents(dit_fn, vsd, vcfg, frames, acts, nz, num_frames=7, n_prompt_frames=4, ddim_noise_steps_inference=5)
+        ref_u8 = O.vae_decode_latents(vsd, vcfg, ref)
+    lat, video = predict(m, v, frames, acts, nz, num_frames=7, n_prompt_frames=4, ddim_noise_steps_inference=5)
+    assert video.shape == (1, 7, 64, 96, 3) and video.dtype == torch.uint8
+    assert rel_l2(lat, ref) < TOL_ROLLOUT
+    assert (video.cpu().int() - ref_u8.int()).abs().max().item() <= 1
+    cn = torch.randn(1, 4, 16, 8, 12, generator=g) * 6
+    nf = torch.randn(1, 1, 16, 8, 12, generator=g)
+    with torch.no_grad():
+        l_r, old_r, new_r = O.trainer_predict_noise(dit_fn, vsd, vcfg, frames, acts, cn, nf, ddim_noise_steps_inference=5)
+    l_g, old_g, new_g = predict_noise(m, v, frames, acts, cn, nf, ddim_noise_steps_inference=5)
+    assert rel_l2(l_g, l_r) < TOL_SMALL and rel_l2(old_g, old_r) < TOL_SMALL and rel_l2(new_g, new_r) < TOL_ROLLOUT
+
+
+def test_dataset_step_and_prompt_resize():
+    """§8(f)3 / (f)2: the per-sample dataset transform (ToTensor + SplitImages + Resize((360, 640)) of a 270 x 2400 strip) and the
+    prompt-frame resize (arbitrary size -> 360 x 640, incl. down-scaling with antialiasing) as HIP kernels vs the oracle
+    (torch's antialiased bilinear interpolate, which torchvision's Resize calls)."""
+    from gtav_amd.data import resize_frames, strip_to_clip
+    g = torch.Generator().manual_seed(5)
+    strip = torch.randint(0, 256, (270, 2400, 3), generator=g, dtype=torch.uint8)
+    clip = strip_to_clip(strip)
+    ref = O.strip_to_clip(strip)
+    assert clip.shape == ref.shape == (5, 3, 360, 640)
+    assert (clip.cpu() - ref).abs().max().item() < 2e-6
+    for (H, W_) in ((720, 1280), (500, 333), (360, 640), (123, 77)):
+        x = torch.rand(2, 3, H, W_, generator=g)
+        got = resize_frames(x.to(dev()))
+        want = O.resize_frames(x)
+        assert got.shape == want.shape == (2, 3, 360, 640)
+        assert (got.cpu() - want).abs().max().item() < 2e-6, (H, W_)
+
+
+def test_read_prompt_frame_and_video_out(tmp_path):
+    """generate.py:150-153 + 244-246 around the path: a PNG start frame -> prompt tensor; generated uint8 frames -> a video file."""
+    from PIL import Image
+    from gtav_amd.data import read_avi_mjpeg, read_prompt_frame, write_video
+    g = torch.Generator().manual_seed(6)
+    img = torch.randint(0, 256, (300, 500, 3), generator=g, dtype=torch.uint8)
+    p = str(tmp_path / "start.png")
+    Image.fromarray(img.numpy(), "RGB").save(p)
+    x = read_prompt_frame(p)
+    assert x.shape == (1, 1, 3, 360, 640)
+    want = O.resize_frames(img.permute(2, 0, 1)[None].float() / 255.0)
+    assert (x[0].cpu() - want).abs().max().item() < 2e-6
+    # a smooth clip (JPEG is lossy: noise would not survive it) through the uint8 tail and the video writer
+    from gtav_amd.dummy_dataset import ImageDataset
+    frames = (ImageDataset(split="test")[0]["video"][:3].permute(0, 2, 3, 1) * 255).clamp(0, 255).byte()
+    out = write_video(str(tmp_path / "clip.mp4"), frames, fps=10)          # no torchvision here: lands as Motion-JPEG AVI
+    back = read_avi_mjpeg(out)
+    assert back.shape == frames.shape and (back.int() - frames.int()).abs().float().mean().item() < 2.0

@@ -185,3 +185,30 @@ def test_bench_launcher_unit():
     t0 = __import__("time").time()
     rc = bench.launch_ranks(2, ["--gpus", "2", "--mode", "nonsense"])      # argparse rejects it in every rank: exit status 2
     assert rc == 2 and __import__("time").time() - t0 < 120
+
+
+def test_video_writer_and_one_hot(tmp_path):
+    """§8(f)2 host side: uint8 frames -> Motion-JPEG AVI (RIFF structure, frame count, size, round trip within JPEG error),
+    .npy and PNG-directory outputs; the 25-way action one-hot with -1 -> zero row (web_dataset.py:22-38)."""
+    import struct
+    from gtav_amd.data import actions_to_one_hot, read_avi_mjpeg, write_video
+    ramp = (torch.linspace(0, 200, 64)[:, None, None] + torch.linspace(0, 40, 96)[None, :, None] + torch.tensor([0., 10., 20.])).byte()
+    frames = torch.stack([ramp + 5 * i for i in range(4)])
+    p = write_video(str(tmp_path / "v.avi"), frames, fps=10)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"AVI " and struct.unpack("<I", raw[4:8])[0] == len(raw) - 8
+    avih = raw.find(b"avih")
+    us_per_frame, _, _, _, total = struct.unpack("<5I", raw[avih + 8:avih + 28])
+    w, h = struct.unpack("<2I", raw[avih + 8 + 32:avih + 8 + 40])
+    assert (us_per_frame, total, w, h) == (100000, 4, 96, 64) and raw.count(b"00dc") >= 8 and b"MJPG" in raw
+    back = read_avi_mjpeg(p)
+    assert back.shape == frames.shape and (back.int() - frames.int()).abs().float().mean().item() < 3.0
+    assert write_video(str(tmp_path / "v.mp4"), frames).endswith((".mp4", ".avi"))
+    import numpy as np
+    assert np.array_equal(np.load(write_video(str(tmp_path / "v.npy"), frames)), frames.numpy())
+    d = write_video(str(tmp_path / "pngs"), frames)
+    assert sorted(os.listdir(d)) == [f"frame_{i:04d}.png" for i in range(4)]
+    with pytest.raises(ValueError):
+        write_video(str(tmp_path / "bad.avi"), frames.float())
+    oh = actions_to_one_hot([-1, 3, 0, 24, -1])
+    assert oh.shape == (5, 25) and oh.sum().item() == 3 and oh[1, 3] == 1 and oh[0].sum() == 0
