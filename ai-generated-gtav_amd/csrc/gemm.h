@@ -53,6 +53,10 @@ struct GemmParams {
     int Tmax;   // temporal: frames in the kv cache per batch item
     const float* rope_cs;   // [npos][32][2]: (cos, sin) of rotation pair k at [pos][k] (interleaved-pair RoPE;
                             // cos/sin of features 2k and 2k+1 are equal, rotary_embedding_torch.py:337)
+    // block -> tile map constants of the loader-wave kernels, filled by their launcher (host): the map's three integer divisions
+    // by run-time values cost ~110 scalar instructions (two float-reciprocal sequences) = 0.3-0.4 us in front of the first fill;
+    // with the divisors' 32-bit reciprocals (a / d == mulhi(a, ceil(2^32 / d)) for a * d < 2^32) they are three s_mul_hi_u32
+    struct TileMap { int tiles_m, tiles_n, gn, group, tiles; unsigned rcp_tiles, rcp_group, rcp_gn, rcp_gnlast; } tm;
 };
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.

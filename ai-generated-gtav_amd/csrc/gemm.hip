@@ -56,6 +56,44 @@ __device__ __forceinline__ uint2 pack4(float& amax, float a, float b, float c, f
     return cv.u;
 }
 
+
+// K-step synchronisation: the wave's LDS reads have drained, all but its VM youngest vector-memory operations (the LDS-DMA fills of
+// newer tiles) have completed, then the workgroup barrier.  The waits are the BUILTIN, not inline asm, and the lgkmcnt(0) is
+// UNCONDITIONAL (ahead of the run-time choice of the vmcnt count): hipcc's own wait-count pass then knows on every path that no LDS
+// read is outstanding after this point.  With the asm form (and with the lgkmcnt inside the branches) it did not, and in the
+// software-pipelined loops it put an `s_waitcnt lgkmcnt(0)` between the fragment reads of tile t and the MFMAs of tile t - 1 in
+// every second K-step: the reads' full LDS round trip exposed (gemm.s of round 2).  The barrier stays inline asm with a memory
+// clobber: no LDS or global access may move across it.
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+template <int VM>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(VM >= 0 && VM < 64, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(VM, 15));
+}
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0)); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int VM>
+__device__ __forceinline__ void kstep_sync() {
+    wait_lgkm0();
+    wait_vm<VM>();
+    wg_barrier();
+}
+// the same for an NS-stage ring with G fills per wave and K-step: min(NS - 2, rem) newer tiles are in flight (rem = K-steps after this one)
+template <int NS, int G>
+__device__ __forceinline__ void wait_vm_ring(int rem) {
+    if constexpr (NS >= 6) { if (rem >= 4) { wait_vm<4 * G>(); return; } }
+    if constexpr (NS >= 5) { if (rem >= 3) { wait_vm<3 * G>(); return; } }
+    if constexpr (NS >= 4) { if (rem >= 2) { wait_vm<2 * G>(); return; } }
+    if constexpr (NS >= 3) { if (rem >= 1) { wait_vm<G>(); return; } }
+    wait_vm<0>();
+}
+template <int NS, int G>
+__device__ __forceinline__ void kstep_sync_ring(int rem) {
+    wait_lgkm0();
+    wait_vm_ring<NS, G>(rem);
+    wg_barrier();
+}
+
 #ifdef GTAV_EXPERIMENTS
 // s_memrealtime (100 MHz, one counter for the whole chip) orders the phases of different blocks; s_memtime (shader cycles) is
 // a per-XCD counter with unrelated offsets and only gives this block's own cycle count (-> its clock)
@@ -68,11 +106,12 @@ struct BlockStamps {
     __device__ __forceinline__ void end(const GemmParams& p) {
         if (p.stamps && threadIdx.x == 0) {
             t[3] = __builtin_amdgcn_s_memrealtime();
-            unsigned long long* d = p.stamps + (size_t)blockIdx.x * 8;
+            unsigned long long* d = p.stamps + (size_t)blockIdx.x * ((p.debug & 32) ? 64 : 8);
             d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3]; d[4] = c0; d[5] = __builtin_amdgcn_s_memtime();
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            d[6] = xcc & 0xF; d[7] = 0;
+            atomicOr(&d[6], (unsigned long long)(xcc & 0xF));   // bits 8.. may hold a loader wave's stamp (mainloop_l); the tool zeroes the buffer
+
         }
     }
 };
@@ -84,6 +123,21 @@ struct BlockStamps {
     __device__ __forceinline__ void end(const GemmParams&) {}
 };
 #endif
+
+// Scheduling directive for a region that holds NM MFMAs and ND independent ds_reads: emit them as MFMA, RPM reads, MFMA, RPM reads,
+// ... until the reads are out, the remaining MFMAs last (sched_group_barrier masks: 0x008 = MFMA, 0x100 = DS read).  The reads go
+// into the issue shadows of the FIRST MFMAs so that the rest of the MFMA block covers their LDS round trip before the K-step's
+// lgkmcnt(0) + barrier.
+template <int NM, int ND, int RPM = 1>
+__device__ __forceinline__ void interleave_mfma_dsread() {
+    constexpr int NG = (ND + RPM - 1) / RPM;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+    }
+    if constexpr (NM > NG) __builtin_amdgcn_sched_group_barrier(0x008, NM - NG, 0);
+}
 
 // NS-stage LDS ring.  Tile t lives in stage t % NS.  Steady state: NS-1 tiles are in flight when iteration t starts;
 // the wave waits (counted vmcnt, never 0 in the main loop) until ITS OWN share of tile t has landed, the raw
@@ -149,9 +203,7 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
     for (int t = 0; t < nkt; ++t) {
         // tiles newer than t already issued: min(NS - 2, nkt - 1 - t), G loads each
         const int rem = nkt - 1 - t;
-        if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
-        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        kstep_sync_ring<NS, G>(rem);
         if (t == 0) GTAV_STAMP(bs.t[1]);
         const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
         if (refill && !late) stage(t + NS - 1);
@@ -366,11 +418,7 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
     // drain this wave's LDS reads, barrier: tile t is visible to everyone and nobody reads tile t - 1 any more
     auto sync = [&](int t) {
         const int rem = nkt - 1 - t;
-        if (NS >= 6 && rem >= 4) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(4 * G) : "memory");
-        else if (NS >= 5 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(3 * G) : "memory");
-        else if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
-        else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        kstep_sync_ring<NS, G>(rem);
         if (t == 0) GTAV_STAMP(bs.t[1]);
     };
     auto rd = [&](int t, f16x8 (&wf)[2][FI], f16x8 (&xf)[2][FJ]) {
@@ -406,9 +454,14 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             sync(t);
             const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
             if (refill && !late) stage(t + NS - 1);
-            rd(t, wr, xr);
-            __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMA block (hipcc would sink them)
-            if (t > 0 && !GTAV_DBG(p, 2)) mm(wm_, xm_);
+            if (t > 0 && !GTAV_DBG(p, 2)) {
+                rd(t, wr, xr);
+                mm(wm_, xm_);
+                interleave_mfma_dsread<2 * FI * FJ, 2 * (FI + FJ), 1>();   // one read in each of the first MFMAs' issue shadows (not a block of reads first)
+            } else {
+                rd(t, wr, xr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if (refill && late) {
                 asm volatile("" ::: "memory");
                 stage(t + NS - 1);
@@ -472,17 +525,42 @@ __device__ __forceinline__ void tile_map(const GemmParams& p, int& n0, int& m0, 
     m0 = tile_m * TMB;
 }
 
+// The same map from host-precomputed constants (GemmParams::tm, filled by launch_l): no run-time integer division.
+__device__ __forceinline__ int div_rcp(int a, unsigned rcp) { return rcp ? (int)__umulhi((unsigned)a, rcp) : a; }   // rcp == 0 encodes a divisor of 1
+template <bool SPLITK, int TNB, int TMB>
+__device__ __forceinline__ void tile_map_fast(const GemmParams& p, int& n0, int& m0, int& ks, int& kt0, int& nkt) {
+    const GemmParams::TileMap& tm = p.tm;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    int tile_id = swz;
+    ks = 0, kt0 = 0, nkt = p.K / TK;
+    if constexpr (SPLITK) {
+        ks = div_rcp(swz, tm.rcp_tiles);
+        tile_id = swz - ks * tm.tiles;
+        nkt = nkt / p.splitk;       // a power of two or a small divisor: one division, off the loaders' critical path
+        kt0 = ks * nkt;
+    }
+    const int ng = div_rcp(tile_id, tm.rcp_group), rem = tile_id - ng * tm.group;
+    const int n_first = ng * tm.gn;
+    const bool last = n_first + tm.gn > tm.tiles_n;      // last, partial group of n-panels
+    const int gn = last ? tm.tiles_n - n_first : tm.gn;
+    const int tile_m = div_rcp(rem, last ? tm.rcp_gnlast : tm.rcp_gn), tile_n = n_first + (rem - tile_m * gn);
+    n0 = tile_n * TNB;
+    m0 = tile_m * TMB;
+}
+
 // QKV epilogue staged through LDS: bias + RoPE happen in registers (pairs are lane-local), the block's fp16 result is laid
 // out in LDS in the shape of its DESTINATION rows (q/k: [token][feature], V^T: [feature][token]) and leaves as 16-byte
 // stores — a whole 128-byte head row of one token (or 8 consecutive tokens of one V^T row) per 8 lanes — instead of 8-byte
 // stores scattered over 16 rows per wave-instruction.  tab[] holds the per-token destination coordinates (one integer
 // division per token instead of one per lane and token).
-template <int FI, int FJ, int WM>
+template <int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
 __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, bool tr) {
-    constexpr int TM = WM * 16 * FJ, TNB = 32 * FI;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
-    const bool compute_wave = threadIdx.x < 128 * WM;
+    constexpr int TM = WM * 16 * FJ, TNB = 16 * FI * WN;
+    const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6) - WOFF;   // WOFF leading waves are loader waves (mainloop_l)
+    const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
+    const bool compute_wave = w >= 0 && w < WN * WM;
     const bool spatial = p.qkv_mode == QKV_SPATIAL;
     constexpr int PN = (TNB / 8 + 7) / 8 * 8 * 16;   // LDS bytes per token row (q/k image): 16-byte chunks rounded up to 8
     constexpr int PT = (TM / 8 + 7) / 8 * 8 * 16;    // LDS bytes per feature row (V^T image)
@@ -596,24 +674,25 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
 // features 16 FI wn .. and tokens 16 FJ wm ..; acc[i][j] is the 16 x 16 MFMA tile (feature group i, token group j).
 // The bias of the non-transposed epilogues is fetched BEFORE the main loop (prefetch_bias): its L2 / HBM round trip used to
 // sit at the head of every epilogue.
-template <int EPI, int FI, int WM>
+template <int EPI, int FI, int WM, int WN = 2, int WOFF = 0>
 __device__ __forceinline__ void prefetch_bias(const GemmParams& p, int n0, f32x4 (&pbias)[FI]) {
-    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1, g = lane >> 4;
+    const int w = (int)(threadIdx.x >> 6) - WOFF;
+    const int lane = threadIdx.x & 63, wn = w % WN, g = lane >> 4;
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
         const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
         pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PARTIAL && p.bias && n < p.N && threadIdx.x < 128 * WM) pbias[i] = *(const f32x4*)(p.bias + n);
+        if (EPI != EPI_PARTIAL && p.bias && n < p.N && w >= 0 && w < WN * WM) pbias[i] = *(const f32x4*)(p.bias + n);
     }
 }
 
-template <int EPI, int FI, int FJ, int WM>
+template <int EPI, int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr) {
     constexpr int TM = WM * 16 * FJ;
-    constexpr int CT = FI / 2;                      // 64-feature sub-tiles per block tile row
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wn = w & 1, wm = w >> 1, li = lane & 15, g = lane >> 4;
-    const bool compute_wave = threadIdx.x < 128 * WM;
+    constexpr int CT = 16 * FI * WN / 64;           // 64-feature sub-tiles per block tile row
+    const int lane = threadIdx.x & 63, wraw = threadIdx.x >> 6, w = wraw - WOFF;   // WOFF leading waves are loader waves (mainloop_l)
+    const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
+    const bool compute_wave = w >= 0 && w < WN * WM;
     float amax = 0.f;
 
     if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
@@ -644,7 +723,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         __syncthreads();
         const int nkt_out = p.ldo >> 6, last_rt = (p.M - 1) >> 7;
         constexpr int PR = TM / 8;                      // 1-KiB pieces (8 token rows) per 64-feature sub-tile column
-        for (int q = w; q < CT * PR; q += (int)(blockDim.x >> 6)) {
+        for (int q = wraw; q < CT * PR; q += (int)(blockDim.x >> 6)) {
             const int cs = q / PR, pq = q - cs * PR;
             const int gr = m0 + 8 * pq;                 // first token row of the piece (m0 % 8 == 0)
             const int rt = gr >> 7;
@@ -659,7 +738,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     if constexpr (EPI == EPI_QKV) {
         // block-uniform: 8-token groups of a V^T row must not straddle attention items
         if (!GTAV_DBG(p, 16) && (p.qkv_mode == QKV_TEMPORAL || p.S % 8 == 0)) {
-            qkv_staged<FI, FJ, WM>(p, acc, pbias, smem, n0, m0, tr);
+            qkv_staged<FI, FJ, WM, WN, WOFF>(p, acc, pbias, smem, n0, m0, tr);
             return;
         }
     }
@@ -880,6 +959,240 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 || (WM == 4 && NS == 2)) ? 2 : 1
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Loader-wave GEMM (shapes 20+): the fills are issued by DEDICATED loader waves, the compute waves never touch global memory in
+// the K loop.
+//
+// Why (round-2 measurements, profiles/round2/ingest_bw.txt, gemm_dbg_r2b.txt): a CU takes L2-resident bytes in at ~64 B/clk
+// (124-134 GB/s) whether by LDS-DMA or by register loads — the two paths share that limit and do not add — and a wave that issues
+// an LDS-DMA instruction is held until the texture-address unit has accepted it.  In the all-waves-fill kernels above every wave
+// issues its share of the next tile right after the K-step barrier, so all waves sit in the address queue together (28 KB at
+// 64 B/clk = 450 cycles at M = 720) and only then start their 256-512 cycles of MFMAs: the two phases ADD (fc1 at M = 720: 10.2 us
+// with the MFMAs skipped, 13.7 us with them; main loop 8.5 us where either phase alone needs 3.5).  Here NL loader waves (one per
+// SIMD) own the fill stream and block in that queue on their own; WN x WM compute waves (two per SIMD, balanced) run
+// barrier -> fragment reads of tile t -> MFMAs of tile t - 1 (the one-step software pipeline of mainloop_g) and the K-step costs
+// max(ingest, MFMA) instead of their sum.  All waves meet at ONE s_barrier per K-step:
+//   loader  t: s_waitcnt vmcnt: its own pieces of tile t have landed            | barrier t | issue tile t + NS - 1 into slot (t - 1) % NS
+//   compute t: s_waitcnt lgkmcnt(0): its fragment reads of tile t - 1 are done  | barrier t | read tile t, MFMA tile t - 1
+// so after barrier t tile t is complete and visible and nobody reads tile t - 1 any more.  Loader waves take part in the epilogue's
+// barriers and in its copy-out loops (they have nothing else to do).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, typename AfterPrologue>
+__device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                           f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
+    static_assert(NS >= 3 && NL >= 1, "loader-wave ring: at least 3 stages and one loader wave");
+    constexpr int NCW = WN * WM;
+    constexpr int WPC = 2 * FI * WN, XPC = 2 * FJ * WM, NP = WPC + XPC;   // 1-KiB pieces per stage
+    constexpr int G = (NP + NL - 1) / NL;
+    constexpr int STAGE_BYTES = NP * 1024;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wraw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nktot = p.K / TK;
+    if (wraw < NL) {
+        // ------------------------------------------------ loader wave ------------------------------------------------
+        // The loader waves are the FIRST waves of the workgroup: a CU starts the waves of a workgroup one after the other (the
+        // twelfth wave of these blocks issued its first instruction 0.8-1.0 us after the first one, profiles/round2 stamps), and
+        // nothing can be computed before tile 0 is in LDS.  At this scale instructions count: a wave issues ~250 instructions in
+        // 0.5 us, so every piece address is a wave-uniform SGPR pair (operand base + tile offsets, scalar ALU) plus ONE constant
+        // per-lane offset (lane * 16) — the scalar-base form of the direct-to-LDS load — instead of a 64-bit per-lane pointer
+        // recomputed per piece.
+        const int lw = wraw;
+        const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
+        const unsigned voff = (unsigned)lane * 16u;
+        const unsigned smem0 = lds_offset(smem);
+        const char* sb[G];
+        unsigned ldso[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            int q = lw * G + i;
+            q = q < NP ? q : NP - 1;                         // the last wave repeats the final piece (same bytes, same place)
+            const bool isw = q < WPC;
+            const int row = isw ? n0 + 8 * q : m0 + 8 * (q - WPC);
+            int rt = row >> 7;
+            const int lim = isw ? last_wt : last_rt;
+            rt = rt < lim ? rt : lim;                        // ragged edges re-read a valid tile (results are masked)
+            sb[i] = (const char*)(isw ? p.W : p.X) + ((size_t)rt * nktot + kt0) * TILE_BYTES + ((row & 127) >> 3) * 1024;
+            ldso[i] = smem0 + q * 1024;
+        }
+        auto stage = [&](int t) {
+            const unsigned so = (unsigned)(t % NS) * STAGE_BYTES;
+            const size_t go = (size_t)t * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < G; ++i) glds16_s(sb[i] + go, voff, ldso[i] + so);
+        };
+        const int npro = nkt < NS - 1 ? nkt : NS - 1;
+#ifdef GTAV_EXPERIMENTS
+        if (p.stamps && lw == 0 && lane == 0) p.stamps[(size_t)blockIdx.x * ((p.debug & 32) ? 64 : 8) + 7] = __builtin_amdgcn_s_memrealtime();   // first loader: first fill issued now
+#endif
+        for (int t = 0; t < npro; ++t) stage(t);
+        for (int t = 0; t < nkt; ++t) {
+            wait_vm_ring<NS, G>(nkt - 1 - t);                // this wave's share of tile t has landed
+#ifdef GTAV_EXPERIMENTS
+            if (t == 0 && p.stamps && lw == 0 && lane == 0) p.stamps[(size_t)blockIdx.x * ((p.debug & 32) ? 64 : 8) + 6] |= (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFFFull) << 8;   // its tile-0 share landed
+#endif
+            wg_barrier();
+            if (t == 0) GTAV_STAMP(bs.t[1]);
+#ifdef GTAV_EXPERIMENTS
+            // detailed mode (debug bit 5; the tool then gives every block 64 slots): slot 8 + t = loader 0 past barrier t
+            if ((p.debug & 32) && p.stamps && lw == 0 && lane == 0 && t < 24) p.stamps[(size_t)blockIdx.x * 64 + 8 + t] = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (t + NS - 1 < nkt && !GTAV_DBG(p, 1)) stage(t + NS - 1);
+        }
+        return;
+    }
+    // ------------------------------------------------ compute wave ------------------------------------------------
+    const int w = wraw - NL;
+    const int wn = w % WN, wm = w / WN;
+    const int li = lane & 15, g = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = (16 * FI * wn + li) * 128 + ch;
+        xoff[s] = WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
+    }
+    after_prologue();   // register loads the epilogue wants early (bias)
+    auto rd = [&](int t, f16x8 (&wf)[2][FI], f16x8 (&xf)[2][FJ]) {
+        const char* b = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i) wf[s][i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) xf[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
+        }
+    };
+    auto mm = [&](const f16x8 (&wf)[2][FI], const f16x8 (&xf)[2][FJ]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                }
+    };
+    if constexpr (FI * FJ >= 16) {
+        // Large wave tiles (64 x 64: 16 MFMAs per 32-deep half of a K-step): pipeline by HALF K-steps with one register set per half —
+        //   barrier t | read (t, half 0) -> A | MFMA (t - 1, half 1) from B | read (t, half 1) -> B | MFMA (t, half 0) from A
+        // every batch of reads is in flight under 16 MFMAs (256 cycles), the fragments cost (FI + FJ) x 8 registers instead of the
+        // x 16 of two whole-K-step sets (the 256 x 128 tile then fits the 168 registers three waves per SIMD leave).
+        f16x8 wa[FI], xa[FJ], wb[FI], xb[FJ];
+        auto rdh = [&](int t, int sh, f16x8 (&wf)[FI], f16x8 (&xf)[FJ]) {
+            const char* b = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) wf[i] = *(const f16x8*)(b + woff[sh] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) xf[j] = *(const f16x8*)(b + xoff[sh] + j * 16 * 128);
+        };
+        auto mmh = [&](const f16x8 (&wf)[FI], const f16x8 (&xf)[FJ]) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[j], wf[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                }
+        };
+        const bool domm = !GTAV_DBG(p, 2);
+        for (int t = 0; t < nkt; ++t) {
+            wait_lgkm0();
+            wg_barrier();
+            if (t == 0) GTAV_STAMP(bs.t[1]);
+            // the FI + FJ fragment reads of one half are issued BETWEEN the FI x FJ MFMAs of the other half (one read per MFMA, in
+            // the MFMA's issue shadow) instead of as a block in front of them: a block of 7-8 ds_read_b128 holds the wave's issue
+            // for ~60 cycles in which the matrix pipe drains, twice per K-step
+            if (t > 0) {
+                rdh(t, 0, wa, xa);
+                if (domm) mmh(wb, xb);
+                interleave_mfma_dsread<FI * FJ, FI + FJ>();
+            } else {
+                rdh(t, 0, wa, xa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rdh(t, 1, wb, xb);
+            if (domm) mmh(wa, xa);
+            interleave_mfma_dsread<FI * FJ, FI + FJ>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (domm) mmh(wb, xb);
+    } else {
+        f16x8 wA[2][FI], xA[2][FJ], wB[2][FI], xB[2][FJ];
+        auto step = [&](int t, f16x8 (&wr)[2][FI], f16x8 (&xr)[2][FJ], const f16x8 (&wm_)[2][FI], const f16x8 (&xm_)[2][FJ]) {
+#ifdef GTAV_EXPERIMENTS
+            if ((p.debug & 32) && p.stamps && w == 0 && lane == 0 && t < 24) p.stamps[(size_t)blockIdx.x * 64 + 32 + t] = __builtin_amdgcn_s_memrealtime();   // compute wave 0 arrives at barrier t
+#endif
+            wait_lgkm0();
+            wg_barrier();
+            if (t == 0) GTAV_STAMP(bs.t[1]);
+            if (t > 0 && !GTAV_DBG(p, 2)) {
+                rd(t, wr, xr);
+                mm(wm_, xm_);
+                interleave_mfma_dsread<2 * FI * FJ, 2 * (FI + FJ), 1>();   // one read in each of the first MFMAs' issue shadows
+            } else {
+                rd(t, wr, xr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int t = 0;
+        for (; t + 1 < nkt; t += 2) {
+            step(t, wA, xA, wB, xB);
+            step(t + 1, wB, xB, wA, xA);
+        }
+        if (t < nkt) {
+            step(t, wA, xA, wB, xB);
+            if (!GTAV_DBG(p, 2)) mm(wA, xA);
+        } else if (!GTAV_DBG(p, 2)) {
+            mm(wB, xB);
+        }
+    }
+}
+
+template <int EPI, int NS, int FI, int FJ, int WN, int WM, int NL>
+__global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmParams p) {
+    constexpr int TNB = 16 * FI * WN, TM = 16 * FJ * WM;
+    constexpr int STAGE = (2 * FI * WN + 2 * FJ * WM) * 1024;
+    // ring, or the QKV epilogue's pitched LDS image + token table (qkv_staged), whichever is larger
+    constexpr int PNB = (TNB / 8 + 7) / 8 * 8 * 16, PTB = (TM / 8 + 7) / 8 * 8 * 16;
+    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem_l[];
+    static_assert(NS * STAGE >= EPIB, "the ring must cover the epilogue's LDS image");
+    char* smem = smem_l;
+    // Every kernel argument the prologue needs is fetched HERE, in one batch of scalar loads behind one wait.  Left to itself hipcc
+    // loads GemmParams field by field in the basic blocks that use them: five to six dependent s_load / s_waitcnt lgkmcnt(0) round
+    // trips (100-200 ns each from a cold scalar cache) in front of the loaders' first fill (first fill 0.5-0.6 us after block entry,
+    // profiles/round2 stamps).  The empty asm statements are uses that pin the loads to this point.
+#define GTAV_PIN_S(x) asm volatile("" ::"s"(x))
+    GTAV_PIN_S(p.X); GTAV_PIN_S(p.W); GTAV_PIN_S(p.M); GTAV_PIN_S(p.N); GTAV_PIN_S(p.K); GTAV_PIN_S(p.splitk);
+    GTAV_PIN_S(p.tm.tiles_m); GTAV_PIN_S(p.tm.tiles_n); GTAV_PIN_S(p.tm.gn); GTAV_PIN_S(p.tm.group); GTAV_PIN_S(p.tm.tiles);
+    GTAV_PIN_S(p.tm.rcp_tiles); GTAV_PIN_S(p.tm.rcp_group); GTAV_PIN_S(p.tm.rcp_gn); GTAV_PIN_S(p.tm.rcp_gnlast);
+    GTAV_PIN_S(p.bias); GTAV_PIN_S(p.out); GTAV_PIN_S(p.ldo); GTAV_PIN_S(p.qkv_mode); GTAV_PIN_S(p.D);
+#undef GTAV_PIN_S
+    BlockStamps bs;
+    bs.begin(p);
+    int n0, m0, ks, kt0, nkt;
+    tile_map_fast<EPI == EPI_PARTIAL, TNB, TM>(p, n0, m0, ks, kt0, nkt);
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool tr = false;
+    f32x4 pbias[FI];
+    auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
+    if constexpr (EPI == EPI_QKV) {
+        tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+        if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    } else {
+        mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    }
+    GTAV_STAMP(bs.t[2]);
+    epilogue<EPI, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
+    bs.end(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Persistent ping-pong GEMM for large M (shape 16): one 1024-thread block per CU, two groups of 8 waves.
 //
 // What the stamps of round 2 showed for the two-blocks-per-CU shape at M = 5760 (profiles/round2/stamps_*.txt): the 512
@@ -1010,9 +1323,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_pp_kernel(GemmParams p) {
                 for (int k = 0; k < P; ++k) {
                     const int rem = P - 1 - k;
                     // this wave's share of K-step k has landed (younger fills of this wave: min(NS - 2, rem) K-steps of G)
-                    if (NS >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * G) : "memory");
-                    else if (NS >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(G) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    kstep_sync_ring<(NS < 4 ? NS : 4), G>(rem);
                     const bool refill = k + NS - 1 < P;      // the last NS - 1 slots belong to the next tile (filled by the other group)
                     int fslot = slot + NS - 1;
                     fslot = fslot >= NS ? fslot - NS : fslot;
@@ -1259,6 +1570,7 @@ static int device_cus(int* dev_out) {
 // fc1 at M = 5760: 71-76 us against 57 us for shape 12.  Not selected by the heuristic (GTAV_PP=1 in the experiments build or a
 // forced shape 16 run it); the de-phased shape 12 above gets the same overlap with 16 computing waves.
 static int g_pp_enable = GTAV_ENV_INT("GTAV_PP", 0);
+static int g_l_for_8 = GTAV_ENV_INT("GTAV_L_FOR_8", 1);   // experiments build: 0 keeps the 96 x 96 tile (shape 8) where the cost model picks it
 bool gemm_pp_ok(int M, int N, int K, int epi) {
     if (!(epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_QKV || epi == EPI_RESID)) return false;
     if (K % TK != 0 || K / TK < 14 || M % 8 != 0 || N % 8 != 0) return false;
@@ -1284,8 +1596,46 @@ static int launch_pp(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+// loader-wave kernels: dynamic LDS above 64 KiB needs the per-device opt-in once per instantiation
+template <int EPI, int NS, int FI, int FJ, int WN, int WM, int NL>
+static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
+    constexpr int LDS = NS * (2 * FI * WN + 2 * FJ * WM) * 1024;
+    static unsigned long long attr_devs = 0;
+    int dev = 0;
+    GTAV_REQUIRE(device_cus(&dev) > 0, "gemm: no current device");
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_l_kernel<EPI, NS, FI, FJ, WN, WM, NL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_devs |= 1ull << (dev & 63);
+    }
+    GemmParams q = p;
+    {
+        GemmParams::TileMap& tm = q.tm;
+        tm.tiles_m = cdiv(p.M, 16 * FJ * WM);
+        tm.tiles_n = cdiv(p.N, 16 * FI * WN);
+        tm.tiles = tm.tiles_m * tm.tiles_n;
+        tm.gn = tm.tiles_n >= 8 ? tm.tiles_n >> 3 : 1;
+        tm.group = tm.tiles_m * tm.gn;
+        const int gnlast = tm.tiles_n % tm.gn ? tm.tiles_n % tm.gn : tm.gn;
+        auto rcp = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };   // ceil(2^32 / d), d >= 2
+        GTAV_REQUIRE((long long)tm.tiles * splitk < 65536, "gemm: grid of %d tiles x %d slices is too large for the 32-bit reciprocal tile map", tm.tiles, splitk);
+        // a divisor of 1 has no 32-bit reciprocal (it would be 2^32): 0 encodes it, div_rcp() then returns its argument
+        tm.rcp_tiles = tm.tiles > 1 ? rcp(tm.tiles) : 0;
+        tm.rcp_group = tm.group > 1 ? rcp(tm.group) : 0;
+        tm.rcp_gn = tm.gn > 1 ? rcp(tm.gn) : 0;
+        tm.rcp_gnlast = gnlast > 1 ? rcp(gnlast) : 0;
+    }
+    const dim3 grid(q.tm.tiles * splitk);
+    GTAV_LAUNCH((gemm_l_kernel<EPI, NS, FI, FJ, WN, WM, NL>), grid, dim3(64 * (WN * WM + NL)), LDS, stream, q);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int EPI>
 static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
+    if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
+    if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
+    if (shape == 23) return launch_l<EPI, 4, 4, 3, 2, 2, 4>(p, splitk, stream);   // 128 x 96, 4 compute waves of 64 x 48 + 4 loader waves
+    if (shape == 25) return launch_l<EPI, 5, 2, 3, 4, 2, 4>(p, splitk, stream);   // shape 20 with a 5-stage ring (140 KiB)
     if (shape == 16) {
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_QKV || EPI == EPI_RESID) {
             GTAV_REQUIRE(gemm_pp_ok(p.M, p.N, p.K, EPI) || (p.K / TK >= 12 && p.M % 8 == 0 && p.N % 8 == 0),
@@ -1333,7 +1683,7 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_debug & (3 | 16);   // bit 4: direct (unstaged) QKV epilogue
+    p.debug = g_debug & (3 | 16 | 32);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
     p.stamps = nullptr;
 #ifdef GTAV_EXPERIMENTS
     p.stamps = g_stamps;            // the tool sizes the buffer for the largest grid it launches (g_stamp_blocks)
@@ -1384,6 +1734,9 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         if (cost(64, 96) < best) best = cost(64, 96), wm = 14;   // M = 288-320 (g256 window step, batch-2 cached step)
         if (cost(64, 48) < best) best = cost(64, 48), wm = 11;
     }
+    // Round 2: the 128 x 96 tile runs on the loader-wave kernel (shape 20: 4 loader + 8 compute waves, fills and MFMAs overlap by
+    // construction): QKV 14.1 -> 10.7 us, fc1 13.3 -> 10.9, fc2 12.0 -> 10.2, out-proj 6.6 -> 6.1 at M = 720 (profiles/round2).
+    if (!g_force_wm && !(g_debug & 64) && (wm == 9 || (wm == 8 && g_l_for_8))) wm = (g_debug & 128) ? 25 : 20;   // debug bit 6 (experiments build): round-1 shapes, for A/B runs in one process
     if (!g_force_wm && wm == 2 && cdiv(p.M, 192) * cdiv(p.N, 128) * splitk >= 320) {
         // large M: 128 x 192 tiles (4 waves of 64 x 96, still two blocks per CU) move 17 % fewer fill bytes per FLOP than
         // 128 x 128: QKV 62.6 -> 55.5 us, fc1 63.8 -> 61.1 us at M = 5760 (profiles/round1/v17_gemm_128x192_microbench.txt);

@@ -293,7 +293,7 @@ def test_gemm_8wave_tile_matches(M, N, K):
         lib.gtav_op_gemm_set_stages(0)
 
 
-@pytest.mark.parametrize("shape", [7, 8, 9, 11, 12, 14])
+@pytest.mark.parametrize("shape", [7, 8, 9, 11, 12, 14, 20, 21, 23])
 def test_gemm_other_tiles_all_epilogues(shape):
     """Block shapes 7 (256 x 256, phased K-tile, mainloop256), 8 (96 x 96) and 9 (128 features x 96 tokens; piece-granular
     mainloop_g) through every epilogue they support, incl. ragged token and feature edges, K of one and two tiles

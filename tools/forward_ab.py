@@ -1,0 +1,66 @@
+"""A/B of GEMM shape selections on the REAL DiT forward in ONE process on ONE GPU (boxes differ by up to ~10 % in MFMA-bound kernels,
+so numbers from different gpurun calls do not compare).  Experiments build; alternates the variants `--rounds` times.
+Usage (GPU box): python tools/forward_ab.py [--batch 1] [--variants 0 64]   (variant = gemm debug bits; 64 = round-1 shapes)"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from gtav_amd import lib as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--variants", type=int, nargs="+", default=[0, 64])
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--actions", action="store_true")
+    ap.add_argument("--depth", type=int, default=16, help="fewer blocks: the weights then stay in the 256 MiB Infinity Cache between forwards")
+    a = ap.parse_args()
+    lib = L.load_experiments()
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT_models
+    dev = torch.device("cuda", 0)
+    B = a.batch
+    from gtav_amd.model.dit import DiT
+    dit = DiT(depth=a.depth, init_weights=False, max_batch=B)
+    dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=a.depth), seed=0))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 5, 16, 18, 32, generator=g).to(dev)
+    t = torch.tensor([[15, 15, 15, 15, 500]] * B)
+    act = None
+    if a.actions:
+        act = torch.zeros(B, 5, 25, device=dev)
+        act[:, :, 3] = 1
+    ref = None
+    for r in range(a.rounds):
+        for v in a.variants:
+            lib.gtav_op_gemm_set_debug(v)
+            for _ in range(3):
+                out = dit(x, t, act)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = out.clone()
+            err = ((out - ref).norm() / ref.norm()).item()
+            t0 = time.perf_counter()
+            n = 20
+            for _ in range(n):
+                dit(x, t, act)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            dit.profile(True)
+            for _ in range(4):
+                dit(x, t, act)
+            torch.cuda.synchronize()
+            prof = dit.profile_read()
+            dit.profile(False)
+            cls = " ".join(f"{k.replace('gemm_', '')}={v[0] / max(v[1], 1) * 1e3:.2f}" for k, v in prof.items() if v[1] and k != "empty_event_pair")
+            print(f"round {r} variant {v:3d}: forward {ms:.3f} ms (rel diff vs first {err:.1e}) | us per launch: {cls}", flush=True)
+    lib.gtav_op_gemm_set_debug(0)
+
+
+if __name__ == "__main__":
+    main()

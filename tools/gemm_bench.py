@@ -25,7 +25,7 @@ def main():
     lib = L.load_experiments()   # libgtav_amd_exp.so: the debug bits below exist only in that build
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
-    shapes = [("qkv", 3072, 1024, 5), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]
+    shapes = [("qkv", 3072, 1024, 5), ("qkvt", 3072, 1024, 7), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]   # epi 7 here = temporal QKV
     if "floor" in a.only:   # one K-step only: launch + first tile + epilogue (the per-launch floor of each epilogue)
         shapes += [("floor_gelu", 4096, 64, 2), ("floor_f32", 4096, 64, 0), ("floor_part", 1024, 64, 6), ("floor_n128", 128, 64, 0)]
     print(f"{'shape':>5} {'M':>6} {'N':>5} {'K':>5} {'ns':>3} {'split':>5} {'us':>9} {'TFLOP/s':>9}")
@@ -44,6 +44,7 @@ def main():
             q = torch.empty(3, M, 1024, device=dev, dtype=torch.float16)
             cs = torch.ones(144, 64, device=dev)
             sn = torch.zeros(144, 64, device=dev)
+            kvc = torch.empty(max(1, M // 720) * 5 * 144 * 2 * 1024, device=dev, dtype=torch.float16)
             for ns, dbg, wm in [(n_, d_, w_) for w_ in a.wm for n_ in a.stages for d_ in a.debug]:
                 lib.gtav_op_gemm_set_stages(ns)
                 lib.gtav_op_gemm_set_debug(dbg)
@@ -55,6 +56,12 @@ def main():
                         Mq = (M // 144) * 144
                         L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Mq, 1024, 0, q[0].data_ptr(), q[1].data_ptr(),
                                                      q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), st))
+                    elif epi == 7:      # temporal layout: q [M][D], k/v into a [B][Tmax][P][2][D] cache (B = 1 here, Tq = M / 144 frames)
+                        Tq = M // 144
+                        Bq = max(1, Tq // 5)
+                        Tq = min(Tq, 5)
+                        L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Bq * Tq * 144, 1024, 1, q[0].data_ptr(), kvc.data_ptr(),
+                                                     kvc.data_ptr(), 144, Tq, 0, 5, cs.data_ptr(), st))
                     elif epi == 6:
                         g = lib.gtav_op_gemm_splitk_ln  # noqa: F841  (partial GEMM only: use the raw op below)
                         L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), 0, out.data_ptr(), N, M, N, K, 6, 0, sk, 1, st))

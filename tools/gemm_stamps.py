@@ -86,6 +86,8 @@ def main():
                 s = rows[-1]
                 nb = s.shape[0]
                 t0, t1, t2, t3, c0, c1, xcc = (s[:, i] for i in range(7))     # t*: s_memrealtime (100 MHz); c*: s_memtime (cycles)
+                lstart, lland = s[:, 7], xcc >> 8            # loader-wave kernels: last loader's first issue / its tile-0 pieces landed
+                xcc = xcc & 0xF
                 span_us = float(t3.max() - t0.min()) / 100.0
                 cyc_per_us = float(torch.median((c1 - c0).double() / (t3 - t0).clamp_min(1).double())) * 100.0
                 f = lambda c: c.double() / 100.0            # 10 ns ticks -> us
@@ -102,6 +104,11 @@ def main():
                       f"span {span_us:6.2f} us, clock {cyc_per_us / 1e3:.2f} GHz, XCDs used {len(set(xcc.tolist()))}")
                 print(f"      block start after first: med {pct(start, .5):6.2f} p90 {pct(start, .9):6.2f} max {float(start.max()):6.2f} us")
                 print(f"      prologue (entry -> first K-tile landed): med {pct(pro, .5):5.2f} p90 {pct(pro, .9):5.2f} us")
+                if int(lstart.max()) != 0:
+                    ls = (lstart - t0).double() / 100.0
+                    ll = ((lland - (t0 & 0xFFFFFFFFFFFF)).double()) / 100.0
+                    print(f"      last loader wave: first fill issued {pct(ls, .5):5.2f} us after block entry (p90 {pct(ls, .9):5.2f}); its tile-0 pieces landed at "
+                          f"{pct(ll, .5):5.2f} (p90 {pct(ll, .9):5.2f})")
                 print(f"      main loop:                               med {pct(main_, .5):5.2f} p90 {pct(main_, .9):5.2f} us")
                 print(f"      epilogue:                                med {pct(epi_, .5):5.2f} p90 {pct(epi_, .9):5.2f} us")
                 print(f"      block total:                             med {pct(tot, .5):5.2f} p90 {pct(tot, .9):5.2f} us   (sum of block time / 256 CUs / span = "
