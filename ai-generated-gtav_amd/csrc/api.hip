@@ -62,6 +62,11 @@ struct Slot {
     int c0;          // f32: column offset in destination
     bool set = false;
     bool required = true;
+    // training (gtav_dit_train_enable): fp32 master copy (f16 slots; f32 slots train in place), gradient (contiguous [R][C], a
+    // slice of the gradient arena), AdamW moments, and for f16 GEMM weights the tile-major copy of the TRANSPOSE (dX = dY W)
+    float *master = nullptr, *grad = nullptr, *am = nullptr, *av = nullptr;
+    f16* wT = nullptr;
+    bool trainable = false;
 };
 
 struct WeightTable {
@@ -80,6 +85,8 @@ struct WeightTable {
                      (long long)numel, sl.R, sl.C);
         if (sl.kind == SLOT_F16_PAD) RET_IF(launch_convert_pad_f16(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, 1, s));
         else RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, (float*)sl.dst, sl.Cp, sl.c0, s));
+        if (sl.master && sl.kind == SLOT_F16_PAD) RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, sl.master, sl.C, 0, s));
+        if (sl.wT) RET_IF(launch_convert_T_f16(src, sl.C, sl.R, sl.C, sl.wT, s));
         sl.set = true;
         return 0;
     }
@@ -88,7 +95,8 @@ struct WeightTable {
         GTAV_REQUIRE(it != slots.end(), "get_weight: unknown key '%s'", name);
         Slot& sl = it->second;
         GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "get_weight: '%s' size mismatch", name);
-        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_unpad_f16_to_f32((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, 1, s));
+        if (sl.kind == SLOT_F16_PAD && sl.master) RET_IF(launch_copy_f32_strided(sl.master, sl.C, sl.R, sl.C, dst, sl.C, s));   // training: the fp32 master
+        else if (sl.kind == SLOT_F16_PAD) RET_IF(launch_unpad_f16_to_f32((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, 1, s));
         else RET_IF(launch_copy_f32_strided((const float*)sl.dst + sl.c0, sl.Cp, sl.R, sl.C, dst, sl.C, s));
         return 0;
     }
@@ -274,6 +282,24 @@ struct gtav_dit {
     float* ac_table = nullptr;  // alphas_cumprod [1000]
     std::vector<float> ac_host;
     bool finalized = false;
+    // ---- training: saved activations of the last training forward, backward workspace, optimizer state ----
+    struct Train {
+        bool on = false, have_fwd = false, have_actions = false;
+        int B = 0, T = 0, M = 0, Mp = 0, rows = 0;
+        float loss_scale = 65536.0f;
+        long step = 0;
+        std::vector<Slot*> params;          // trainable slots in a fixed (sorted-by-name) order
+        float* grad_arena = nullptr;        // all gradients, contiguous (one all-reduce); caller-owned when passed to train_enable
+        size_t grad_count = 0;
+        float* ctl = nullptr;               // [8]: sumsq, step coefficient, skipped steps, grad norm
+        std::vector<float*> res;            // residual states r_0 .. r_4L, fp32 [M][D]
+        struct HB { f16 *xnA, *ao, *y1, *xnB, *u, *hh, *y2, *q, *k, *v; };   // per half-block (spatial: q, k = [nb][head][S][64], v = Vt; temporal: q [M][D], k = kv cache)
+        std::vector<HB> hb;
+        f16 *xnF = nullptr, *xp = nullptr;
+        float *z0 = nullptr, *cpre = nullptr;                   // pre-SiLU values of the conditioning path
+        float *dres = nullptr, *dtmp = nullptr, *stats = nullptr, *dmod = nullptr, *dSc = nullptr, *dc = nullptr, *dh0 = nullptr, *dz0 = nullptr;
+        f16 *g_d = nullptr, *g_h = nullptr, *g_u = nullptr, *g_qkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dfo = nullptr;
+    } tr;
 };
 
 static int dit_cond(gtav_dit* h, const int64_t* t64, int rows, int Tq, const StepParams* sp, int use_cur, const float* actions,
@@ -698,6 +724,350 @@ int gtav_dit_profile(gtav_dit* h, int32_t enable) {
 int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class) {
     GTAV_REQUIRE(h && ms_by_class && launches_by_class, "dit_profile_read: null argument");
     for (int i = 0; i < PC_COUNT; ++i) { ms_by_class[i] = h->prof.ms[i]; launches_by_class[i] = h->prof.n[i]; }
+    return 0;
+}
+
+
+// ================================================================================================
+// DiT training step: forward with saved activations, backward, AdamW.
+// Reference: train_dit.py:649-650 (forward + mse), :680 accelerator.backward, :232-238 AdamW(betas 0.9 / 0.999, eps 1e-7),
+// :965-970 clip_grad_norm_ / optimizer.step / zero_grad.  Mixed precision like the reference's bf16 autocast + fp32 master
+// weights, with fp16 operands and a loss scale in place of bf16's exponent range: activation gradients travel as fp16 GEMM
+// operands multiplied by tr.loss_scale, weight gradients / LayerNorm statistics / the residual-stream gradient are fp32.
+// ================================================================================================
+int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena_numel) {
+    GTAV_REQUIRE(h, "train_enable: null handle");
+    GTAV_REQUIRE(!h->tr.on, "train_enable: already enabled");
+    for (auto& kv : h->wt.slots) GTAV_REQUIRE(!kv.second.set, "train_enable: call it before any gtav_dit_set_weight (the fp32 masters are filled by set_weight)");
+    gtav_dit::Train& t = h->tr;
+    Arena& a = h->arena;
+    const int D = h->D, L = h->L, Hp = h->Hm_pad;
+    GTAV_REQUIRE(h->Hm == h->Hm_pad && h->Kpe == h->C * h->p * h->p, "train_enable: padded MLP width / patch size are not implemented for training");
+    size_t count = 0;
+    std::vector<std::string> names;
+    for (auto& kv : h->wt.slots) {
+        const std::string& n = kv.first;
+        if (n.rfind("tables.", 0) == 0 || n.find("rotary_emb.freqs") != std::string::npos) continue;   // constants (requires_grad False upstream)
+        kv.second.trainable = true;
+        t.params.push_back(&kv.second);
+        names.push_back(n);
+        count += (size_t)kv.second.R * kv.second.C;
+    }
+    t.grad_count = count;
+    if (grad_arena_dev) {
+        GTAV_REQUIRE(grad_arena_numel == (int64_t)count, "train_enable: the gradient arena has %lld elements, the model has %lld trainable parameters",
+                     (long long)grad_arena_numel, (long long)count);
+        t.grad_arena = grad_arena_dev;
+    } else {
+        RET_IF(a.alloc_t(&t.grad_arena, count));
+    }
+    size_t off = 0;
+    for (size_t pi = 0; pi < t.params.size(); ++pi) {
+        Slot* sl = t.params[pi];
+        const size_t n = (size_t)sl->R * sl->C;
+        sl->grad = t.grad_arena + off;
+        off += n;
+        RET_IF(a.alloc_t(&sl->am, n));
+        RET_IF(a.alloc_t(&sl->av, n));
+        if (sl->kind == SLOT_F16_PAD) {
+            RET_IF(a.alloc_t(&sl->master, n));
+            if (names[pi] != "x_embedder.proj.weight")   // every GEMM weight but the patch embedding needs W^T for dX
+                RET_IF(a.alloc_t(&sl->wT, (size_t)round_up(sl->C, 128) * round_up(sl->R, 64)));
+        } else {
+            sl->master = (float*)sl->dst + sl->c0;
+        }
+    }
+    RET_IF(a.alloc_t(&t.ctl, 8));
+    const size_t Mx = round_up(h->Mmax, 128), Mp = round_up(h->Mmax, 64), Mm = h->Mmax;
+    t.res.resize(4 * L + 1);
+    for (auto& r : t.res) RET_IF(a.alloc_t(&r, Mx * D));
+    t.hb.resize(2 * L);
+    for (int i = 0; i < 2 * L; ++i) {
+        gtav_dit::Train::HB& b = t.hb[i];
+        RET_IF(a.alloc_t(&b.xnA, Mx * D)); RET_IF(a.alloc_t(&b.ao, Mx * D)); RET_IF(a.alloc_t(&b.y1, Mx * D)); RET_IF(a.alloc_t(&b.xnB, Mx * D));
+        RET_IF(a.alloc_t(&b.u, Mx * Hp)); RET_IF(a.alloc_t(&b.hh, Mx * Hp)); RET_IF(a.alloc_t(&b.y2, Mx * D));
+        RET_IF(a.alloc_t(&b.q, Mx * D));
+        if (i % 2 == 0) { RET_IF(a.alloc_t(&b.k, Mx * D)); RET_IF(a.alloc_t(&b.v, Mx * D)); }
+        else { RET_IF(a.alloc_t(&b.k, Mx * 2 * D)); b.v = b.k; }
+    }
+    RET_IF(a.alloc_t(&t.xnF, Mx * D)); RET_IF(a.alloc_t(&t.xp, Mx * h->Kpe));
+    const size_t R = h->max_rows;
+    RET_IF(a.alloc_t(&t.z0, R * D)); RET_IF(a.alloc_t(&t.cpre, R * D));
+    RET_IF(a.alloc_t(&t.dres, Mx * D)); RET_IF(a.alloc_t(&t.dtmp, Mx * D)); RET_IF(a.alloc_t(&t.stats, 2 * Mx));
+    RET_IF(a.alloc_t(&t.dmod, R * h->MODW)); RET_IF(a.alloc_t(&t.dSc, R * D)); RET_IF(a.alloc_t(&t.dc, R * D)); RET_IF(a.alloc_t(&t.dh0, R * D));
+    RET_IF(a.alloc_t(&t.dz0, R * D));
+    RET_IF(a.alloc_t(&t.g_d, Mx * D)); RET_IF(a.alloc_t(&t.g_h, Mx * Hp)); RET_IF(a.alloc_t(&t.g_u, Mx * Hp)); RET_IF(a.alloc_t(&t.g_qkv, Mx * 3 * D));
+    RET_IF(a.alloc_t(&t.dao, Mm * D)); RET_IF(a.alloc_t(&t.dfo, Mx * 64));
+    const size_t widest = (size_t)(Hp > 3 * D ? Hp : 3 * D);
+    RET_IF(a.alloc_t(&t.tA, widest * Mp)); RET_IF(a.alloc_t(&t.tB, widest * Mp));
+    t.on = true;
+    return 0;
+}
+
+int gtav_dit_train_param_count(gtav_dit* h, int64_t* numel) {
+    GTAV_REQUIRE(h && numel, "train_param_count: null argument");
+    int64_t c = 0;
+    for (auto& kv : h->wt.slots) {
+        const std::string& n = kv.first;
+        if (n.rfind("tables.", 0) == 0 || n.find("rotary_emb.freqs") != std::string::npos) continue;
+        c += (int64_t)kv.second.R * kv.second.C;
+    }
+    *numel = c;
+    return 0;
+}
+
+int gtav_dit_set_loss_scale(gtav_dit* h, float scale) {
+    GTAV_REQUIRE(h && scale > 0.f, "set_loss_scale: bad argument");
+    h->tr.loss_scale = scale;
+    return 0;
+}
+
+int gtav_dit_zero_grad(gtav_dit* h, void* stream) {
+    GTAV_REQUIRE(h && h->tr.on, "zero_grad: training is not enabled");
+    GTAV_CHECK_HIP(hipMemsetAsync(h->tr.grad_arena, 0, h->tr.grad_count * sizeof(float), (hipStream_t)stream));
+    return 0;
+}
+
+// raw (loss-scaled) gradient of one parameter, torch layout; the caller divides by the loss scale
+int gtav_dit_get_grad(gtav_dit* h, const char* name, float* dst, int64_t numel, void* stream) {
+    GTAV_REQUIRE(h && name && dst && h->tr.on, "get_grad: bad argument / training is not enabled");
+    auto it = h->wt.slots.find(name);
+    GTAV_REQUIRE(it != h->wt.slots.end() && it->second.grad, "get_grad: '%s' is not a trainable parameter", name);
+    GTAV_REQUIRE(numel == (int64_t)it->second.R * it->second.C, "get_grad: '%s' size mismatch", name);
+    GTAV_CHECK_HIP(hipMemcpyAsync(dst, it->second.grad, numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int gtav_dit_train_forward(gtav_dit* h, const float* x, const int64_t* t64, const float* actions, float* out, int32_t B, int32_t T, void* stream) {
+    GTAV_REQUIRE(h && x && t64 && out, "train_forward: null argument");
+    GTAV_REQUIRE(h->tr.on && h->finalized, "train_forward: call gtav_dit_train_enable, load the weights and finalize first");
+    GTAV_REQUIRE(B >= 1 && B <= h->maxB && T >= 1 && T <= h->maxT, "train_forward: B=%d T=%d outside capacity (%d, %d)", B, T, h->maxB, h->maxT);
+    GTAV_REQUIRE(!actions || h->A > 0, "train_forward: model has no external_cond");
+    hipStream_t s = (hipStream_t)stream;
+    gtav_dit::Train& tr = h->tr;
+    const int D = h->D, P = h->P, NB = B * T, M = NB * P, L = h->L, rows = NB, ldhc = D + h->Apad;
+    h->prepared.valid = false;
+    h->kvrec.valid = false;
+    // conditioning path with its pre-activations kept (dit_cond applies SiLU inside the skinny GEMM)
+    RET_IF(launch_cond_inputs(t64, rows, 1, nullptr, 0, h->sincos, h->E, actions, h->A, 0, h->A, h->HC, ldhc, D, h->Apad, h->err_flag, s));
+    RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, tr.z0, D, rows, D, 256, 0, s));
+    RET_IF(launch_silu(tr.z0, D, h->HC, ldhc, rows, D, s));
+    RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, tr.cpre, D, rows, D, ldhc, 0, s));
+    RET_IF(launch_silu(tr.cpre, D, h->Sc, D, rows, D, s));
+    RET_IF(launch_skinny_f32(h->Sc, D, h->w_ada, h->b_ada, h->mod, h->MODW, rows, h->MODW, D, 0, s));
+    const float* mod = h->mod;
+    RET_IF(launch_patchify(x, nullptr, NB, h->C, h->H, h->W, h->p, tr.xp, h->Kpe, 1.f, 0.f, h->err_flag, s));
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = tr.xp; g.ldx = h->Kpe; g.W = h->w_pe; g.M = M; g.N = D; g.K = h->Kpe; g.bias = h->b_pe; g.out = tr.res[0]; g.ldo = D;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    LnPending pend;
+    bool have_pend = false;
+    auto resid_gemm = [&](const f16* X, const f16* Wt, int K, const float* bias, const float* gate, float* x_out, f16* y_save) -> int {
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = X; q.ldx = K; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
+        q.splitk = gemm_choose_splitk(M, D, K);
+        GTAV_REQUIRE((size_t)q.splitk * M <= h->parts_rows, "split-K slabs exceed workspace");
+        RET_IF(launch_gemm(q, EPI_PARTIAL, s));
+        memset(&pend, 0, sizeof(pend));
+        pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * D; pend.ld = D; pend.bias = bias;
+        pend.gate = gate; pend.gate_stride = h->MODW; pend.gate_rows = nullptr; pend.rows_per_gate = P;
+        pend.x_out = x_out; pend.y_save = y_save;
+        have_pend = true;
+        return 0;
+    };
+    for (int l = 0; l < L; ++l)
+        for (int hf = 0; hf < 2; ++hf) {
+            const int i = l * 2 + hf;
+            const gtav_dit::Half& w = h->halves[i];
+            gtav_dit::Train::HB& b = tr.hb[i];
+            const float* mb = mod + (size_t)i * 6 * D;
+            // LN1 normalises r_{2i} (= r_{2i-1} + gate (fc2 of the previous half-block), written to res[2i] by this launch)
+            RET_IF(launch_ln_modulate(i == 0 ? tr.res[0] : tr.res[2 * i - 1], D, b.xnA, D, M, D, mb, mb + D, h->MODW, nullptr, P, have_pend ? &pend : nullptr, h->err_flag, s));
+            have_pend = false;
+            memset(&g, 0, sizeof(g));
+            g.X = b.xnA; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
+            if (hf == 0) { g.qkv_mode = QKV_SPATIAL; g.q = b.q; g.k = b.k; g.v = b.v; g.rope_cs = h->rope_s.cs_dev; }
+            else { g.qkv_mode = QKV_TEMPORAL; g.q = b.q; g.k = b.k; g.v = b.k; g.Tq = T; g.t0 = 0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev; }
+            RET_IF(launch_gemm(g, EPI_QKV, s));
+            if (hf == 0) RET_IF(launch_attn_spatial(b.q, b.k, b.v, b.ao, NB, h->heads, P, s));
+            else RET_IF(launch_attn_temporal(b.q, b.k, b.ao, B, P, D, T, 0, h->maxT, s));
+            RET_IF(resid_gemm(b.ao, w.w_out, D, w.b_out, mb + 2 * D, tr.res[2 * i + 1], b.y1));
+            RET_IF(launch_ln_modulate(tr.res[2 * i], D, b.xnB, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, nullptr, P, &pend, h->err_flag, s));
+            have_pend = false;
+            memset(&g, 0, sizeof(g));
+            g.X = b.xnB; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = b.u; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
+            RET_IF(launch_gemm(g, EPI_F16_TILED, s));       // the pre-activation is kept: gelu'(u) in the backward pass
+            RET_IF(launch_gelu_tiled(b.u, b.hh, (size_t)round_up(M, 128) * h->Hm_pad, s));
+            RET_IF(resid_gemm(b.hh, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, tr.res[2 * i + 2], b.y2));
+        }
+    const float* mf = mod + (size_t)L * 12 * D;
+    RET_IF(launch_ln_modulate(tr.res[4 * L - 1], D, tr.xnF, D, M, D, mf, mf + D, h->MODW, nullptr, P, &pend, h->err_flag, s));
+    memset(&g, 0, sizeof(g));
+    g.X = tr.xnF; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
+    RET_IF(launch_gemm(g, EPI_F32, s));
+    RET_IF(launch_unpatchify(h->fo, h->Nfin, out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
+    tr.B = B; tr.T = T; tr.M = M; tr.Mp = round_up(M, 64); tr.rows = rows; tr.have_actions = actions != nullptr; tr.have_fwd = true;
+    return 0;
+}
+
+// Backward of loss = mean((v_pred[:, -1] - v_target)^2) through the forward saved by gtav_dit_train_forward.  Gradients are ADDED to the
+// gradient arena (gtav_dit_zero_grad first), multiplied by the loss scale.
+int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_target, void* stream) {
+    GTAV_REQUIRE(h && v_pred && v_target, "train_backward: null argument");
+    GTAV_REQUIRE(h->tr.on && h->tr.have_fwd, "train_backward: no saved forward (gtav_dit_train_forward)");
+    hipStream_t s = (hipStream_t)stream;
+    gtav_dit::Train& tr = h->tr;
+    const int D = h->D, P = h->P, L = h->L, B = tr.B, T = tr.T, M = tr.M, Mp = tr.Mp, NB = B * T, rows = tr.rows, Hp = h->Hm_pad, MODW = h->MODW;
+    const int ldhc = D + h->Apad;
+    auto slot = [&](const std::string& n) -> Slot& { return h->wt.slots[n]; };
+    // dX = dY W: A = dY tile-major [M][Kc], WT = tile-major W^T [N][Kc]
+    auto gemm_dx = [&](const f16* A, const f16* WT, int N, int Kc, int epi, void* out, int ldo) -> int {
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = A; q.ldx = Kc; q.W = WT; q.M = M; q.N = N; q.K = Kc; q.out = out; q.ldo = ldo; q.err_flag = h->err_flag;
+        return launch_gemm(q, epi, s);
+    };
+    // dW[n][k] += sum_m dY[m][n] X[m][k]: both operands transposed to [.][Mp] (tokens are the contraction), accumulating epilogue
+    auto gemm_dw = [&](const f16* dY, int N, const f16* X, int K, float* grad) -> int {
+        RET_IF(launch_transpose_tiled_f16(dY, M, N, tr.tA, s));
+        RET_IF(launch_transpose_tiled_f16(X, M, K, tr.tB, s));
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = tr.tA; q.ldx = Mp; q.W = tr.tB; q.M = N; q.N = K; q.K = Mp; q.out = grad; q.ldo = K;
+        return launch_gemm(q, EPI_RESID, s);
+    };
+    const float scale = 2.0f * tr.loss_scale / ((float)B * (float)(h->C * h->H * h->W));
+    GTAV_REQUIRE(h->Nfin <= 64, "train_backward: a final projection wider than 64 features is not implemented");
+    const float* mod = h->mod;
+    float* dmod = tr.dmod;
+    // ---- loss -> final projection -> final LayerNorm ----
+    RET_IF(launch_mse_bwd_patch(v_pred, v_target, B, T, h->C, h->H, h->W, h->p, scale, tr.dfo, 64, h->err_flag, s));
+    {
+        Slot& wf = slot("final_layer.linear.weight");
+        // db: column sums over the 64-wide (zero-padded) dfo, only the first Nfin belong to the bias: sum into a scratch row first
+        GTAV_CHECK_HIP(hipMemsetAsync(tr.dSc, 0, 64 * sizeof(float), s));
+        RET_IF(launch_colsum_tiled_f16(tr.dfo, M, 64, tr.dSc, s));
+        RET_IF(launch_add_f32(slot("final_layer.linear.bias").grad, tr.dSc, slot("final_layer.linear.bias").grad, h->Nfin, s));
+        // dW_final [Nfin][D] += dfo^T xnF   (M = Nfin rows of the 64-row transposed operand)
+        RET_IF(launch_transpose_tiled_f16(tr.dfo, M, 64, tr.tA, s));
+        RET_IF(launch_transpose_tiled_f16(tr.xnF, M, D, tr.tB, s));
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = tr.tA; q.ldx = Mp; q.W = tr.tB; q.M = h->Nfin; q.N = D; q.K = Mp; q.out = wf.grad; q.ldo = D;
+        RET_IF(launch_gemm(q, EPI_RESID, s));
+        // d xnF = dfo W_final  -> fp32 [M][D]
+        RET_IF(gemm_dx(tr.dfo, wf.wT, D, 64, EPI_F32, tr.dtmp, D));
+        const float* mf = mod + (size_t)L * 12 * D;
+        float* dmf = dmod + (size_t)L * 12 * D;
+        RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[4 * L], mf + D, MODW, P, M, D, tr.dres, 0, tr.stats, s));
+        RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[4 * L], tr.stats, NB, P, D, dmf, dmf + D, MODW, s));
+    }
+    // ---- the 2 L half-blocks in reverse; tr.dres = d loss / d (residual state) ----
+    for (int i = 2 * L - 1; i >= 0; --i) {
+        const int l = i / 2, hf = i % 2;
+        gtav_dit::Train::HB& b = tr.hb[i];
+        char pre[64];
+        snprintf(pre, sizeof(pre), "blocks.%d.%c_", l, hf == 0 ? 's' : 't');
+        const std::string P_(pre);
+        const float* mb = mod + (size_t)i * 6 * D;
+        float* dmb = dmod + (size_t)i * 6 * D;
+        // r_{2i+2} = r_{2i+1} + gate_mlp y2
+        RET_IF(launch_gate_bwd(tr.dres, mb + 5 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
+        RET_IF(launch_frame_reduce_gate(tr.dres, b.y2, NB, P, D, dmb + 5 * D, MODW, s));
+        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "mlp.fc2.bias").grad, s));
+        RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad));
+        RET_IF(gemm_dx(tr.g_d, slot(P_ + "mlp.fc2.weight").wT, Hp, D, EPI_F16_TILED, tr.g_h, Hp));
+        RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
+        RET_IF(launch_colsum_tiled_f16(tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, s));
+        RET_IF(gemm_dw(tr.g_u, Hp, b.xnB, D, slot(P_ + "mlp.fc1.weight").grad));
+        RET_IF(gemm_dx(tr.g_u, slot(P_ + "mlp.fc1.weight").wT, D, Hp, EPI_F32, tr.dtmp, D));
+        RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i + 1], mb + 4 * D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
+        RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i + 1], tr.stats, NB, P, D, dmb + 3 * D, dmb + 4 * D, MODW, s));
+        // r_{2i+1} = r_{2i} + gate_msa y1
+        RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
+        RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
+        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "attn.to_out.bias").grad, s));
+        RET_IF(gemm_dw(tr.g_d, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad));
+        RET_IF(gemm_dx(tr.g_d, slot(P_ + "attn.to_out.weight").wT, D, D, EPI_F16, tr.dao, D));
+        if (hf == 0) RET_IF(launch_attn_spatial_bwd(b.q, b.k, b.v, tr.dao, NB, h->heads, P, D, h->rope_s.cs_dev, tr.g_qkv, h->err_flag, s));
+        else RET_IF(launch_attn_temporal_bwd(b.q, b.k, tr.dao, B, P, D, T, h->maxT, h->rope_t.cs_dev, tr.g_qkv, h->err_flag, s));
+        RET_IF(gemm_dw(tr.g_qkv, 3 * D, b.xnA, D, slot(P_ + "attn.to_qkv.weight").grad));
+        RET_IF(gemm_dx(tr.g_qkv, slot(P_ + "attn.to_qkv.weight").wT, D, 3 * D, EPI_F32, tr.dtmp, D));
+        RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i], mb + D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
+        RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i], tr.stats, NB, P, D, dmb, dmb + D, MODW, s));
+    }
+    // ---- patch embedding: r_0 = xp W_pe^T + b_pe ----
+    RET_IF(launch_colsum_f32(tr.dres, D, M, D, slot("x_embedder.proj.bias").grad, s));
+    RET_IF(launch_to_tiled_f16(tr.dres, M, D, tr.g_d, h->err_flag, s));
+    {
+        Slot& wpe = slot("x_embedder.proj.weight");
+        GTAV_REQUIRE(wpe.C == h->Kpe, "train_backward: a patch embedding with padded K (%d of %d) is not implemented", wpe.C, h->Kpe);
+        RET_IF(gemm_dw(tr.g_d, D, tr.xp, h->Kpe, wpe.grad));
+    }
+    // ---- conditioning path (fp32, `rows` = B T rows): mod = SiLU(c) W_ada^T + b_ada, c = W_2 SiLU(W_0 e + b_0) + b_2 (+ W_ext a + b_ext) ----
+    for (int i = 0; i <= 2 * L; ++i) {
+        const size_t row0 = (size_t)i * 6 * D;
+        const int n = i < 2 * L ? 6 * D : 2 * D;
+        std::string wn, bn;
+        if (i < 2 * L) {
+            char pre[64];
+            snprintf(pre, sizeof(pre), "blocks.%d.%c_adaLN_modulation.1.", i / 2, i % 2 == 0 ? 's' : 't');
+            wn = std::string(pre) + "weight"; bn = std::string(pre) + "bias";
+        } else {
+            wn = "final_layer.adaLN_modulation.1.weight"; bn = "final_layer.adaLN_modulation.1.bias";
+        }
+        RET_IF(launch_gemm_tn_f32(dmod + row0, MODW, h->Sc, D, rows, n, D, slot(wn).grad, D, s));
+        RET_IF(launch_colsum_f32(dmod + row0, MODW, rows, n, slot(bn).grad, s));
+    }
+    GTAV_CHECK_HIP(hipMemsetAsync(tr.dSc, 0, (size_t)rows * D * sizeof(float), s));
+    RET_IF(launch_ada_bwd_dx(dmod, MODW, h->w_ada, D, rows, tr.dSc, s));
+    RET_IF(launch_silu_bwd(tr.dSc, D, tr.cpre, D, tr.dc, D, rows, D, s));
+    RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("t_embedder.mlp.2.bias").grad, s));
+    RET_IF(launch_gemm_tn_f32(tr.dc, D, h->HC, ldhc, rows, D, D, slot("t_embedder.mlp.2.weight").grad, D, s));
+    if (tr.have_actions) {
+        RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("external_cond.bias").grad, s));
+        RET_IF(launch_gemm_tn_f32(tr.dc, D, h->HC + D, ldhc, rows, D, h->A, slot("external_cond.weight").grad, h->A, s));
+    }
+    RET_IF(launch_gemm_nn_f32(tr.dc, D, h->w_t2cat, ldhc, rows, D, D, tr.dh0, D, s));
+    RET_IF(launch_silu_bwd(tr.dh0, D, tr.z0, D, tr.dz0, D, rows, D, s));
+    RET_IF(launch_colsum_f32(tr.dz0, D, rows, D, slot("t_embedder.mlp.0.bias").grad, s));
+    RET_IF(launch_gemm_tn_f32(tr.dz0, D, h->E, 256, rows, D, 256, slot("t_embedder.mlp.0.weight").grad, 256, s));
+    return 0;
+}
+
+// One optimizer step over every trainable parameter: global gradient norm -> clipping coefficient (folded with 1 / loss_scale; a
+// non-finite norm skips the step) -> AdamW -> refreshed fp16 operand copies (W and W^T) of the GEMM weights.
+int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, void* stream) {
+    GTAV_REQUIRE(h && h->tr.on, "adamw_step: training is not enabled");
+    hipStream_t s = (hipStream_t)stream;
+    gtav_dit::Train& tr = h->tr;
+    GTAV_CHECK_HIP(hipMemsetAsync(tr.ctl, 0, 2 * sizeof(float), s));
+    RET_IF(launch_sumsq(tr.grad_arena, tr.grad_count, tr.ctl, s));
+    RET_IF(launch_clip_coef(tr.ctl, 1.0f / tr.loss_scale, max_grad_norm, s));
+    tr.step += 1;
+    const float bc1 = 1.0f - powf(beta1, (float)tr.step), bc2 = 1.0f - powf(beta2, (float)tr.step);
+    for (Slot* sl : tr.params) {
+        const int ld = sl->kind == SLOT_F16_PAD ? sl->C : sl->Cp;
+        RET_IF(launch_adamw(sl->master, ld, sl->R, sl->C, sl->grad, sl->am, sl->av, tr.ctl, lr, beta1, beta2, eps, weight_decay, bc1, bc2, s));
+        if (sl->kind == SLOT_F16_PAD) {
+            RET_IF(launch_convert_pad_f16(sl->master, sl->C, sl->R, sl->C, (f16*)sl->dst, sl->Rp, sl->Cp, 1.0f, 1, s));
+            if (sl->wT) RET_IF(launch_convert_T_f16(sl->master, sl->C, sl->R, sl->C, sl->wT, s));
+        }
+    }
+    RET_IF(launch_add_f32(h->b_t2, h->b_ext, h->b_t2a, h->D, s));   // fused bias of c when actions are given (gtav_dit_finalize)
+    h->prepared.valid = false;
+    h->kvrec.valid = false;
+    return 0;
+}
+
+// ctl: [0] sum of squares of the scaled gradients, [1] step coefficient (0 = the step was skipped), [2] skipped steps so far,
+// [3] unscaled global gradient norm of the last step (torch.nn.utils.clip_grad_norm_'s return value)
+int gtav_dit_train_stats(gtav_dit* h, float* out4_host, void* stream) {
+    GTAV_REQUIRE(h && out4_host && h->tr.on, "train_stats: bad argument");
+    GTAV_CHECK_HIP(hipMemcpyAsync(out4_host, h->tr.ctl, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

@@ -174,10 +174,15 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp)
             if (sp < nchunk && sp < pd.nsplit) y = y + sl[sp];
+        if (pd.y_save) {   // training forward: the branch output before the gate (d gate needs it)
+            float am = 0.f;
+            *(f16x4*)(pd.y_save + (size_t)m * pd.ld + c) = sat4(y[0], y[1], y[2], y[3], am);
+        }
         if (pd.gate) y = y * g4;
         v = v + y;
-        if (pd.flags & 1) store16_sc1(xr + c, v);
-        else *(f32x4*)(xr + c) = v;
+        float* xw = pd.x_out ? pd.x_out + (size_t)m * ldx + c : xr + c;   // training forward keeps every residual state
+        if (pd.flags & 1) store16_sc1(xw, v);
+        else *(f32x4*)xw = v;
     }
     float s = wave_sum_dpp((v[0] + v[1]) + (v[2] + v[3]));
     if (lane == 0) red[wid] = s;
@@ -588,6 +593,7 @@ int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const
     GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && rows_per_mod > 0 && ldo == D, "ln_modulate: D=%d must be %%64, <= 2048, ldo == D", D);
     GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
                  "ln_modulate: bad pending update");
+    GTAV_REQUIRE(!pend || M <= g_ln_rowblock_max || (!pend->x_out && !pend->y_save), "ln_modulate: x_out / y_save need the row-block kernel");
     LN_DISPATCH(0, shift, scale, mod_stride, rows, rows_per_mod);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;

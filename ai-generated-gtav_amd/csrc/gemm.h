@@ -15,6 +15,8 @@ enum GemmEpi : int {
     EPI_QKV = 5,        // bias, RoPE on q/k, scatter to attention layouts (model/attention.py:50-58,109-118)
     EPI_PARTIAL = 6,    // split-K: out_f32[ks][m][n] = raw partial sums (no bias); the following LayerNorm kernel
                         // reduces the slabs and applies bias + gate + residual (ops.h: LnPending)
+    EPI_F16_TILED = 7,  // out_f16 = acc + bias, TILE-MAJOR like the GELU epilogues (no activation): training keeps the MLP's
+                        // pre-activation, and the backward pass's activation gradients are GEMM operands themselves
 };
 
 enum QkvMode : int {

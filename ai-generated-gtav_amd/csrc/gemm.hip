@@ -442,7 +442,52 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                 }
     };
-    if constexpr (NS >= 3) {
+    if constexpr (FI * FJ >= 16) {
+        // Large wave tiles (128 x 48, 96 x 48: 18-24 MFMAs per 32-deep half of a K-step), one block per CU, two waves per SIMD:
+        // pipelined by HALF K-steps with one register set per half (fragments (FI + FJ) x 8 registers, the accumulators take 72-96):
+        //   barrier t | early fills | read (t, half 0) -> A | MFMA (t - 1, half 1) from B | read (t, half 1) -> B | MFMA (t, half 0) | late fills
+        // with one fragment read in each of the first MFMAs' issue shadows.
+        f16x8 wa[FI], xa[FJ], wb[FI], xb[FJ];
+        auto rdh = [&](int t, int sh, f16x8 (&wf)[FI], f16x8 (&xf)[FJ]) {
+            const char* b = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) wf[i] = *(const f16x8*)(b + woff[sh] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) xf[j] = *(const f16x8*)(b + xoff[sh] + j * 16 * 128);
+        };
+        auto mmh = [&](const f16x8 (&wf)[FI], const f16x8 (&xf)[FJ]) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[j], wf[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                }
+        };
+        const bool domm = !GTAV_DBG(p, 2);
+        for (int t = 0; t < nkt; ++t) {
+            sync(t);
+            const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
+            if (refill && !late) stage(t + NS - 1);
+            if (t > 0) {
+                rdh(t, 0, wa, xa);
+                if (domm) mmh(wb, xb);
+                interleave_mfma_dsread<FI * FJ, FI + FJ>();
+            } else {
+                rdh(t, 0, wa, xa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rdh(t, 1, wb, xb);
+            if (domm) mmh(wa, xa);
+            interleave_mfma_dsread<FI * FJ, FI + FJ>();
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill && late) {
+                asm volatile("" ::: "memory");
+                stage(t + NS - 1);
+            }
+        }
+        if (domm) mmh(wb, xb);
+    } else if constexpr (NS >= 3) {
         // Small-M shapes (one block per CU, 1.5 waves per SIMD): nothing else on the SIMD covers a wave's LDS-read latency, and
         // with reads and MFMAs of the same K-step in one iteration every K-step exposed it four times (the compiler interleaves
         // 4 reads / wait / 4 MFMAs: ~0.58 us per K-step at M = 720, profiles/round2 stamps).  One-step software pipeline instead:
@@ -695,7 +740,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     const bool compute_wave = w >= 0 && w < WN * WM;
     float amax = 0.f;
 
-    if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
+    if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
         // The fp16 output is the next GEMM's A operand (tile-major).  The block's TM x 128 result is assembled in LDS in
         // that image's row format — CT sub-tile columns of [TM tokens][64 features], rows swizzled like the destination —
         // and then copied out as fully contiguous 1 KiB pieces (8 token rows, 16 B per lane) instead of 16 scattered 8-byte
@@ -714,8 +759,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                     const f32x4 v = acc[i][j] + bv;
                     if constexpr (EPI == EPI_GELU_TANH)
                         *(uint2*)dst = pack4(amax, gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
-                    else
+                    else if constexpr (EPI == EPI_GELU_ERF)
                         *(uint2*)dst = pack4(amax, gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
+                    else
+                        *(uint2*)dst = pack4(amax, v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -927,7 +974,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 // run faster while its partner idles — its K-step is bound by its own barrier-synchronised fill / read / MFMA chain, not by a fill
 // rate shared with the partner — so an offset only moves the idle time.  The same measurement explains the ping-pong kernel below.
 template <int EPI, int NS, int FI, int FJ, int WM>
-__global__ __launch_bounds__(128 * WM, (WM == 2 || (WM == 4 && NS == 2)) ? 2 : 1) void gemm_g_kernel(GemmParams p) {
+__global__ __launch_bounds__(128 * WM, ((WM == 2 || (WM == 4 && NS == 2)) && FI <= 4) ? 2 : 1) void gemm_g_kernel(GemmParams p) {
     constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
     constexpr int STAGE = (4 * FI + 2 * FJ * WM) * 1024;
     // ring, or the QKV epilogue's pitched LDS image + token table (qkv_staged), whichever is larger
@@ -1636,15 +1683,10 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
     if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
     if (shape == 23) return launch_l<EPI, 4, 4, 3, 2, 2, 4>(p, splitk, stream);   // 128 x 96, 4 compute waves of 64 x 48 + 4 loader waves
     if (shape == 25) return launch_l<EPI, 5, 2, 3, 4, 2, 4>(p, splitk, stream);   // shape 20 with a 5-stage ring (140 KiB)
-    if (shape == 16) {
-        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_QKV || EPI == EPI_RESID) {
-            GTAV_REQUIRE(gemm_pp_ok(p.M, p.N, p.K, EPI) || (p.K / TK >= 12 && p.M % 8 == 0 && p.N % 8 == 0),
-                         "gemm: the ping-pong kernel needs K >= 768, M %% 8 == 0, N %% 8 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
-            return launch_pp<EPI>(p, stream);
-        } else {
-            GTAV_REQUIRE(false, "gemm: the ping-pong kernel (shape 16) has no epilogue %d", (int)EPI);
-        }
-    }
+    // (Round 2 also measured one-block-per-CU large tiles on mainloop_g's half-K-step pipeline — 256 x 192, 192 x 192 and
+    // 256 x 144 with 8 / 6 waves of 128 x 48 / 96 x 48 — and the 256 x 128 loader-wave tile, shape 21: all correct, all 5-30 %
+    // SLOWER than the two-blocks-per-CU 128 x 192 tile at M = 5760 / 11 520, profiles/round2/gemm_large_tile_*.txt: without a
+    // co-resident block the prologue and epilogue of every tile are exposed.  The 1-block shapes 30-32 were removed again.)
     if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 2, 3>), grid, dim3(384));
@@ -1658,7 +1700,7 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384));   // 3 stages 1-3 % and 5 stages 4-5 % slower
     } else if (shape == 8) {   // 96 x 96, 6 waves
-        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
+        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
         } else {
             const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 96) * splitk);
@@ -1709,7 +1751,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     } else {
         GTAV_REQUIRE(p.out && p.ldo >= p.N && p.ldo % 4 == 0, "gemm: bad output ldo=%d", p.ldo);
         if (epi == EPI_RESID && p.gate) GTAV_REQUIRE(p.rows_per_gate > 0, "gemm/resid: rows_per_gate");
-        if (epi == EPI_GELU_TANH || epi == EPI_GELU_ERF) GTAV_REQUIRE(p.ldo % 64 == 0, "gemm/gelu: tile-major output needs ldo %% 64 == 0");
+        if (epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_F16_TILED) GTAV_REQUIRE(p.ldo % 64 == 0, "gemm/gelu: tile-major output needs ldo %% 64 == 0");
         if (epi == EPI_PARTIAL) {
             splitk = p.splitk;
             GTAV_REQUIRE(splitk >= 1 && (p.K / TK) % splitk == 0, "gemm/partial: splitk=%d must divide K/64=%d", splitk, p.K / TK);
@@ -1727,7 +1769,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         auto cost = [&](int tn, int tm) { return cdiv(cdiv(p.M, tm) * cdiv(p.N, tn) * splitk, 256) * (tn + tm); };
         int best = cost(128, 128);
         if (cost(128, 96) < best) best = cost(128, 96), wm = 9;
-        const bool ok96 = p.N % 96 == 0 && epi != EPI_GELU_TANH && epi != EPI_GELU_ERF && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL);
+        const bool ok96 = p.N % 96 == 0 && epi != EPI_GELU_TANH && epi != EPI_GELU_ERF && epi != EPI_F16_TILED && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL);
         if (ok96 && cost(96, 96) < best) best = cost(96, 96), wm = 8;
         // skinny M (M = 144: the context-cached sampler step): 64 x 48 tiles put 144-192 blocks of 224 KB where the
         // 128 x 96 grid has 48-64 blocks of 448 KB
@@ -1763,6 +1805,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         case EPI_RESID: return launch_epi<EPI_RESID>(p, ns, wm, splitk, stream);
         case EPI_QKV: return launch_epi<EPI_QKV>(p, ns, wm, splitk, stream);
         case EPI_PARTIAL: return launch_epi<EPI_PARTIAL>(p, ns, wm, splitk, stream);
+        case EPI_F16_TILED: return launch_epi<EPI_F16_TILED>(p, ns, wm, splitk, stream);
         default: GTAV_REQUIRE(false, "gemm: unknown epilogue %d", epi);
     }
     return 0;

@@ -47,6 +47,11 @@ struct LnPending {
     int rows_per_gate;
     int flags;   // set by the launcher: bit 0 = residual write-back as sc1 stores, bit 1 = fp16 output as paired 16-byte sc1 stores
     int* err_flag;   // device error word (common.h ERR_F16_SAT is raised when the fp16 output saturated); may be null
+    // training forward (api.hip gtav_dit_train_forward): the backward pass needs every intermediate residual state and every
+    // branch output, so the updated row goes to x_out (same leading dimension as x) instead of in place, and the branch output
+    // y = sum_s parts[s] + bias (before the gate) is kept as fp16 rows of ld elements in y_save.  Both may be null.
+    float* x_out;
+    f16* y_save;
 };
 
 // LayerNorm outputs are GEMM A-operands: fp16 TILE-MAJOR with logical row length D (buffer rows padded to 128).
@@ -118,6 +123,38 @@ int launch_vtarget(const float* x, const float* noise, const float* alpha /*[row
                    float clamp_abs, hipStream_t stream);
 int launch_mse(const float* a, size_t a_stride, const float* b, size_t b_stride, int rows, int n, float* out_scalar,
                hipStream_t stream);
+
+// ---- train.hip (backward pass + optimizer) ---------------------------------------------
+// src tile-major logical [R][C] (C % 64 == 0) -> dst tile-major logical [C][round_up(R, 64)], zero K padding
+int launch_transpose_tiled_f16(const f16* src, int R, int C, f16* dst, hipStream_t stream);
+// fp32 row-major [R][C] -> fp16 tile-major of the transpose, logical [C][round_up(R, 64)] inside [round_up(C, 128)][...]
+int launch_convert_T_f16(const float* src, int lds, int R, int C, f16* dst, hipStream_t stream);
+int launch_gelu_tiled(const f16* u, f16* h, size_t n, hipStream_t stream);
+int launch_gelu_bwd_tiled(const f16* dh, const f16* u, f16* du, size_t n, int* err_flag, hipStream_t stream);
+int launch_ln_mod_bwd(const float* dxn, const float* x, const float* scale, int mod_stride, int rows_per_mod, int M, int D, float* dres, int accumulate,
+                      float* stats, hipStream_t stream);
+int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats, int frames, int P, int D, float* dshift, float* dscale, int mod_stride,
+                           hipStream_t stream);
+int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int rows_per_mod, int M, int D, f16* dy_tiled, int* err_flag, hipStream_t stream);
+int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream);
+int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, hipStream_t stream);     // db[n] += sum_m dy[m][n]
+int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, hipStream_t stream);   // db[n] += sum_m a[m][n]
+int launch_to_tiled_f16(const float* a, int M, int D, f16* out, int* err_flag, hipStream_t stream);
+int launch_mse_bwd_patch(const float* vpred, const float* vtarget, int B, int T, int C, int H, int W, int p, float scale, f16* dfo, int ldf, int* err_flag,
+                         hipStream_t stream);
+int launch_attn_spatial_bwd(const f16* Q, const f16* K, const f16* Vt, const f16* dO, int NB, int heads, int S, int D, const float* rope_cs, f16* dqkv,
+                            int* err_flag, hipStream_t stream);
+int launch_attn_temporal_bwd(const f16* q, const f16* kv, const f16* dO, int B, int P, int D, int T, int Tmax, const float* rope_cs, f16* dqkv, int* err_flag,
+                             hipStream_t stream);
+int launch_silu(const float* x, int ldx, float* y, int ldy, int R, int C, hipStream_t stream);
+int launch_silu_bwd(const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx, int R, int C, hipStream_t stream);
+int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R, int N, int K, float* dW, int lddw, hipStream_t stream);   // dW += dY^T X
+int launch_gemm_nn_f32(const float* dY, int lddy, const float* W, int ldw, int R, int N, int K, float* dX, int lddx, hipStream_t stream);   // dX = dY W
+int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, hipStream_t stream);                         // dSc += dmod W_ada
+int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream);
+int launch_clip_coef(float* ctl, float inv_scale, float max_norm, hipStream_t stream);
+int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,
+                 float wd, float bc1, float bc2, hipStream_t stream);
 
 // ---- attention.hip -----------------------------------------------------------------------
 // Full (non-causal) attention over S tokens per (nb, head), head_dim 64 (model/attention.py:127-129, model/vae.py:101).

@@ -1,0 +1,722 @@
+// Training-side kernels of the DiT (backward of train_dit.py:680 `accelerator.backward`, AdamW of :232-238,
+// gradient clipping of :965-967).  The dense contractions of the backward pass run on the forward's fp16 MFMA GEMM (csrc/gemm.hip)
+//   dX = dY W        ->  launch_gemm(X = dY [M][N], W = W^T [K][N])                 (contraction over the layer's outputs)
+//   dW = dY^T X      ->  launch_gemm(X = dY^T [N][Mp], W = X^T [K][Mp], EPI_RESID)  (contraction over the tokens, accumulating)
+// so what lives here is what surrounds them: tile-major transposes, the LayerNorm + modulate / gate / GELU / RoPE / attention
+// backward kernels, the per-frame reductions that produce the adaLN gradients, the fp32 conditioning-path backward and the
+// optimizer.  Gradients of activations travel in fp16 (tile-major GEMM operands) scaled by the loss scale; everything that is
+// accumulated (weight gradients, the residual-stream gradient, LayerNorm statistics) is fp32.  All kernels are HBM-bound or tiny.
+#include "ops.h"
+
+namespace gtav {
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red /*[16]*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_dpp(v);
+    __syncthreads();                       // red[] may still be read from a previous call
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Tile-major transpose: src logical [R][C] (C % 64 == 0, rows padded to 128) -> dst logical [C][Rp], Rp = round_up(R, 64), rows of
+// dst padded to 128 by the caller's allocation; dst columns [R, Rp) are written as zeros (they are the K padding of the dW GEMM:
+// both operands must be zero there).  One block = one 64 x 64 sub-tile through LDS, 16-byte accesses on both sides.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_tiled_kernel(const f16* __restrict__ src, int R, int C, f16* __restrict__ dst, int Rp) {
+    __shared__ f16 t[64][72];              // [r][c], 144-byte pitch
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int q = threadIdx.x; q < 512; q += 256) {
+        const int r = q >> 3, ch = q & 7;              // row of the sub-tile, 8-element chunk along c
+        uint4 v = uint4{0, 0, 0, 0};
+        if (r0 + r < R) v = *(const uint4*)(src + tiled_off(r0 + r, c0 + 8 * ch, C));
+        *(uint4*)&t[r][8 * ch] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 512; q += 256) {
+        const int c = q >> 3, rh = q & 7;              // dst row (= src column), 8-element chunk along r
+        union { f16 h[8]; uint4 u; } o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.h[i] = t[8 * rh + i][c];
+        if (r0 + 8 * rh < Rp) *(uint4*)(dst + tiled_off(c0 + c, r0 + 8 * rh, Rp)) = o.u;
+    }
+}
+
+// fp32 row-major [R][C] (ld = lds) -> fp16 tile-major of the TRANSPOSE, logical [C][Rp] (Rp = round_up(R, 64)); zero padding in
+// both directions inside [round_up(C, 128)][Rp].  The W^T operands of the dX GEMMs, refreshed after every optimizer step.
+__global__ void convert_T_kernel(const float* __restrict__ src, int lds, int R, int C, f16* __restrict__ dst, int Cp, int Rp) {
+    const size_t total = (size_t)Cp * Rp;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % Rp);     // source row = destination column
+        const int c = (int)(idx / Rp);
+        float v = 0.f;
+        if (r < R && c < C) v = src[(size_t)r * lds + c];
+        if (v == v) v = __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+        dst[tiled_off(c, r, Rp)] = (f16)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// GELU(tanh) forward / backward on flat fp16 buffers (u and h / dh and du share one layout, so tile-major needs no index math).
+//   gelu'(u) = s + u s (1 - s) 2 k (1 + 3 c u^2),  s = sigmoid(2 k (u + c u^3)), k = sqrt(2/pi), c = 0.044715
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void gelu_tiled_kernel(const f16* __restrict__ u, f16* __restrict__ h, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        union { uint4 q; f16 e[8]; } a, o;
+        a.q = ((const uint4*)u)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = (f16)__builtin_amdgcn_fmed3f(gelu_tanh_f((float)a.e[j]), -F16_MAX, F16_MAX);
+        ((uint4*)h)[i] = o.q;
+    }
+}
+__global__ void gelu_bwd_tiled_kernel(const f16* __restrict__ dh, const f16* __restrict__ u, f16* __restrict__ du, size_t n8, int* err_flag) {
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        union { uint4 q; f16 e[8]; } a, b, o;
+        a.q = ((const uint4*)dh)[i];
+        b.q = ((const uint4*)u)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (float)b.e[j];
+            const float k = 0.7978845608028654f, c = 0.044715f;
+            const float s = 1.0f / (1.0f + __expf(-2.0f * k * x * (1.0f + c * x * x)));
+            const float g = s + x * s * (1.0f - s) * 2.0f * k * (1.0f + 3.0f * c * x * x);
+            const float v = (float)a.e[j] * g;
+            amax = fmaxf(amax, fabsf(v));
+            o.e[j] = (f16)__builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+        }
+        ((uint4*)du)[i] = o.q;
+    }
+    sat_report(amax, err_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// LayerNorm (eps 1e-6, no affine) + modulate backward, one block per token row (D / 4 threads):
+//   xhat = (x - mean) rstd,  g = dxn (1 + scale + 1e-6),  dx = rstd (g - mean(g) - xhat mean(g xhat))
+//   dres[m] = (accumulate ? dres[m] : 0) + dx;   stats[m] = (mean, rstd) for the per-frame reductions
+// The adaLN gradients are sums over the P tokens of a frame: dshift = sum dxn, dscale = sum dxn xhat (frame_reduce_ln_kernel).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void ln_mod_bwd_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ scale,
+                                                         int mod_stride, int rows_per_mod, int M, int D, float* __restrict__ dres,
+                                                         int accumulate, float* __restrict__ stats) {
+    __shared__ float red[16];
+    const int m = blockIdx.x, c = threadIdx.x * 4;
+    const bool act = c < D;
+    const float* sc = scale + (size_t)(m / rows_per_mod) * mod_stride;
+    f32x4 xv = f32x4{0.f, 0.f, 0.f, 0.f}, gv = xv, sv = xv;
+    if (act) {
+        xv = *(const f32x4*)(x + (size_t)m * D + c);
+        gv = *(const f32x4*)(dxn + (size_t)m * D + c);
+        sv = *(const f32x4*)(sc + c);
+    }
+    const float mean = block_sum((xv[0] + xv[1]) + (xv[2] + xv[3]), red) / (float)D;
+    f32x4 d = xv - mean;
+    const float var = block_sum(act ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f, red) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    f32x4 xh = d * rstd, g;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = act ? gv[e] * (1.0f + (sv[e] + 1e-6f)) : 0.f;
+    const float s1 = block_sum((g[0] + g[1]) + (g[2] + g[3]), red) / (float)D;
+    const float s2 = block_sum(act ? (g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3]) : 0.f, red) / (float)D;
+    if (threadIdx.x == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
+    if (!act) return;
+    f32x4 dx;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dx[e] = rstd * (g[e] - s1 - xh[e] * s2);
+    float* o = dres + (size_t)m * D + c;
+    if (accumulate) dx = dx + *(const f32x4*)o;
+    *(f32x4*)o = dx;
+}
+
+// dshift[f][d] = sum over the P tokens of frame f of dxn;  dscale[f][d] = sum of dxn xhat.  One thread per (frame, feature).
+__global__ void frame_reduce_ln_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats, int frames,
+                                       int P, int D, float* __restrict__ dshift, float* __restrict__ dscale, int mod_stride) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (d >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int t = 0; t < P; ++t) {
+        const size_t m = (size_t)f * P + t;
+        const float g = dxn[m * D + d];
+        a += g;
+        b += g * (x[m * D + d] - stats[2 * m]) * stats[2 * m + 1];
+    }
+    dshift[(size_t)f * mod_stride + d] = a;
+    dscale[(size_t)f * mod_stride + d] = b;
+}
+
+// Gated residual branch x += gate y (model/dit.py:207-223) backward: dy = gate dres -> fp16 TILE-MAJOR (the dX / dW GEMM operand);
+// dgate[f][d] = sum over the frame's tokens of dres y (frame_reduce_gate_kernel; y = the branch output saved by the forward).
+__global__ void gate_bwd_kernel(const float* __restrict__ dres, const float* __restrict__ gate, int mod_stride, int rows_per_mod, int M, int D,
+                                f16* __restrict__ dy, int* err_flag) {
+    const size_t total = (size_t)M * (D / 4);
+    float amax = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % (D / 4)) * 4;
+        const int m = (int)(idx / (D / 4));
+        f32x4 v = *(const f32x4*)(dres + (size_t)m * D + c);
+        if (gate) v = v * *(const f32x4*)(gate + (size_t)(m / rows_per_mod) * mod_stride + c);
+        *(f16x4*)(dy + tiled_off(m, c, D)) = sat4(v[0], v[1], v[2], v[3], amax);
+    }
+    sat_report(amax, err_flag);
+}
+__global__ void frame_reduce_gate_kernel(const float* __restrict__ dres, const f16* __restrict__ y, int frames, int P, int D,
+                                         float* __restrict__ dgate, int mod_stride) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (d >= D) return;
+    float a = 0.f;
+    for (int t = 0; t < P; ++t) {
+        const size_t m = (size_t)f * P + t;
+        a += dres[m * D + d] * (float)y[m * D + d];
+    }
+    dgate[(size_t)f * mod_stride + d] = a;
+}
+
+// db[n] += sum_m dY[m][n] for a tile-major fp16 dY (logical [M][N], N % 64 == 0).  Block = one 64-column tile column x a slice of rows.
+__global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(M, r_begin + rows_per_block);
+    float a = 0.f;
+    for (int r = r_begin + rg; r < r_end; r += 4) a += (float)dy[tiled_off(r, n, N)];
+    part[rg][c] = a;
+    __syncthreads();
+    if (rg == 0) atomicAdd(db + n, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+}
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ db, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(M, r_begin + rows_per_block);
+    float s = 0.f;
+    for (int r = r_begin; r < r_end; ++r) s += a[(size_t)r * lda + n];
+    atomicAdd(db + n, s);
+}
+
+// fp32 row-major [M][D] -> fp16 tile-major (the patch-embedding gradient as a dW operand)
+__global__ void to_tiled_f16_kernel(const float* __restrict__ a, int M, int D, f16* __restrict__ out, int* err_flag) {
+    const size_t total = (size_t)M * (D / 4);
+    float amax = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % (D / 4)) * 4;
+        const int m = (int)(idx / (D / 4));
+        const f32x4 v = *(const f32x4*)(a + (size_t)m * D + c);
+        *(f16x4*)(out + tiled_off(m, c, D)) = sat4(v[0], v[1], v[2], v[3], amax);
+    }
+    sat_report(amax, err_flag);
+}
+
+// Loss gradient: loss = mean((v_pred[:, -1] - v_target)^2) over B n elements (train_dit.py:650).  d v_pred is non-zero for the last
+// frame only; it goes straight to the final projection's output gradient dfo[m][f] (m = token, f = (ph, pw, c): the inverse of
+// DiT.unpatchify, model/dit.py:328-341) as an fp16 tile-major GEMM operand, times `scale` = 2 loss_scale / (B n).
+__global__ void mse_bwd_patch_kernel(const float* __restrict__ vpred, const float* __restrict__ vtarget, int B, int T, int C, int H, int W, int p,
+                                     float scale, f16* __restrict__ dfo, int ldf, int* err_flag) {
+    const int gh = H / p, gw = W / p, F = C * p * p;
+    const size_t total = (size_t)B * T * gh * gw * ldf;
+    float amax = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % ldf);
+        const size_t m = idx / ldf;
+        const int gx = (int)(m % gw), gy = (int)((m / gw) % gh), t = (int)((m / ((size_t)gw * gh)) % T), b = (int)(m / ((size_t)gw * gh * T));
+        float v = 0.f;
+        if (t == T - 1 && f < F) {
+            const int c = f % C, pw = (f / C) % p, ph = f / (C * p);
+            const size_t pix = ((size_t)c * H + (gy * p + ph)) * W + (gx * p + pw);
+            v = scale * (vpred[((size_t)b * T + t) * C * H * W + pix] - vtarget[(size_t)b * C * H * W + pix]);
+        }
+        amax = fmaxf(amax, fabsf(v));
+        dfo[tiled_off((int)m, f, ldf)] = (f16)__builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+    }
+    sat_report(amax, err_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Spatial attention backward (model/attention.py:99-136), one block per (frame, head), S tokens, head_dim 64, fp32 math.
+//   P = softmax(Q K^T / 8);  dV = P^T dO;  dP = dO V^T;  dS = P (dP - rowsum(P dP)) / 8;  dQ = dS K;  dK = dS^T Q
+// Inputs in the forward's layouts (Q, K [nb][head][S][64] with RoPE applied, Vt [nb][head][64][S]); dO fp16 row-major [M][D].
+// Output: dqkv fp16 TILE-MAJOR logical [M][3 D] (q | k | v column blocks of the to_qkv Linear), dq / dk rotated back through the
+// interleaved-pair RoPE (the transpose of a rotation is the rotation by the negative angle).
+// Query rows are processed 16 at a time: their P and dS rows live in LDS, dK / dV accumulate in registers (thread = (d, key group)).
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int AB_MAXS = 160;   // S <= 160 (DiT: 144)
+__global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+                                                               const f16* __restrict__ dO, int heads, int S, int D,
+                                                               const float* __restrict__ rope_cs, f16* __restrict__ dqkv, int* err_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    f16* sQ = (f16*)smraw;                 // [S][64]
+    f16* sK = sQ + S * 64;
+    f16* sV = sK + S * 64;                 // [S][64] (transposed back from Vt)
+    f16* sdO = sV + S * 64;
+    float* sP = (float*)(sdO + S * 64);    // [16][S]
+    float* sdS = sP + 16 * S;              // [16][S]
+    const int item = blockIdx.x, nb = item / heads, head = item % heads;
+    const int tid = threadIdx.x;
+    const f16* q = Q + (size_t)item * S * 64;
+    const f16* k = K + (size_t)item * S * 64;
+    const f16* vt = Vt + (size_t)item * 64 * S;
+    for (int i = tid; i < S * 8; i += 256) {       // 16-byte chunks
+        ((uint4*)sQ)[i] = ((const uint4*)q)[i];
+        ((uint4*)sK)[i] = ((const uint4*)k)[i];
+        const int s = i >> 3, ch = i & 7;
+        ((uint4*)sdO)[i] = *(const uint4*)(dO + ((size_t)nb * S + s) * D + head * 64 + 8 * ch);
+    }
+    for (int i = tid; i < S * 64; i += 256) {
+        const int d = i / S, s = i % S;
+        sV[s * 64 + d] = vt[i];
+    }
+    __syncthreads();
+    const int d_own = tid & 63, jg = tid >> 6;     // dK / dV ownership: feature d, keys j = jg, jg + 4, ...
+    constexpr int JMAX = AB_MAXS / 4;
+    float accK[JMAX], accV[JMAX];
+#pragma unroll
+    for (int i = 0; i < JMAX; ++i) accK[i] = accV[i] = 0.f;
+    const int ri = tid >> 4, cj = tid & 15;        // score ownership: query row ri of the 16-row block, keys cj, cj + 16, ...
+    float amax = 0.f;
+    for (int r0 = 0; r0 < S; r0 += 16) {
+        const int i = r0 + ri;
+        constexpr int NJ = AB_MAXS / 16;
+        float sc[NJ], dp[NJ];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) {
+            const int j = cj + 16 * c;
+            sc[c] = -INFINITY;
+            dp[c] = 0.f;
+            if (j < S && i < S) {
+                float a = 0.f, b = 0.f;
+                for (int d = 0; d < 64; d += 2) {
+                    a += (float)sQ[i * 64 + d] * (float)sK[j * 64 + d] + (float)sQ[i * 64 + d + 1] * (float)sK[j * 64 + d + 1];
+                    b += (float)sdO[i * 64 + d] * (float)sV[j * 64 + d] + (float)sdO[i * 64 + d + 1] * (float)sV[j * 64 + d + 1];
+                }
+                sc[c] = a * 0.125f;
+                dp[c] = b;
+                mx = fmaxf(mx, sc[c]);
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) {
+            sc[c] = (cj + 16 * c < S && i < S) ? __expf(sc[c] - mx) : 0.f;
+            sum += sc[c];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) {
+            sc[c] *= inv;
+            dsum += sc[c] * dp[c];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) {
+            const int j = cj + 16 * c;
+            if (j < S) {
+                sP[ri * S + j] = sc[c];
+                sdS[ri * S + j] = sc[c] * (dp[c] - dsum) * 0.125f;
+            }
+        }
+        __syncthreads();
+        // dQ rows of this block: 16 x 64 outputs, 4 per thread (row ri, features 4 cj .. 4 cj + 3); RoPE^T; store
+        if (i < S) {
+            float dq[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < S; ++j) {
+                const float w = sdS[ri * S + j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dq[e] += w * (float)sK[j * 64 + 4 * cj + e];
+            }
+            const f32x4 cs = *(const f32x4*)(rope_cs + (size_t)i * 64 + 4 * cj);
+            const float o0 = dq[0] * cs[0] + dq[1] * cs[1], o1 = dq[1] * cs[0] - dq[0] * cs[1];
+            const float o2 = dq[2] * cs[2] + dq[3] * cs[3], o3 = dq[3] * cs[2] - dq[2] * cs[3];
+            *(f16x4*)(dqkv + tiled_off(nb * S + i, head * 64 + 4 * cj, 3 * D)) = sat4(o0, o1, o2, o3, amax);
+        }
+        // dV[j][d] += sum_i P[i][j] dO[i][d];  dK[j][d] += sum_i dS[i][j] Q[i][d]
+        const int rows = min(16, S - r0);
+#pragma unroll
+        for (int c = 0; c < JMAX; ++c) {
+            const int j = jg + 4 * c;
+            if (j < S) {
+                float av = 0.f, ak = 0.f;
+                for (int r = 0; r < rows; ++r) {
+                    av += sP[r * S + j] * (float)sdO[(r0 + r) * 64 + d_own];
+                    ak += sdS[r * S + j] * (float)sQ[(r0 + r) * 64 + d_own];
+                }
+                accV[c] += av;
+                accK[c] += ak;
+            }
+        }
+        __syncthreads();
+    }
+    // dK (RoPE^T needs the pair partner: lanes d and d ^ 1 are neighbours in the wave) and dV
+#pragma unroll
+    for (int c = 0; c < JMAX; ++c) {
+        const int j = jg + 4 * c;
+        if (j < S) {      // uniform per wave: j depends on jg (= the wave index) and c only
+            const float mine = accK[c], other = __shfl_xor(mine, 1, 64);
+            const float co = rope_cs[(size_t)j * 64 + (d_own & ~1)], si = rope_cs[(size_t)j * 64 + (d_own | 1)];
+            const float dk = (d_own & 1) ? mine * co - other * si : mine * co + other * si;
+            const size_t m = (size_t)nb * S + j;
+            amax = fmaxf(amax, fmaxf(fabsf(dk), fabsf(accV[c])));
+            dqkv[tiled_off((int)m, D + head * 64 + d_own, 3 * D)] = (f16)__builtin_amdgcn_fmed3f(dk, -F16_MAX, F16_MAX);
+            dqkv[tiled_off((int)m, 2 * D + head * 64 + d_own, 3 * D)] = (f16)__builtin_amdgcn_fmed3f(accV[c], -F16_MAX, F16_MAX);
+        }
+    }
+    sat_report(amax, err_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Temporal (causal) attention backward (model/attention.py:41-71): per (b, position p, head) a T x T lower-triangular problem,
+// T <= 8.  16 lanes per item, 4 head features per lane, dot products by 4 xor-shuffles inside the 16-lane group.
+// q fp16 [M][D] (m = (b T + t) P + p), kv cache [B][Tmax][P][2][D] (k with RoPE, v), dO fp16 row-major [M][D];
+// output dqkv fp16 tile-major [M][3 D] with RoPE^T on dq / dk (position = frame index t).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int TT>
+__global__ __launch_bounds__(256) void attn_temporal_bwd_kernel(const f16* __restrict__ q, const f16* __restrict__ kv, const f16* __restrict__ dO, int B,
+                                                                int P, int D, int Tmax, const float* __restrict__ rope_cs, f16* __restrict__ dqkv,
+                                                                int* err_flag) {
+    const int heads = D >> 6;
+    const int gidx = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
+    const int items = B * P * heads;
+    const bool valid = gidx < items;
+    const int it = valid ? gidx : items - 1;
+    const int head = it % heads, p = (it / heads) % P, b = it / (heads * P);
+    const int col = head * 64 + 4 * l;
+    float qv[TT][4], kk[TT][4], vv[TT][4], go[TT][4];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const size_t m = ((size_t)b * TT + t) * P + p;
+        const f16x4 a = *(const f16x4*)(q + m * D + col), g = *(const f16x4*)(dO + m * D + col);
+        const size_t slot = (((size_t)b * Tmax + t) * P + p) * 2 * D;
+        const f16x4 kx = *(const f16x4*)(kv + slot + col), vx = *(const f16x4*)(kv + slot + D + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qv[t][e] = (float)a[e]; go[t][e] = (float)g[e]; kk[t][e] = (float)kx[e]; vv[t][e] = (float)vx[e]; }
+    }
+    auto dot16 = [&](const float (&a)[4], const float (&b2)[4]) {
+        float s = (a[0] * b2[0] + a[1] * b2[1]) + (a[2] * b2[2] + a[3] * b2[3]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        return s;
+    };
+    float dq[TT][4], dk[TT][4], dv[TT][4];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[t][e] = dk[t][e] = dv[t][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float sc[TT], dp[TT], mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s <= t; ++s) {
+            sc[s] = dot16(qv[t], kk[s]) * 0.125f;
+            dp[s] = dot16(go[t], vv[s]);
+            mx = fmaxf(mx, sc[s]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s <= t; ++s) { sc[s] = __expf(sc[s] - mx); sum += sc[s]; }
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int s = 0; s <= t; ++s) { sc[s] *= inv; dsum += sc[s] * dp[s]; }
+#pragma unroll
+        for (int s = 0; s <= t; ++s) {
+            const float ds = sc[s] * (dp[s] - dsum) * 0.125f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dq[t][e] += ds * kk[s][e];
+                dk[s][e] += ds * qv[t][e];
+                dv[s][e] += sc[s] * go[t][e];
+            }
+        }
+    }
+    float amax = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int m = (b * TT + t) * P + p;
+            const f32x4 cs = *(const f32x4*)(rope_cs + (size_t)t * 64 + 4 * l);
+            const float q0 = dq[t][0] * cs[0] + dq[t][1] * cs[1], q1 = dq[t][1] * cs[0] - dq[t][0] * cs[1];
+            const float q2 = dq[t][2] * cs[2] + dq[t][3] * cs[3], q3 = dq[t][3] * cs[2] - dq[t][2] * cs[3];
+            const float k0 = dk[t][0] * cs[0] + dk[t][1] * cs[1], k1 = dk[t][1] * cs[0] - dk[t][0] * cs[1];
+            const float k2 = dk[t][2] * cs[2] + dk[t][3] * cs[3], k3 = dk[t][3] * cs[2] - dk[t][2] * cs[3];
+            *(f16x4*)(dqkv + tiled_off(m, col, 3 * D)) = sat4(q0, q1, q2, q3, amax);
+            *(f16x4*)(dqkv + tiled_off(m, D + col, 3 * D)) = sat4(k0, k1, k2, k3, amax);
+            *(f16x4*)(dqkv + tiled_off(m, 2 * D + col, 3 * D)) = sat4(dv[t][0], dv[t][1], dv[t][2], dv[t][3], amax);
+        }
+    }
+    sat_report(amax, err_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// fp32 conditioning path (tens of rows): SiLU, the two small GEMM forms of a Linear's backward, and the adaLN mega-projection.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void silu_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int R, int C) {
+    const size_t total = (size_t)R * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C), r = (int)(idx / C);
+        const float v = x[(size_t)r * ldx + c];
+        y[(size_t)r * ldy + c] = v / (1.0f + expf(-v));
+    }
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, float* __restrict__ dx, int lddx, int R, int C) {
+    const size_t total = (size_t)R * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C), r = (int)(idx / C);
+        const float v = x[(size_t)r * ldx + c], s = 1.0f / (1.0f + expf(-v));
+        dx[(size_t)r * lddx + c] = dy[(size_t)r * lddy + c] * s * (1.0f + v * (1.0f - s));
+    }
+}
+// dW[n][k] += sum_r dY[r][n] X[r][k]      (one thread per (n, k); R is tens of rows)
+__global__ void gemm_tn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx, int R, int N, int K, float* __restrict__ dW,
+                                   int lddw) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = blockIdx.y;
+    if (k >= K) return;
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += dY[(size_t)r * lddy + n] * X[(size_t)r * ldx + k];
+    dW[n * lddw + k] += a;
+}
+// dX[r][k] = sum_n dY[r][n] W[n][k]       (one thread per (r, k))
+__global__ void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ W, int ldw, int R, int N, int K, float* __restrict__ dX,
+                                   int lddx) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (k >= K) return;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += dY[(size_t)r * lddy + n] * W[(size_t)n * ldw + k];
+    dX[(size_t)r * lddx + k] = a;
+}
+// The adaLN projection mod = SiLU(c) W_ada^T + b_ada with W_ada [MODW][D] (MODW ~ 2 x 10^5): dSc[r][n] = sum_k dmod[r][k] W_ada[k][n].
+// Block = (256 features n) x (a chunk of KC rows k of W_ada), up to 16 conditioning rows per pass in registers; W_ada is read once
+// per pass (0.8 GB at full size, re-read from L2 for the next 16 rows), partial sums leave by atomics into the zeroed dSc.
+__global__ __launch_bounds__(256) void ada_bwd_dx_kernel(const float* __restrict__ dmod, int MODW, const float* __restrict__ W, int D, int R, int KC,
+                                                         float* __restrict__ dSc) {
+    __shared__ float sd[16][256];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int k0 = blockIdx.y * KC, k1 = min(MODW, k0 + KC);
+    for (int rb = 0; rb < R; rb += 16) {
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int kb = k0; kb < k1; kb += 256) {
+            __syncthreads();
+            for (int i = 0; i < 16; ++i) {
+                const int k = kb + threadIdx.x;
+                sd[i][threadIdx.x] = (rb + i < R && k < k1) ? dmod[(size_t)(rb + i) * MODW + k] : 0.f;
+            }
+            __syncthreads();
+            const int kn = min(256, k1 - kb);
+            if (n < D)
+                for (int kk = 0; kk < kn; ++kk) {
+                    const float w = W[(size_t)(kb + kk) * D + n];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[i] += sd[i][kk] * w;
+                }
+        }
+        if (n < D)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (rb + i < R) atomicAdd(dSc + (size_t)(rb + i) * D + n, acc[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Optimizer (torch.optim.AdamW semantics, train_dit.py:232-238) with the loss scale and the clipping coefficient folded in.
+//   ctl[0] = sum of squares of the SCALED gradients (sumsq_kernel, all parameters), ctl[1] = coefficient written by clip_coef_kernel:
+//   inv_scale * min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_), or 0 when the norm is not finite (overflow:
+//   the step is skipped and ctl[2] counts it).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ ctl) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += g[i] * g[i];
+    const float t = block_sum(a, red);
+    if (threadIdx.x == 0) atomicAdd(ctl, t);
+}
+__global__ void clip_coef_kernel(float* ctl, float inv_scale, float max_norm) {
+    const float norm = sqrtf(ctl[0]) * inv_scale;
+    if (!(norm == norm) || isinf(norm)) {
+        ctl[1] = 0.f;
+        ctl[2] += 1.f;
+    } else {
+        ctl[1] = inv_scale * (max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f);
+    }
+    ctl[3] = norm;
+}
+__global__ void adamw_kernel(float* __restrict__ p, int ldp, int R, int C, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             const float* __restrict__ ctl, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+    const float coef = ctl[1];
+    if (coef == 0.f) return;               // overflow: skip the step
+    const size_t total = (size_t)R * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const size_t r = idx / C;
+        const float gr = g[idx] * coef;
+        const float mm = beta1 * m[idx] + (1.0f - beta1) * gr;
+        const float vv = beta2 * v[idx] + (1.0f - beta2) * gr * gr;
+        m[idx] = mm;
+        v[idx] = vv;
+        float* pp = p + r * ldp + c;
+        const float w = *pp * (1.0f - lr * wd);
+        *pp = w - (lr / bc1) * mm / (sqrtf(vv) / sqrtf(bc2) + eps);
+    }
+}
+
+static int grid_for(size_t n, int block = 256) { return (int)((n + block - 1) / block < 4096 ? (n + block - 1) / block : 4096); }
+
+}  // namespace
+
+int launch_transpose_tiled_f16(const f16* src, int R, int C, f16* dst, hipStream_t stream) {
+    GTAV_REQUIRE(R > 0 && C > 0 && C % 64 == 0, "transpose: bad shape %d x %d", R, C);
+    const int Rp = round_up(R, 64);
+    hipLaunchKernelGGL(transpose_tiled_kernel, dim3(C / 64, Rp / 64), dim3(256), 0, stream, src, R, C, dst, Rp);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_convert_T_f16(const float* src, int lds, int R, int C, f16* dst, hipStream_t stream) {
+    const int Cp = round_up(C, 128), Rp = round_up(R, 64);
+    hipLaunchKernelGGL(convert_T_kernel, dim3(grid_for((size_t)Cp * Rp)), dim3(256), 0, stream, src, lds, R, C, dst, Cp, Rp);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gelu_tiled(const f16* u, f16* h, size_t n, hipStream_t stream) {
+    GTAV_REQUIRE(n % 8 == 0, "gelu: element count must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_tiled_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, u, h, n / 8);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gelu_bwd_tiled(const f16* dh, const f16* u, f16* du, size_t n, int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(n % 8 == 0, "gelu_bwd: element count must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_bwd_tiled_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, dh, u, du, n / 8, err_flag);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_ln_mod_bwd(const float* dxn, const float* x, const float* scale, int mod_stride, int rows_per_mod, int M, int D, float* dres, int accumulate,
+                      float* stats, hipStream_t stream) {
+    GTAV_REQUIRE(D % 4 == 0 && D <= 2048, "ln_mod_bwd: D=%d", D);
+    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(M), dim3(round_up(D / 4, 64)), 0, stream, dxn, x, scale, mod_stride, rows_per_mod, M, D, dres, accumulate, stats);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats, int frames, int P, int D, float* dshift, float* dscale, int mod_stride,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(frame_reduce_ln_kernel, dim3(cdiv(D, 256), frames), dim3(256), 0, stream, dxn, x, stats, frames, P, D, dshift, dscale, mod_stride);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int rows_per_mod, int M, int D, f16* dy_tiled, int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(D % 64 == 0, "gate_bwd: D=%d", D);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for((size_t)M * (D / 4))), dim3(256), 0, stream, dres, gate, mod_stride, rows_per_mod, M, D, dy_tiled, err_flag);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(frame_reduce_gate_kernel, dim3(cdiv(D, 256), frames), dim3(256), 0, stream, dres, y, frames, P, D, dgate, mod_stride);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, hipStream_t stream) {
+    GTAV_REQUIRE(N % 64 == 0, "colsum: N=%d must be a multiple of 64", N);
+    const int splits = cdiv(M, 512);
+    hipLaunchKernelGGL(colsum_tiled_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dy, M, N, db, cdiv(M, splits));
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, hipStream_t stream) {
+    const int splits = cdiv(M, 256);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(N, 256), splits), dim3(256), 0, stream, a, lda, M, N, db, cdiv(M, splits));
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_to_tiled_f16(const float* a, int M, int D, f16* out, int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(D % 64 == 0, "to_tiled: D=%d", D);
+    hipLaunchKernelGGL(to_tiled_f16_kernel, dim3(grid_for((size_t)M * (D / 4))), dim3(256), 0, stream, a, M, D, out, err_flag);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_mse_bwd_patch(const float* vpred, const float* vtarget, int B, int T, int C, int H, int W, int p, float scale, f16* dfo, int ldf, int* err_flag,
+                         hipStream_t stream) {
+    GTAV_REQUIRE(ldf % 64 == 0 && ldf >= C * p * p, "mse_bwd: ldf=%d", ldf);
+    const size_t total = (size_t)B * T * (H / p) * (W / p) * ldf;
+    hipLaunchKernelGGL(mse_bwd_patch_kernel, dim3(grid_for(total)), dim3(256), 0, stream, vpred, vtarget, B, T, C, H, W, p, scale, dfo, ldf, err_flag);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_attn_spatial_bwd(const f16* Q, const f16* K, const f16* Vt, const f16* dO, int NB, int heads, int S, int D, const float* rope_cs, f16* dqkv,
+                            int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(S > 0 && S <= AB_MAXS && S % 8 == 0 && D == heads * 64, "attn_spatial_bwd: S=%d (<= %d), D=%d", S, AB_MAXS, D);
+    const size_t lds = (size_t)4 * S * 64 * 2 + (size_t)2 * 16 * S * 4;
+    static unsigned long long attr_devs = 0;
+    int dev = 0;
+    GTAV_CHECK_HIP(hipGetDevice(&dev));
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_devs |= 1ull << (dev & 63);
+    }
+    hipLaunchKernelGGL(attn_spatial_bwd_kernel, dim3(NB * heads), dim3(256), lds, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_attn_temporal_bwd(const f16* q, const f16* kv, const f16* dO, int B, int P, int D, int T, int Tmax, const float* rope_cs, f16* dqkv, int* err_flag,
+                             hipStream_t stream) {
+    GTAV_REQUIRE(T >= 1 && T <= 8 && T <= Tmax && D % 64 == 0, "attn_temporal_bwd: T=%d", T);
+    const size_t threads = (size_t)B * P * (D / 64) * 16;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+#define GTAV_TB(TT) case TT: hipLaunchKernelGGL(attn_temporal_bwd_kernel<TT>, grid, block, 0, stream, q, kv, dO, B, P, D, Tmax, rope_cs, dqkv, err_flag); break
+    switch (T) { GTAV_TB(1); GTAV_TB(2); GTAV_TB(3); GTAV_TB(4); GTAV_TB(5); GTAV_TB(6); GTAV_TB(7); GTAV_TB(8); }
+#undef GTAV_TB
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_silu(const float* x, int ldx, float* y, int ldy, int R, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, x, ldx, y, ldy, R, C);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_silu_bwd(const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx, int R, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, dy, lddy, x, ldx, dx, lddx, R, C);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R, int N, int K, float* dW, int lddw, hipStream_t stream) {
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, stream, dY, lddy, X, ldx, R, N, K, dW, lddw);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gemm_nn_f32(const float* dY, int lddy, const float* W, int ldw, int R, int N, int K, float* dX, int lddx, hipStream_t stream) {
+    hipLaunchKernelGGL(gemm_nn_f32_kernel, dim3(cdiv(K, 256), R), dim3(256), 0, stream, dY, lddy, W, ldw, R, N, K, dX, lddx);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, hipStream_t stream) {
+    const int KC = 2048;
+    hipLaunchKernelGGL(ada_bwd_dx_kernel, dim3(cdiv(D, 256), cdiv(MODW, KC)), dim3(256), 0, stream, dmod, MODW, W, D, R, KC, dSc);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, stream, g, n, ctl);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_clip_coef(float* ctl, float inv_scale, float max_norm, hipStream_t stream) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, ctl, inv_scale, max_norm);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,
+                 float wd, float bc1, float bc2, hipStream_t stream) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, p, ldp, R, C, g, m, v, ctl, lr, beta1, beta2, eps, wd, bc1, bc2);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gtav

@@ -57,6 +57,15 @@ SIGNATURES = {
     "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "gtav_dit_prepare_frame": [_p, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _p, _p],
     "gtav_dit_check": [_p, _p],
+    "gtav_dit_train_param_count": [_p, C.POINTER(C.c_int64)],
+    "gtav_dit_train_enable": [_p, _p, _l],
+    "gtav_dit_set_loss_scale": [_p, _f],
+    "gtav_dit_zero_grad": [_p, _p],
+    "gtav_dit_train_forward": [_p, _p, _p, _p, _p, _i, _i, _p],
+    "gtav_dit_train_backward": [_p, _p, _p, _p],
+    "gtav_dit_get_grad": [_p, C.c_char_p, _p, _l, _p],
+    "gtav_dit_adamw_step": [_p, _f, _f, _f, _f, _f, _f, _p],
+    "gtav_dit_train_stats": [_p, C.POINTER(C.c_float), _p],
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

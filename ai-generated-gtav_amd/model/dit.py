@@ -144,8 +144,11 @@ class DiT(_HipModule):
     _prefix = "gtav_dit"
 
     def __init__(self, input_h=18, input_w=32, patch_size=2, in_channels=16, hidden_size=1024, depth=12, num_heads=16,
-                 mlp_ratio=4.0, external_cond_dim=25, max_frames=5, *, max_batch=1, init_weights=True):
+                 mlp_ratio=4.0, external_cond_dim=25, max_frames=5, *, max_batch=1, init_weights=True, trainable=False):
         super().__init__()
+        self._trainable = bool(trainable)    # keyword-only, not in the reference: keeps fp32 masters, gradients and AdamW state on the GPU
+        self._grads = None
+        self._loss_scale = 65536.0
         self.in_channels = in_channels
         self.out_channels = in_channels
         self.patch_size = patch_size
@@ -224,6 +227,16 @@ class DiT(_HipModule):
                                  max_cond_rows=max(self._capacity_b * self._capacity_t, self._capacity_rows), **self._cfg_kwargs)
             with torch.cuda.device(self.device):
                 _lib.check(L.gtav_dit_create(C.byref(cfg), C.byref(self._handle)))
+                if self._trainable:
+                    if self._grads is not None:
+                        raise RuntimeError("a trainable DiT cannot grow its workspace after the first step (the optimizer state lives in the "
+                                           "handle): size it with max_batch / max_frames or reserve() first")
+                    n = C.c_int64(0)
+                    _lib.check(L.gtav_dit_train_param_count(self._handle, C.byref(n)))
+                    # one contiguous fp32 gradient arena owned by torch: a single all-reduce covers the whole model (train.py)
+                    self._grads = torch.zeros(n.value, device=self.device, dtype=torch.float32)
+                    _lib.check(L.gtav_dit_train_enable(self._handle, self._grads.data_ptr(), n.value))
+                    _lib.check(L.gtav_dit_set_loss_scale(self._handle, self._loss_scale))
             self._dirty = True
         if self._dirty:
             gh, gw = self.input_h // self.patch_size, self.input_w // self.patch_size
@@ -259,6 +272,82 @@ class DiT(_HipModule):
         return out
 
     __call__ = forward
+
+    # ------------------------------------------------------------------------------------------
+    # training step (reference: train_dit.py:649-650, :680, :232-238, :965-970)
+    # ------------------------------------------------------------------------------------------
+    def forward_train(self, x: torch.Tensor, t: torch.Tensor, external_cond: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """DiT.forward keeping the activations `backward_` needs (same result as forward)."""
+        assert self._trainable, "construct the model with trainable=True"
+        B, T, Cc, H, W = x.shape
+        assert H == self.input_h and W == self.input_w
+        self._ensure(B, T)
+        dev = self.device
+        xd = x.to(dev, torch.float32).contiguous()
+        td = t.to(dev, torch.int64).contiguous()
+        ad = external_cond.to(dev, torch.float32).contiguous() if torch.is_tensor(external_cond) else None
+        out = torch.empty_like(xd)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().gtav_dit_train_forward(self._handle, xd.data_ptr(), td.data_ptr(), _lib.ptr(ad), out.data_ptr(), B, T,
+                                                          _lib.current_stream()))
+        return out
+
+    def backward_(self, v_pred: torch.Tensor, v_target: torch.Tensor):
+        """Adds d mean((v_pred[:, -1] - v_target)^2) / d theta (times the loss scale) to the gradient arena (`accelerator.backward`)."""
+        vt = v_target.to(self.device, torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_train_backward(self._handle, v_pred.data_ptr(), vt.data_ptr(), _lib.current_stream()))
+
+    def zero_grad(self):
+        if not self._handle:
+            self._ensure(self._capacity_b, self._capacity_t)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_zero_grad(self._handle, _lib.current_stream()))
+
+    @property
+    def grad_arena(self) -> torch.Tensor:
+        """All gradients (loss-scaled), contiguous, parameters in lexicographic name order: what a data-parallel run all-reduces."""
+        return self._grads
+
+    @property
+    def loss_scale(self) -> float:
+        return self._loss_scale
+
+    @loss_scale.setter
+    def loss_scale(self, v: float):
+        self._loss_scale = float(v)
+        if self._handle:
+            _lib.check(_lib.load().gtav_dit_set_loss_scale(self._handle, self._loss_scale))
+
+    def grad(self, name: str) -> torch.Tensor:
+        """Unscaled gradient of one parameter in its state-dict shape."""
+        shp = self._shapes()[name]
+        out = torch.empty(shp, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_get_grad(self._handle, name.encode(), out.data_ptr(), out.numel(), _lib.current_stream()))
+        return out / self._loss_scale
+
+    def adamw_step(self, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-7, max_grad_norm: float = 0.0):
+        """clip_grad_norm_ + AdamW.step on the GPU masters (train_dit.py:232-238, 965-968); refreshes the fp16 GEMM operands."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_adamw_step(self._handle, float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                                       float(max_grad_norm), _lib.current_stream()))
+
+    def train_stats(self):
+        """(step applied?, skipped steps so far, unscaled global gradient norm of the last step); synchronises."""
+        buf = (C.c_float * 4)()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_train_stats(self._handle, buf, _lib.current_stream()))
+        return buf[1] != 0.0, int(buf[2]), float(buf[3])
+
+    def pull_weights(self):
+        """Copies the trained fp32 masters from the GPU back into the host state dict (checkpoints, state_dict())."""
+        L = _lib.load()
+        with torch.cuda.device(self.device):
+            for k, shp in self._shapes().items():
+                out = torch.empty(shp, device=self.device, dtype=torch.float32)
+                _lib.check(L.gtav_dit_get_weight(self._handle, k.encode(), out.data_ptr(), out.numel(), _lib.current_stream()))
+                self._sd[k] = out.cpu()
 
     # ------------------------------------------------------------------------------------------
     # fused sampler entry (train_dit.denoise_step + generate.py:220), used by gtav_amd.generate

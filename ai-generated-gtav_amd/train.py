@@ -21,8 +21,9 @@ def encode_frames(vae, frames: torch.Tensor) -> torch.Tensor:
 @torch.inference_mode()
 def forward_loss(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx: torch.Tensor,
                  ctx_noise_idx: torch.Tensor, ctx_noise: torch.Tensor, noise: torch.Tensor, noise_steps: int = 50,
-                 n_prompt_frames: int = 4, noise_abs_max: float = 20.0, clamp_min: float = 1e-6):
-    """train_dit.py:590-650 for clips of n_prompt_frames + 1 frames. Returns (loss (1,) tensor, v_pred, v_target)."""
+                 n_prompt_frames: int = 4, noise_abs_max: float = 20.0, clamp_min: float = 1e-6, keep_activations: bool = False):
+    """train_dit.py:590-650 for clips of n_prompt_frames + 1 frames. Returns (loss (1,) tensor, v_pred, v_target).
+    keep_activations: run the DiT through forward_train so that dit.backward_(v_pred, v_target) can follow."""
     dev = dit.device
     L = _lib.load()
     B, total = latents.shape[:2]
@@ -53,7 +54,7 @@ def forward_loss(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], ta
         v_target = torch.empty_like(x_last)
         _lib.check(L.gtav_vtarget(x_last.data_ptr(), nz_last.data_ptr(), a_last.data_ptr(), v_target.data_ptr(), B, n,
                                   noise_abs_max, stream))
-    v_pred = dit(x_noisy, t, a)
+    v_pred = dit.forward_train(x_noisy, t, a) if keep_activations else dit(x_noisy, t, a)
     out = torch.empty(1 + B, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
         vp_last = v_pred[:, -1]
@@ -130,3 +131,45 @@ def predict_noise(dit, vae, frames: torch.Tensor, actions: Optional[torch.Tensor
     with torch.cuda.device(dev):
         _lib.check(L.gtav_clamp_frames(x_old.data_ptr(), 1, n, n - 1, fsz, -float(noise_abs_max), float(noise_abs_max), _lib.current_stream()))
     return latents, x_old, x
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Optimisation step.  Reference: train_dit.py:680 accelerator.backward, :232-260 AdamW + cosine schedule with
+# warm-up and a floor, :965-970 clip_grad_norm_ / optimizer.step / scheduler.step / zero_grad; accelerate's DDP averages the
+# gradients of the ranks.  Here: backward kernels into one contiguous gradient arena, ONE all-reduce over it (RCCL over xGMI:
+# 2.4 GB of fp32 for DiT-S/2), clipping + AdamW fused on the GPU.
+# ------------------------------------------------------------------------------------------------------------------------
+def cosine_with_min_lr(step: int, base_lr: float, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.25,
+                       min_lr: float = 0.0) -> float:
+    """transformers.get_cosine_with_min_lr_schedule_with_warmup as called at train_dit.py:253-260 (num_cycles=0.25): linear warm-up,
+    then base_lr * (min_rate + (1 - min_rate) * 0.5 (1 + cos(2 pi cycles progress))), min_rate = min_lr / base_lr."""
+    import math
+    if step < num_warmup_steps:
+        return base_lr * step / max(1, num_warmup_steps)
+    progress = (step - num_warmup_steps) / max(1, num_training_steps - num_warmup_steps)
+    factor = 0.5 * (1.0 + math.cos(math.pi * num_cycles * 2.0 * progress))
+    rate = min_lr / base_lr
+    return base_lr * max(0.0, factor * (1.0 - rate) + rate)
+
+
+def all_reduce_gradients(dit, world_size: int):
+    """Data-parallel gradient averaging (what DDP does under accelerate): one all-reduce over the contiguous arena, in place."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(dit.grad_arena, op=dist.ReduceOp.SUM)
+        dit.grad_arena.div_(world_size)
+
+
+@torch.inference_mode()
+def training_step(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx: torch.Tensor, ctx_noise_idx: torch.Tensor,
+                  ctx_noise: torch.Tensor, noise: torch.Tensor, lr: float, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
+                  world_size: int = 1, noise_steps: int = 50, n_prompt_frames: int = 4, noise_abs_max: float = 20.0, clamp_min: float = 1e-6):
+    """One optimisation step on a batch of (n_prompt_frames + 1)-frame latent clips: forward + loss (train_dit.py:590-650), backward,
+    gradient all-reduce, clip, AdamW.  Returns the loss tensor (1,)."""
+    dit.zero_grad()
+    loss, v_pred, v_target = forward_loss(dit, latents, actions, target_noise_idx, ctx_noise_idx, ctx_noise, noise, noise_steps, n_prompt_frames,
+                                          noise_abs_max, clamp_min, keep_activations=True)
+    dit.backward_(v_pred, v_target)
+    all_reduce_gradients(dit, world_size)
+    dit.adamw_step(lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+    return loss

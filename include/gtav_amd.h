@@ -112,6 +112,36 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
 int gtav_dit_profile(gtav_dit* h, int32_t enable);
 int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class);
 
+/* ---- DiT training step ------------------------------------------------------------------------------------
+ * Replaces, for the DiT, what train_dit.py does through torch autograd / torch.optim / accelerate:
+ *   :649-650 `v_pred = self.dit(x_noisy, t, actions); loss = mse_loss(v_pred[:, -1:], v_target)`  -> gtav_dit_train_forward (+ gtav_mse)
+ *   :680     `self.accelerator.backward(scaled_loss)`                                              -> gtav_dit_train_backward
+ *   :232-238 `AdamW(self.dit.parameters(), lr, weight_decay, betas=(0.9, 0.999), eps=1e-7)`, :965-970 `clip_grad_norm_`,
+ *            `optimizer.step()`, `optimizer.zero_grad()`                                           -> gtav_dit_adamw_step, gtav_dit_zero_grad
+ *   DDP's gradient all-reduce (accelerate)                                                         -> one all-reduce over the gradient arena
+ *                                                                                                     (gtav_comm_allreduce_f32 or torch.distributed)
+ * Mixed precision: fp16 MFMA operands with fp32 accumulation, fp32 master weights / gradients / optimizer state, a loss scale
+ * (default 65536) instead of bf16's exponent range; a non-finite gradient norm skips the step (gtav_dit_train_stats reports it).
+ * gtav_dit_train_enable must be called right after gtav_dit_create (before any gtav_dit_set_weight).  grad_arena_dev (optional):
+ * caller-owned device buffer of gtav_dit_train_param_count floats that receives all gradients contiguously, parameters in the
+ * lexicographic order of their state-dict names (NULL: the handle allocates it).  These calls allocate (enable) or synchronise
+ * (train_stats); forward / backward / adamw_step only enqueue. */
+int gtav_dit_train_param_count(gtav_dit* h, int64_t* numel);
+int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena_numel);
+int gtav_dit_set_loss_scale(gtav_dit* h, float scale);
+int gtav_dit_zero_grad(gtav_dit* h, void* stream);
+/* DiT.forward in training mode: same result as gtav_dit_forward, keeps the activations the backward pass needs. */
+int gtav_dit_train_forward(gtav_dit* h, const float* x_dev, const int64_t* t_dev, const float* actions_dev, float* out_dev,
+                           int32_t B, int32_t T, void* stream);
+/* Adds loss_scale * d mean((v_pred[:, -1] - v_target)^2) / d theta to the gradient arena.  v_pred (B,T,C,H,W) as returned by
+ * gtav_dit_train_forward, v_target (B,C,H,W). */
+int gtav_dit_train_backward(gtav_dit* h, const float* v_pred_dev, const float* v_target_dev, void* stream);
+/* Raw (loss-scaled) gradient of one parameter in torch layout. */
+int gtav_dit_get_grad(gtav_dit* h, const char* name, float* dst_dev, int64_t numel, void* stream);
+int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, void* stream);
+/* out4_host: sum of squares of the scaled gradients, step coefficient (0 = skipped), skipped steps so far, unscaled gradient norm. */
+int gtav_dit_train_stats(gtav_dit* h, float* out4_host, void* stream);
+
 /* Reads and clears the handle's device error word (synchronises): fails if, since the last call, a timestep was outside
  * [0, 999], an input held a NaN/inf, or an fp16 activation store saturated (|x| > 65504 is clamped to +-65504, never
  * inf: the reference runs bf16, which has fp32 range; a checkpoint with outlier channels is reported instead of

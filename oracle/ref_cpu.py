@@ -578,3 +578,32 @@ def actions_to_one_hot(actions) -> Tensor:
     m = a >= 0
     out[torch.arange(len(a))[m], a[m]] = 1
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Training step oracle: the reference obtains gradients from torch autograd (train_dit.py:680
+# `accelerator.backward(scaled_loss)`) and updates with torch.optim.AdamW (:232-238) after clip_grad_norm_ (:965-967).  Autograd
+# through this file's functional forward IS that computation on the CPU in fp32; nothing is re-derived by hand here.
+# ------------------------------------------------------------------------------------------------------------------------
+def dit_loss_and_grads(sd: Dict[str, Tensor], cfg: DiTConfig, x_noisy: Tensor, t: Tensor, actions: Optional[Tensor], v_target: Tensor):
+    """loss = mse(v_pred[:, -1:], v_target) (train_dit.py:649-650) and d loss / d every floating-point parameter but the rotary freqs."""
+    leaves = {k: v.detach().clone().requires_grad_(not k.endswith("freqs")) for k, v in sd.items()}
+    with torch.enable_grad():
+        v_pred = dit_forward(leaves, cfg, x_noisy, t, actions)
+        loss = torch.nn.functional.mse_loss(v_pred[:, -1:], v_target)
+        loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items() if not k.endswith("freqs")}
+    return loss.detach(), v_pred.detach(), grads
+
+
+def adamw_reference(params: Dict[str, Tensor], grads: Dict[str, Tensor], lr: float, weight_decay: float, max_grad_norm: float, steps: int = 1):
+    """clip_grad_norm_ + torch.optim.AdamW(betas=(0.9, 0.999), eps=1e-7) applied `steps` times with the same gradients."""
+    ps = [torch.nn.Parameter(v.detach().clone()) for v in params.values()]
+    opt = torch.optim.AdamW(ps, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.999), eps=1e-7)
+    norm = None
+    for _ in range(steps):
+        for p, g in zip(ps, grads.values()):
+            p.grad = g.detach().clone()
+        norm = torch.nn.utils.clip_grad_norm_(ps, max_grad_norm) if max_grad_norm > 0 else None
+        opt.step()
+    return {k: p.detach() for k, p in zip(params.keys(), ps)}, norm

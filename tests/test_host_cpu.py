@@ -212,3 +212,20 @@ def test_video_writer_and_one_hot(tmp_path):
         write_video(str(tmp_path / "bad.avi"), frames.float())
     oh = actions_to_one_hot([-1, 3, 0, 24, -1])
     assert oh.shape == (5, 25) and oh.sum().item() == 3 and oh[1, 3] == 1 and oh[0].sum() == 0
+
+
+def test_cosine_schedule_matches_transformers():
+    import pytest
+    import torch
+    from gtav_amd.train import cosine_with_min_lr
+    try:
+        from transformers.optimization import get_cosine_with_min_lr_schedule_with_warmup
+    except Exception:
+        pytest.skip("transformers scheduler not importable")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=3e-4)
+    sch = get_cosine_with_min_lr_schedule_with_warmup(opt, num_warmup_steps=10, num_training_steps=200, num_cycles=0.25, min_lr=1e-5)
+    for step in range(200):
+        assert abs(sch.get_last_lr()[0] - cosine_with_min_lr(step, 3e-4, 10, 200, 0.25, 1e-5)) < 1e-10, step
+        opt.step()
+        sch.step()

@@ -30,7 +30,7 @@ __device__ __forceinline__ void interleave() {
 // MODE bits: 1 = barrier per K-step, 2 = reads, 4 = MFMAs, 8 = interleave reads with MFMAs (else reads first), 16 = two reads per MFMA slot
 // XW extra waves do nothing but take part in the barriers (the loader waves of gemm_l_kernel when their fills are switched off)
 template <int WN, int WM, int FI, int FJ, int MODE, int XW = 0>
-__global__ __launch_bounds__(64 * (WN * WM + XW), 1) void kloop(int steps, float* out, unsigned long long* cyc) {
+__global__ __launch_bounds__(64 * (WN * WM + XW), 1) void kloop(int steps, float* out, unsigned long long* cyc, const char* src) {
     constexpr int NS = 4;
     constexpr int WPC = 2 * FI * WN, XPC = 2 * FJ * WM, STAGE = (WPC + XPC) * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -39,6 +39,32 @@ __global__ __launch_bounds__(64 * (WN * WM + XW), 1) void kloop(int steps, float
     __syncthreads();
     if (w < 0) {
         __syncthreads();
+        if constexpr ((MODE & 32) != 0 && XW > 0) {
+            // real loader waves: every K-step each of the XW waves issues its share of a (WPC + XPC)-piece tile by LDS-DMA from an
+            // L2-resident 2 MiB region into the ring (3 tiles in flight), like gemm_l_kernel's loaders
+            constexpr int NP = WPC + XPC, G = (NP + XW - 1) / (XW > 0 ? XW : 1);
+            const int lw = tid >> 6;
+            size_t off = ((size_t)blockIdx.x * 37 * NP * 1024) % (2u << 20);
+            auto stage = [&](int t) {
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    int q = lw * G + i;
+                    q = q < NP ? q : NP - 1;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + q * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(smem + (t % NS) * STAGE + q * 1024), 16, 0, 0);
+                }
+                off += NP * 1024;
+                if (off + NP * 1024 > (2u << 20)) off = 0;
+            };
+            for (int t = 0; t < NS - 1; ++t) stage(t);
+            for (int t = 0; t < steps; ++t) {
+                __builtin_amdgcn_s_waitcnt(waitcnt_imm((NS - 2) * G, 15));
+                asm volatile("s_barrier" ::: "memory");
+                stage(t + NS - 1);
+            }
+            __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+            return;
+        }
         if (MODE & 1) for (int t = 0; t < steps; ++t) asm volatile("s_barrier" ::: "memory");
         return;
     }
@@ -107,6 +133,7 @@ __global__ __launch_bounds__(64 * (WN * WM + XW), 1) void kloop(int steps, float
     if (w == 0 && lane == 0) { cyc[blockIdx.x] = c1 - c0; cyc[gridDim.x + blockIdx.x] = r1 - r0; }
 }
 
+static char* g_src = nullptr;
 template <int WN, int WM, int FI, int FJ, int MODE, int XW = 0>
 static void run(const char* what) {
     const int steps = 4000, cus = 256;
@@ -122,7 +149,7 @@ static void run(const char* what) {
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((kloop<WN, WM, FI, FJ, MODE, XW>), dim3(cus), dim3(64 * (WN * WM + XW)), LDS, 0, steps, out, cyc);
+        hipLaunchKernelGGL((kloop<WN, WM, FI, FJ, MODE, XW>), dim3(cus), dim3(64 * (WN * WM + XW)), LDS, 0, steps, out, cyc, (const char*)g_src);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -141,11 +168,18 @@ static void run(const char* what) {
 }
 
 int main() {
+    CK(hipMalloc((void**)&g_src, (2u << 20) + (1u << 20)));
+    CK(hipMemset(g_src, 0x3c, (2u << 20) + (1u << 20)));
     // 128 x 96 block tile
     run<4, 2, 2, 3, 1 | 2 | 4>("8 waves of 32x48, barrier, reads first");
     run<4, 2, 2, 3, 1 | 2 | 4 | 8>("8 waves of 32x48, barrier, interleaved 1/MFMA");
     run<4, 2, 2, 3, 1 | 2 | 4 | 8 | 16>("8 waves of 32x48, barrier, interleaved 2/MFMA");
     run<4, 2, 2, 3, 1 | 2 | 4 | 8, 4>("8 waves of 32x48 + 4 barrier-only waves, interleaved 1/MFMA");
+    run<4, 2, 2, 3, 1 | 2 | 4 | 8 | 32, 4>("8 waves of 32x48 + 4 LOADER waves (28 KiB / K-step by LDS-DMA)");
+    run<4, 2, 2, 3, 1 | 2 | 32, 4>("8 waves of 32x48 reads only + 4 LOADER waves");
+    run<4, 2, 2, 3, 1 | 32, 4>("8 waves barrier only + 4 LOADER waves (fill stream alone)");
+    run<4, 2, 2, 3, 1 | 4 | 32, 4>("8 waves of 32x48 MFMA only + 4 LOADER waves");
+    run<2, 2, 4, 3, 1 | 2 | 4 | 8 | 32, 4>("4 waves of 64x48 + 4 LOADER waves");
     run<4, 2, 2, 3, 2 | 4 | 8 | 16>("8 waves of 32x48, NO barrier, interleaved 2/MFMA");
     run<4, 2, 2, 3, 1 | 4>("8 waves of 32x48, barrier, MFMA only");
     run<4, 2, 2, 3, 4>("8 waves of 32x48, MFMA only, no barrier");
