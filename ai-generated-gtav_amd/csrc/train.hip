@@ -134,19 +134,27 @@ __global__ __launch_bounds__(512) void ln_mod_bwd_kernel(const float* __restrict
 }
 
 // dshift[f][d] = sum over the P tokens of frame f of dxn;  dscale[f][d] = sum of dxn xhat.  One thread per (frame, feature).
-__global__ void frame_reduce_ln_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats, int frames,
-                                       int P, int D, float* __restrict__ dshift, float* __restrict__ dscale, int mod_stride) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (d >= D) return;
+__global__ __launch_bounds__(256) void frame_reduce_ln_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats, int frames,
+                                                              int P, int D, float* __restrict__ dshift, float* __restrict__ dscale, int mod_stride) {
+    // block = 64 features x 4 token groups (tokens tg, tg + 4, ...): four times the loads in flight of one thread per feature
+    __shared__ float ra[4][64], rb[4][64];
+    const int dl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl, f = blockIdx.y;
     float a = 0.f, b = 0.f;
-    for (int t = 0; t < P; ++t) {
-        const size_t m = (size_t)f * P + t;
-        const float g = dxn[m * D + d];
-        a += g;
-        b += g * (x[m * D + d] - stats[2 * m]) * stats[2 * m + 1];
+    if (d < D)
+        for (int t = tg; t < P; t += 4) {
+            const size_t m = (size_t)f * P + t;
+            const float g = dxn[m * D + d];
+            a += g;
+            b += g * (x[m * D + d] - stats[2 * m]) * stats[2 * m + 1];
+        }
+    ra[tg][dl] = a;
+    rb[tg][dl] = b;
+    __syncthreads();
+    if (tg == 0 && d < D) {
+        dshift[(size_t)f * mod_stride + d] = (ra[0][dl] + ra[1][dl]) + (ra[2][dl] + ra[3][dl]);
+        dscale[(size_t)f * mod_stride + d] = (rb[0][dl] + rb[1][dl]) + (rb[2][dl] + rb[3][dl]);
     }
-    dshift[(size_t)f * mod_stride + d] = a;
-    dscale[(size_t)f * mod_stride + d] = b;
 }
 
 // Gated residual branch x += gate y (model/dit.py:207-223) backward: dy = gate dres -> fp16 TILE-MAJOR (the dX / dW GEMM operand);
@@ -164,29 +172,44 @@ __global__ void gate_bwd_kernel(const float* __restrict__ dres, const float* __r
     }
     sat_report(amax, err_flag);
 }
-__global__ void frame_reduce_gate_kernel(const float* __restrict__ dres, const f16* __restrict__ y, int frames, int P, int D,
-                                         float* __restrict__ dgate, int mod_stride) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (d >= D) return;
+__global__ __launch_bounds__(256) void frame_reduce_gate_kernel(const float* __restrict__ dres, const f16* __restrict__ y, int frames, int P, int D,
+                                                                float* __restrict__ dgate, int mod_stride) {
+    __shared__ float ra[4][64];
+    const int dl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl, f = blockIdx.y;
     float a = 0.f;
-    for (int t = 0; t < P; ++t) {
-        const size_t m = (size_t)f * P + t;
-        a += dres[m * D + d] * (float)y[m * D + d];
-    }
-    dgate[(size_t)f * mod_stride + d] = a;
+    if (d < D)
+        for (int t = tg; t < P; t += 4) {
+            const size_t m = (size_t)f * P + t;
+            a += dres[m * D + d] * (float)y[m * D + d];
+        }
+    ra[tg][dl] = a;
+    __syncthreads();
+    if (tg == 0 && d < D) dgate[(size_t)f * mod_stride + d] = (ra[0][dl] + ra[1][dl]) + (ra[2][dl] + ra[3][dl]);
 }
 
-// db[n] += sum_m dY[m][n] for a tile-major fp16 dY (logical [M][N], N % 64 == 0).  Block = one 64-column tile column x a slice of rows.
+// db[n] += sum_m dY[m][n] for a tile-major fp16 dY (logical [M][N], N % 64 == 0).  Block = one 64-column tile column x a slice of rows;
+// thread = (8-column chunk, row lane): one 16-byte load per row.
 __global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block) {
-    __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + c;
+    __shared__ float part[32][65];
+    const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int n0 = blockIdx.x * 64;
     const int r_begin = blockIdx.y * rows_per_block, r_end = min(M, r_begin + rows_per_block);
-    float a = 0.f;
-    for (int r = r_begin + rg; r < r_end; r += 4) a += (float)dy[tiled_off(r, n, N)];
-    part[rg][c] = a;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = r_begin + rl; r < r_end; r += 32) {
+        union { uint4 q; f16 e[8]; } v;
+        v.q = *(const uint4*)(dy + tiled_off(r, n0 + 8 * ch, N));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += (float)v.e[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[rl][8 * ch + i] = a[i];
     __syncthreads();
-    if (rg == 0) atomicAdd(db + n, (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]));
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
+        atomicAdd(db + n0 + threadIdx.x, t);
+    }
 }
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ db, int rows_per_block) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -243,58 +266,87 @@ __global__ void mse_bwd_patch_kernel(const float* __restrict__ vpred, const floa
 // Query rows are processed 16 at a time: their P and dS rows live in LDS, dK / dV accumulate in registers (thread = (d, key group)).
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int AB_MAXS = 160;   // S <= 160 (DiT: 144)
-__global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
-                                                               const f16* __restrict__ dO, int heads, int S, int D,
-                                                               const float* __restrict__ rope_cs, f16* __restrict__ dqkv, int* err_flag) {
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot8(const f16x8& a, const f16x8& b, float acc) {
+    // v_dot2_f32_f16: two fp16 products accumulated in fp32 per instruction
+    acc = __builtin_amdgcn_fdot2(f16x2{a[0], a[1]}, f16x2{b[0], b[1]}, acc, false);
+    acc = __builtin_amdgcn_fdot2(f16x2{a[2], a[3]}, f16x2{b[2], b[3]}, acc, false);
+    acc = __builtin_amdgcn_fdot2(f16x2{a[4], a[5]}, f16x2{b[4], b[5]}, acc, false);
+    acc = __builtin_amdgcn_fdot2(f16x2{a[6], a[7]}, f16x2{b[6], b[7]}, acc, false);
+    return acc;
+}
+template <int NT>   // threads per block: NT / 16 query rows per row block, NT / 64 key groups
+__global__ __launch_bounds__(NT) void attn_spatial_bwd_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+                                                              const f16* __restrict__ dO, int heads, int S, int D,
+                                                              const float* __restrict__ rope_cs, f16* __restrict__ dqkv, int* err_flag) {
+    constexpr int RB = NT / 16, JG = NT / 64;
     extern __shared__ __attribute__((aligned(16))) char smraw[];
-    f16* sQ = (f16*)smraw;                 // [S][64]
-    f16* sK = sQ + S * 64;
-    f16* sV = sK + S * 64;                 // [S][64] (transposed back from Vt)
-    f16* sdO = sV + S * 64;
-    float* sP = (float*)(sdO + S * 64);    // [16][S]
-    float* sdS = sP + 16 * S;              // [16][S]
+    // rows of 64 halves padded to 72 (144 bytes): a 16-byte read of consecutive rows by consecutive lanes is bank-conflict free
+    constexpr int LP = 72;
+    f16* sQ = (f16*)smraw;                 // [S][LP]
+    f16* sK = sQ + S * LP;
+    f16* sV = sK + S * LP;                 // [S][LP] (transposed back from Vt)
+    f16* sdO = sV + S * LP;
+    float* sP = (float*)(sdO + S * LP);    // [RB][SP]
+    const int SP = S + 4;                  // fp32 row pitch of the P / dS row blocks
+    float* sdS = sP + RB * SP;
     const int item = blockIdx.x, nb = item / heads, head = item % heads;
     const int tid = threadIdx.x;
     const f16* q = Q + (size_t)item * S * 64;
     const f16* k = K + (size_t)item * S * 64;
     const f16* vt = Vt + (size_t)item * 64 * S;
-    for (int i = tid; i < S * 8; i += 256) {       // 16-byte chunks
-        ((uint4*)sQ)[i] = ((const uint4*)q)[i];
-        ((uint4*)sK)[i] = ((const uint4*)k)[i];
+    for (int i = tid; i < S * 8; i += NT) {        // 16-byte chunks
         const int s = i >> 3, ch = i & 7;
-        ((uint4*)sdO)[i] = *(const uint4*)(dO + ((size_t)nb * S + s) * D + head * 64 + 8 * ch);
+        *(uint4*)(sQ + s * LP + 8 * ch) = ((const uint4*)q)[i];
+        *(uint4*)(sK + s * LP + 8 * ch) = ((const uint4*)k)[i];
+        *(uint4*)(sdO + s * LP + 8 * ch) = *(const uint4*)(dO + ((size_t)nb * S + s) * D + head * 64 + 8 * ch);
     }
-    for (int i = tid; i < S * 64; i += 256) {
+    for (int i = tid; i < S * 64; i += NT) {
         const int d = i / S, s = i % S;
-        sV[s * 64 + d] = vt[i];
+        sV[s * LP + d] = vt[i];
     }
     __syncthreads();
-    const int d_own = tid & 63, jg = tid >> 6;     // dK / dV ownership: feature d, keys j = jg, jg + 4, ...
-    constexpr int JMAX = AB_MAXS / 4;
-    float accK[JMAX], accV[JMAX];
+    // dK / dV ownership: feature d_own, keys j = 4 JG c + 4 jg + e (e < 4): the P / dS rows are read as float4
+    const int d_own = tid & 63, jg = tid >> 6;
+    constexpr int CMAX = (AB_MAXS + 4 * JG - 1) / (4 * JG);
+    f32x4 accK[CMAX], accV[CMAX];
 #pragma unroll
-    for (int i = 0; i < JMAX; ++i) accK[i] = accV[i] = 0.f;
-    const int ri = tid >> 4, cj = tid & 15;        // score ownership: query row ri of the 16-row block, keys cj, cj + 16, ...
+    for (int c = 0; c < CMAX; ++c) accK[c] = accV[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ri = tid >> 4, cj = tid & 15;        // score ownership: query row ri of the RB-row block, keys cj, cj + 16, ...
     float amax = 0.f;
-    for (int r0 = 0; r0 < S; r0 += 16) {
+    for (int r0 = 0; r0 < S; r0 += RB) {
         const int i = r0 + ri;
+        const bool iv = i < S;
         constexpr int NJ = AB_MAXS / 16;
         float sc[NJ], dp[NJ];
         float mx = -INFINITY;
+        {
+            // this thread's query row and its output-gradient row stay in registers for the whole block of keys
+            f16x8 qr[8], gr[8];
+            const int ic = iv ? i : S - 1;
 #pragma unroll
-        for (int c = 0; c < NJ; ++c) {
-            const int j = cj + 16 * c;
-            sc[c] = -INFINITY;
-            dp[c] = 0.f;
-            if (j < S && i < S) {
-                float a = 0.f, b = 0.f;
-                for (int d = 0; d < 64; d += 2) {
-                    a += (float)sQ[i * 64 + d] * (float)sK[j * 64 + d] + (float)sQ[i * 64 + d + 1] * (float)sK[j * 64 + d + 1];
-                    b += (float)sdO[i * 64 + d] * (float)sV[j * 64 + d] + (float)sdO[i * 64 + d + 1] * (float)sV[j * 64 + d + 1];
+            for (int ch = 0; ch < 8; ++ch) {
+                qr[ch] = *(const f16x8*)(sQ + ic * LP + 8 * ch);
+                gr[ch] = *(const f16x8*)(sdO + ic * LP + 8 * ch);
+            }
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) {
+                const int j = cj + 16 * c;
+                sc[c] = -INFINITY;
+                dp[c] = 0.f;
+                if (j < S) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        a = dot8(qr[ch], *(const f16x8*)(sK + j * LP + 8 * ch), a);
+                        b = dot8(gr[ch], *(const f16x8*)(sV + j * LP + 8 * ch), b);
+                    }
+                    if (iv) {
+                        sc[c] = a * 0.125f;
+                        dp[c] = b;
+                        mx = fmaxf(mx, sc[c]);
+                    }
                 }
-                sc[c] = a * 0.125f;
-                dp[c] = b;
-                mx = fmaxf(mx, sc[c]);
             }
         }
 #pragma unroll
@@ -302,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const f16* __rest
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NJ; ++c) {
-            sc[c] = (cj + 16 * c < S && i < S) ? __expf(sc[c] - mx) : 0.f;
+            sc[c] = (cj + 16 * c < S && iv) ? __expf(sc[c] - mx) : 0.f;
             sum += sc[c];
         }
 #pragma unroll
@@ -319,54 +371,59 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const f16* __rest
 #pragma unroll
         for (int c = 0; c < NJ; ++c) {
             const int j = cj + 16 * c;
-            if (j < S) {
-                sP[ri * S + j] = sc[c];
-                sdS[ri * S + j] = sc[c] * (dp[c] - dsum) * 0.125f;
+            if (j < S) {       // rows beyond S hold zeros (sc = 0): the dK / dV loops below may read all 16 rows
+                sP[ri * SP + j] = sc[c];
+                sdS[ri * SP + j] = sc[c] * (dp[c] - dsum) * 0.125f;
             }
         }
         __syncthreads();
         // dQ rows of this block: 16 x 64 outputs, 4 per thread (row ri, features 4 cj .. 4 cj + 3); RoPE^T; store
-        if (i < S) {
+        if (iv) {
             float dq[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < S; ++j) {
-                const float w = sdS[ri * S + j];
+            for (int j = 0; j < S; j += 4) {
+                const f32x4 w4 = *(const f32x4*)(sdS + ri * SP + j);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dq[e] += w * (float)sK[j * 64 + 4 * cj + e];
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f16x4 kx = *(const f16x4*)(sK + (j + jj) * LP + 4 * cj);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dq[e] += w4[jj] * (float)kx[e];
+                }
             }
             const f32x4 cs = *(const f32x4*)(rope_cs + (size_t)i * 64 + 4 * cj);
             const float o0 = dq[0] * cs[0] + dq[1] * cs[1], o1 = dq[1] * cs[0] - dq[0] * cs[1];
             const float o2 = dq[2] * cs[2] + dq[3] * cs[3], o3 = dq[3] * cs[2] - dq[2] * cs[3];
             *(f16x4*)(dqkv + tiled_off(nb * S + i, head * 64 + 4 * cj, 3 * D)) = sat4(o0, o1, o2, o3, amax);
         }
-        // dV[j][d] += sum_i P[i][j] dO[i][d];  dK[j][d] += sum_i dS[i][j] Q[i][d]
-        const int rows = min(16, S - r0);
+        // dV[j][d] += sum_r P[r][j] dO[r][d];  dK[j][d] += sum_r dS[r][j] Q[r][d]   (rows past S contribute zeros)
+        const int rows = min(RB, S - r0);
+        for (int r = 0; r < rows; ++r) {
+            const float go = (float)sdO[(r0 + r) * LP + d_own], qq = (float)sQ[(r0 + r) * LP + d_own];
 #pragma unroll
-        for (int c = 0; c < JMAX; ++c) {
-            const int j = jg + 4 * c;
-            if (j < S) {
-                float av = 0.f, ak = 0.f;
-                for (int r = 0; r < rows; ++r) {
-                    av += sP[r * S + j] * (float)sdO[(r0 + r) * 64 + d_own];
-                    ak += sdS[r * S + j] * (float)sQ[(r0 + r) * 64 + d_own];
+            for (int c = 0; c < CMAX; ++c) {
+                const int j = 4 * JG * c + 4 * jg;
+                if (j < S) {
+                    accV[c] += *(const f32x4*)(sP + r * SP + j) * go;
+                    accK[c] += *(const f32x4*)(sdS + r * SP + j) * qq;
                 }
-                accV[c] += av;
-                accK[c] += ak;
             }
         }
         __syncthreads();
     }
     // dK (RoPE^T needs the pair partner: lanes d and d ^ 1 are neighbours in the wave) and dV
 #pragma unroll
-    for (int c = 0; c < JMAX; ++c) {
-        const int j = jg + 4 * c;
-        if (j < S) {      // uniform per wave: j depends on jg (= the wave index) and c only
-            const float mine = accK[c], other = __shfl_xor(mine, 1, 64);
-            const float co = rope_cs[(size_t)j * 64 + (d_own & ~1)], si = rope_cs[(size_t)j * 64 + (d_own | 1)];
-            const float dk = (d_own & 1) ? mine * co - other * si : mine * co + other * si;
-            const size_t m = (size_t)nb * S + j;
-            amax = fmaxf(amax, fmaxf(fabsf(dk), fabsf(accV[c])));
-            dqkv[tiled_off((int)m, D + head * 64 + d_own, 3 * D)] = (f16)__builtin_amdgcn_fmed3f(dk, -F16_MAX, F16_MAX);
-            dqkv[tiled_off((int)m, 2 * D + head * 64 + d_own, 3 * D)] = (f16)__builtin_amdgcn_fmed3f(accV[c], -F16_MAX, F16_MAX);
+    for (int c = 0; c < CMAX; ++c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * JG * c + 4 * jg + e;
+            if (j < S) {      // uniform per wave: j depends on jg (= the wave index), c and e only
+                const float mine = accK[c][e], other = __shfl_xor(mine, 1, 64);
+                const float co = rope_cs[(size_t)j * 64 + (d_own & ~1)], si = rope_cs[(size_t)j * 64 + (d_own | 1)];
+                const float dk = (d_own & 1) ? mine * co - other * si : mine * co + other * si;
+                const size_t m = (size_t)nb * S + j;
+                amax = fmaxf(amax, fmaxf(fabsf(dk), fabsf(accV[c][e])));
+                dqkv[tiled_off((int)m, D + head * 64 + d_own, 3 * D)] = (f16)__builtin_amdgcn_fmed3f(dk, -F16_MAX, F16_MAX);
+                dqkv[tiled_off((int)m, 2 * D + head * 64 + d_own, 3 * D)] = (f16)__builtin_amdgcn_fmed3f(accV[c][e], -F16_MAX, F16_MAX);
+            }
         }
     }
     sat_report(amax, err_flag);
@@ -474,15 +531,30 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dy, int lddy, const fl
         dx[(size_t)r * lddx + c] = dy[(size_t)r * lddy + c] * s * (1.0f + v * (1.0f - s));
     }
 }
-// dW[n][k] += sum_r dY[r][n] X[r][k]      (one thread per (n, k); R is tens of rows)
-__global__ void gemm_tn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx, int R, int N, int K, float* __restrict__ dW,
-                                   int lddw) {
+// dW[n][k] += sum_r dY[r][n] X[r][k]      (one thread per (8 rows n, column k); R is tens of rows: per r one coalesced X load,
+// eight broadcast dY values, eight FMAs)
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx, int R, int N, int K,
+                                                          float* __restrict__ dW, int lddw) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t n = blockIdx.y;
+    const int n0 = blockIdx.y * 8;
     if (k >= K) return;
-    float a = 0.f;
-    for (int r = 0; r < R; ++r) a += dY[(size_t)r * lddy + n] * X[(size_t)r * ldx + k];
-    dW[n * lddw + k] += a;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool full = n0 + 8 <= N && (lddy & 3) == 0 && (((size_t)dY & 15) == 0) && (n0 & 3) == 0;
+    for (int r = 0; r < R; ++r) {
+        const float x = X[(size_t)r * ldx + k];
+        const float* dy = dY + (size_t)r * lddy + n0;
+        if (full) {
+            const f32x4 d0 = *(const f32x4*)dy, d1 = *(const f32x4*)(dy + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] += d0[i] * x; a[4 + i] += d1[i] * x; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] += (n0 + i < N ? dy[i] : 0.f) * x;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (n0 + i < N) dW[(size_t)(n0 + i) * lddw + k] += a[i];
 }
 // dX[r][k] = sum_n dY[r][n] W[n][k]       (one thread per (r, k))
 __global__ void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ W, int ldw, int R, int N, int K, float* __restrict__ dX,
@@ -495,20 +567,21 @@ __global__ void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const
     dX[(size_t)r * lddx + k] = a;
 }
 // The adaLN projection mod = SiLU(c) W_ada^T + b_ada with W_ada [MODW][D] (MODW ~ 2 x 10^5): dSc[r][n] = sum_k dmod[r][k] W_ada[k][n].
-// Block = (256 features n) x (a chunk of KC rows k of W_ada), up to 16 conditioning rows per pass in registers; W_ada is read once
-// per pass (0.8 GB at full size, re-read from L2 for the next 16 rows), partial sums leave by atomics into the zeroed dSc.
+// Block = (256 features n) x (a chunk of KC rows k of W_ada), up to ADA_RB conditioning rows per pass in registers; W_ada is read once
+// per pass (0.8 GB at full size), partial sums leave by atomics into the zeroed dSc.
+constexpr int ADA_RB = 40;   // conditioning rows per pass (registers): the training batch of 16 x 5 rows takes two passes over W_ada
 __global__ __launch_bounds__(256) void ada_bwd_dx_kernel(const float* __restrict__ dmod, int MODW, const float* __restrict__ W, int D, int R, int KC,
                                                          float* __restrict__ dSc) {
-    __shared__ float sd[16][256];
+    __shared__ float sd[ADA_RB][256];
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int k0 = blockIdx.y * KC, k1 = min(MODW, k0 + KC);
-    for (int rb = 0; rb < R; rb += 16) {
-        float acc[16];
+    for (int rb = 0; rb < R; rb += ADA_RB) {
+        float acc[ADA_RB];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < ADA_RB; ++i) acc[i] = 0.f;
         for (int kb = k0; kb < k1; kb += 256) {
             __syncthreads();
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < ADA_RB; ++i) {
                 const int k = kb + threadIdx.x;
                 sd[i][threadIdx.x] = (rb + i < R && k < k1) ? dmod[(size_t)(rb + i) * MODW + k] : 0.f;
             }
@@ -518,12 +591,12 @@ __global__ __launch_bounds__(256) void ada_bwd_dx_kernel(const float* __restrict
                 for (int kk = 0; kk < kn; ++kk) {
                     const float w = W[(size_t)(kb + kk) * D + n];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[i] += sd[i][kk] * w;
+                    for (int i = 0; i < ADA_RB; ++i) acc[i] += sd[i][kk] * w;
                 }
         }
         if (n < D)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < ADA_RB; ++i)
                 if (rb + i < R) atomicAdd(dSc + (size_t)(rb + i) * D + n, acc[i]);
     }
 }
@@ -608,7 +681,7 @@ int launch_ln_mod_bwd(const float* dxn, const float* x, const float* scale, int 
 }
 int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats, int frames, int P, int D, float* dshift, float* dscale, int mod_stride,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(frame_reduce_ln_kernel, dim3(cdiv(D, 256), frames), dim3(256), 0, stream, dxn, x, stats, frames, P, D, dshift, dscale, mod_stride);
+    hipLaunchKernelGGL(frame_reduce_ln_kernel, dim3(cdiv(D, 64), frames), dim3(256), 0, stream, dxn, x, stats, frames, P, D, dshift, dscale, mod_stride);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -619,7 +692,7 @@ int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int ro
     return 0;
 }
 int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream) {
-    hipLaunchKernelGGL(frame_reduce_gate_kernel, dim3(cdiv(D, 256), frames), dim3(256), 0, stream, dres, y, frames, P, D, dgate, mod_stride);
+    hipLaunchKernelGGL(frame_reduce_gate_kernel, dim3(cdiv(D, 64), frames), dim3(256), 0, stream, dres, y, frames, P, D, dgate, mod_stride);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -652,16 +725,18 @@ int launch_mse_bwd_patch(const float* vpred, const float* vtarget, int B, int T,
 }
 int launch_attn_spatial_bwd(const f16* Q, const f16* K, const f16* Vt, const f16* dO, int NB, int heads, int S, int D, const float* rope_cs, f16* dqkv,
                             int* err_flag, hipStream_t stream) {
-    GTAV_REQUIRE(S > 0 && S <= AB_MAXS && S % 8 == 0 && D == heads * 64, "attn_spatial_bwd: S=%d (<= %d), D=%d", S, AB_MAXS, D);
-    const size_t lds = (size_t)4 * S * 64 * 2 + (size_t)2 * 16 * S * 4;
+    GTAV_REQUIRE(S > 0 && S <= AB_MAXS && S % 16 == 0 && D == heads * 64, "attn_spatial_bwd: S=%d (<= %d, %% 16), D=%d", S, AB_MAXS, D);
+    constexpr int NT = 512;
+    const size_t lds = (size_t)4 * S * 72 * 2 + (size_t)2 * (NT / 16) * (S + 4) * 4;
     static unsigned long long attr_devs = 0;
     int dev = 0;
     GTAV_CHECK_HIP(hipGetDevice(&dev));
     if (!(attr_devs >> (dev & 63) & 1)) {
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_devs |= 1ull << (dev & 63);
     }
-    hipLaunchKernelGGL(attn_spatial_bwd_kernel, dim3(NB * heads), dim3(256), lds, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+    GTAV_REQUIRE(lds <= 160 * 1024, "attn_spatial_bwd: S=%d needs %zu bytes of LDS", S, lds);
+    hipLaunchKernelGGL(attn_spatial_bwd_kernel<NT>, dim3(NB * heads), dim3(NT), lds, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -687,7 +762,7 @@ int launch_silu_bwd(const float* dy, int lddy, const float* x, int ldx, float* d
     return 0;
 }
 int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R, int N, int K, float* dW, int lddw, hipStream_t stream) {
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(cdiv(K, 256), N), dim3(256), 0, stream, dY, lddy, X, ldx, R, N, K, dW, lddw);
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(cdiv(K, 256), cdiv(N, 8)), dim3(256), 0, stream, dY, lddy, X, ldx, R, N, K, dW, lddw);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -69,6 +69,11 @@ SIGNATURES = {
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "gtav_comm_unique_id": [_p],
+    "gtav_comm_init": [C.POINTER(_p), _i, _i, _p],
+    "gtav_comm_allreduce_f32": [_p, _p, _l, _i, _p],
+    "gtav_comm_allgather": [_p, _p, _p, _l, _p],
+    "gtav_comm_destroy": [_p],
     "gtav_vae_create": [C.POINTER(VaeConfig), C.POINTER(_p)],
     "gtav_vae_destroy": [_p],
     "gtav_vae_set_weight": [_p, C.c_char_p, _p, _l, _p],

@@ -140,9 +140,11 @@ def parse_args(argv=None):
     ap.add_argument("--batched-clips", type=int, default=2,
                     help="timed clips per algorithm of the bounded batch-8 + actions leg (config2 / config3); 0 disables it")
     ap.add_argument("--batched-batch", type=int, default=8)
-    ap.add_argument("--mode", choices=["generate", "train"], default="generate",
+    ap.add_argument("--mode", choices=["generate", "train", "train_step"], default="generate",
                     help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
-                         "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline)")
+                         "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline); "
+                         "train_step = the whole optimisation step (SURVEY.md 8(f)1): that forward, backward, gradient all-reduce, "
+                         "clip + AdamW")
     return ap.parse_args(argv)
 
 
@@ -158,7 +160,8 @@ def bench_train(args, world, rank, dev, dist, torch):
     from gtav_amd.model.vae import VAE_models
     from gtav_amd.train import encode_frames, forward_loss
     B = args.batch_per_gpu if args.batch_per_gpu > 1 else 16
-    dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+    full = args.mode == "train_step"
+    dit = DiT_models["DiT-S/2"](init_weights=False, max_batch=B, trainable=full)
     dit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
     vae = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=40)
     vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
@@ -171,9 +174,14 @@ def bench_train(args, world, rank, dev, dist, torch):
     ctx_noise = torch.randn(B, 4, 16, 18, 32, generator=g).to(dev)
     noise = torch.randn(B, 1, 16, 18, 32, generator=g).to(dev)
 
+    from gtav_amd.train import training_step
+
     def step():
         lat = encode_frames(vae, frames)
-        loss, _, _ = forward_loss(dit, lat, actions, tgt, ctx, ctx_noise, noise)
+        if full:
+            loss = training_step(dit, lat, actions, tgt, ctx, ctx_noise, noise, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, world_size=world).clone()
+        else:
+            loss, _, _ = forward_loss(dit, lat, actions, tgt, ctx, ctx_noise, noise)
         if world > 1:
             dist.all_reduce(loss, op=dist.ReduceOp.SUM)
             loss /= world
@@ -196,14 +204,24 @@ def bench_train(args, world, rank, dev, dist, torch):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
     if rank == 0:
-        flops = B * (dit_forward_flops(5 * P_TOK, 5, 15, 1) + 5 * 96.6e9)   # DiT forward + VAE encode
+        flops = B * ((3 if full else 1) * dit_forward_flops(5 * P_TOK, 5, 15, 1) + 5 * 96.6e9)   # DiT forward (+ 2x for backward) + VAE encode
+        extra = {}
+        if full:
+            applied, skipped, gnorm = dit.train_stats()
+            extra = {"optimizer": "AdamW (betas 0.9 / 0.999, eps 1e-7, wd 0.01), clip_grad_norm 1.0, loss scale %g" % dit.loss_scale,
+                     "last_step_applied": bool(applied), "skipped_steps": skipped, "grad_norm": gnorm}
         print(json.dumps({
-            "metric": "training forward+loss samples/sec (5-frame clips, configs/train_dit_actions.yaml shapes)",
+            "metric": ("training step samples/sec (forward + backward + all-reduce + AdamW" if full else "training forward+loss samples/sec (") +
+                      ("; 5-frame clips, configs/train_dit_actions.yaml shapes)" if full else "5-frame clips, configs/train_dit_actions.yaml shapes)"),
+            **extra,
             "value": round(world * B * args.steps / el, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp16 (fp32 accumulate/residual)", "data": "synthetic", "loss": float(loss.item()),
-            "config": {"workload": "BASELINE configs[4]: train_dit.py forward+loss, batch %d per GPU, DiT-S/2 + VAE encode of %d frames" % (B, 5 * B),
-                       "global_batch": world * B, "parallelism": "data-parallel x%d (forward only; loss all-reduce)" % world},
+            "config": {"workload": ("SURVEY.md 8(f)1: train_dit.py optimisation step" if full else "BASELINE configs[4]: train_dit.py forward+loss") +
+                                   ", batch %d per GPU, DiT-S/2 + VAE encode of %d frames" % (B, 5 * B),
+                       "global_batch": world * B,
+                       "parallelism": ("data-parallel x%d (one all-reduce of the 2.4 GB fp32 gradient arena per step)" if full else
+                                       "data-parallel x%d (forward only; loss all-reduce)") % world},
             "achieved_tflops_per_gpu": round(flops * args.steps / el / 1e12, 1)}))
 
 
@@ -225,7 +243,7 @@ def rank_main(args):
         dist.init_process_group(backend="nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
     try:
-        if args.mode == "train":
+        if args.mode in ("train", "train_step"):
             bench_train(args, world, rank, dev, dist, torch)
         else:
             bench_generate(args, world, rank, dev, dist, torch)

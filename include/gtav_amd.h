@@ -258,6 +258,19 @@ void gtav_op_gemm_set_wm(int32_t wm);
 int gtav_op_convert_f16(const float* src_dev, int32_t lds, int32_t R, int32_t C, void* dst_f16_dev, int32_t Rp,
                         int32_t Cp, int32_t tiled, void* stream);
 
+/* ---- collectives: RCCL over xGMI through the C-ABI, one communicator per process / GPU ------------------
+ * Replaces what the reference gets from accelerate / torch.distributed (train_dit.py:199-203 Accelerator, DDP gradient averaging;
+ * README.md:119-122 `accelerate launch`, one process per GPU).  Rank 0 calls gtav_comm_unique_id and hands the 128 bytes to the other
+ * ranks out of band (MPI, a file, a socket); every rank then calls gtav_comm_init on its own device.  librccl.so is opened at run
+ * time (a copy already loaded into the process is reused).  allreduce: in place, fp32, sum or average; allgather: rank r's
+ * bytes_per_rank bytes land at recv + r * bytes_per_rank on every rank.  Calls enqueue on `stream` (init / destroy synchronise). */
+typedef struct gtav_comm gtav_comm;
+int gtav_comm_unique_id(void* id128_host);
+int gtav_comm_init(gtav_comm** out, int32_t nranks, int32_t rank, const void* id128_host);
+int gtav_comm_allreduce_f32(gtav_comm* c, float* buf_dev, int64_t count, int32_t average, void* stream);
+int gtav_comm_allgather(gtav_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
+int gtav_comm_destroy(gtav_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,3 +132,48 @@ def test_training_step_reduces_the_loss():
     losses = [float(training_step(m, lat, a.new_zeros(2, 5, 25), tgt, ctx, cn, nz, lr=2e-4, weight_decay=0.0, max_grad_norm=1.0)) for _ in range(8)]
     assert all(math.isfinite(l) for l in losses)
     assert losses[-1] < losses[0] * 0.9, losses
+
+
+def test_comm_c_abi_single_rank():
+    """gtav_comm_* (RCCL opened at run time) on a communicator of one rank: id, init, all-reduce (sum and average are the identity),
+    all-gather (rank 0's bytes at slot 0).  The multi-rank arithmetic is RCCL's; what is checked here is the binding."""
+    from gtav_amd.comm import Comm
+    torch.cuda.set_device(0)
+    c = Comm(1, 0, Comm.unique_id())
+    t = torch.arange(1000, device=dev(), dtype=torch.float32)
+    ref = t.clone()
+    c.all_reduce_(t)
+    c.all_reduce_(t, average=True)
+    g = c.all_gather(t.half())
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref) and g.shape == (1, 1000) and torch.equal(g[0], ref.half())
+    c.close()
+
+
+def test_full_size_gradients_match_autograd():
+    """DiT-S/2 at its real size (depth 16, hidden 1024, 18 x 32 latents; B = 1, T = 5 with actions: M = 720 tokens, the shapes the
+    loader-wave GEMM, the split-K residual GEMMs and the 144-token spatial attention backward run in production)."""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT_models
+    from oracle import ref_cpu as O
+    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 5, 16, 18, 32, generator=g) * 0.7
+    t = torch.tensor([[15, 15, 15, 15, 420]])
+    a = torch.zeros(1, 5, 25)
+    a[:, :, 3] = 1
+    vt = torch.randn(1, 1, 16, 18, 32, generator=g)
+    torch.set_num_threads(16)
+    _, v_ref, grads = O.dit_loss_and_grads(sd, O.dit_s_2(), x, t, a, vt)
+    m = DiT_models["DiT-S/2"](init_weights=False, max_batch=1, trainable=True)
+    m.load_state_dict(sd)
+    v = m.forward_train(x, t, a)
+    assert rel_l2(v, v_ref) < 1e-3
+    m.zero_grad()
+    m.backward_(v, vt)
+    m.check()
+    keys = ["x_embedder.proj.weight", "t_embedder.mlp.0.weight", "external_cond.weight", "blocks.0.s_attn.to_qkv.weight", "blocks.0.t_attn.to_out.weight",
+            "blocks.7.s_mlp.fc1.weight", "blocks.7.t_mlp.fc2.weight", "blocks.7.t_adaLN_modulation.1.weight", "blocks.15.t_attn.to_qkv.weight",
+            "blocks.15.s_mlp.fc2.bias", "final_layer.linear.weight", "final_layer.adaLN_modulation.1.bias"]
+    worst = {k: rel_l2(m.grad(k), grads[k]) for k in keys}
+    assert max(worst.values()) < 1e-2, worst
