@@ -229,3 +229,72 @@ def test_cosine_schedule_matches_transformers():
         assert abs(sch.get_last_lr()[0] - cosine_with_min_lr(step, 3e-4, 10, 200, 0.25, 1e-5)) < 1e-10, step
         opt.step()
         sch.step()
+
+
+def _grad_allreduce_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gtav_amd.train import all_reduce_gradients
+
+    class FakeDit:          # the trainer only touches .grad_arena: one contiguous fp32 tensor (the GPU model's gradient arena)
+        grad_arena = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    d = FakeDit()
+    all_reduce_gradients(d, world)
+    q.put((rank, d.grad_arena.clone()))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_averages_over_ranks_gloo():
+    """train.all_reduce_gradients (DDP's gradient averaging, one all-reduce over the contiguous arena) on two gloo ranks."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_grad_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.arange(10, dtype=torch.float32) * 1.5          # mean of 1x and 2x
+    assert torch.equal(outs[0], want) and torch.equal(outs[1], want)
+
+
+def test_oracle_autograd_matches_finite_difference():
+    """The training oracle (autograd through ref_cpu.dit_forward) against a central finite difference of the loss in two parameter
+    directions on a tiny model: pins that `dit_loss_and_grads` differentiates the function the forward tests pin.  The oracle is fp32
+    (the reference's CPU path), so the difference quotient is taken with a step of 1e-2 along a unit direction: agreement to 1 %."""
+    import torch
+    import gtav_amd.weights as W
+    from oracle import ref_cpu as O
+    kw = dict(input_h=4, input_w=8, patch_size=2, in_channels=16, hidden_size=128, depth=1, num_heads=2, external_cond_dim=25)
+    sd = W.synth_state_dict(W.dit_param_shapes(**kw), seed=2)
+    cfg = O.DiTConfig(**kw)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 2, 16, 4, 8, generator=g)
+    t = torch.tensor([[10, 500]])
+    a = torch.zeros(1, 2, 25)
+    a[:, :, 3] = 1
+    vt = torch.randn(1, 1, 16, 4, 8, generator=g)
+    loss, _, grads = O.dit_loss_and_grads(sd, cfg, x, t, a, vt)
+
+    def loss_at(sd2):
+        with torch.no_grad():
+            return torch.nn.functional.mse_loss(O.dit_forward(sd2, cfg, x, t, a)[:, -1:], vt).double()
+    for k in ("blocks.0.t_mlp.fc1.weight", "blocks.0.s_adaLN_modulation.1.weight", "final_layer.linear.weight"):
+        d = grads[k] / grads[k].norm()                  # steepest direction: the largest signal against fp32 rounding of the loss
+        eps = 1e-2
+        sp, sm = dict(sd), dict(sd)
+        sp[k] = sd[k] + eps * d
+        sm[k] = sd[k] - eps * d
+        fd = float((loss_at(sp) - loss_at(sm)) / (2 * eps))
+        an = float((grads[k] * d).sum())
+        assert abs(fd - an) <= 1e-2 * abs(an) + 1e-6, (k, fd, an)
