@@ -4,6 +4,7 @@
 #include "ops.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #include <cstring>
 
@@ -560,6 +561,9 @@ static int g_ln_flags = GTAV_ENV_INT("GTAV_LN_FLAGS", 3);   // default: all stor
 // One block per row at every M since the write-through stores: B = 8 (M = 5760) LN 1.71 -> 1.43 ms per forward against the
 // wave-per-row kernel, M = 11 520 / 46 080 neutral.  GTAV_LN_ROWBLOCK_MAX restores a threshold for experiments.
 static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
+// (Round 2 tried one wave per row with no LDS and no barrier for a few hundred rows — bit-identical statistics, a quarter of the
+// waves to start: 5.2-5.3 us per launch against 4.9 for the row-block kernel at M = 720 in a one-process A/B, profiles/round2/
+// forward_ab_B1_ln_wave_row.txt: the 16 dependent DPP reductions of one wave cost more than the barriers they replace.  Removed.)
 
 #define LN_LAUNCH_(MODE, PEND, NV, P0, P1, STRIDE, ROWS, RPM) \
     hipLaunchKernelGGL((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)

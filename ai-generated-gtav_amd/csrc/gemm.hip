@@ -1687,6 +1687,15 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
     // 256 x 144 with 8 / 6 waves of 128 x 48 / 96 x 48 — and the 256 x 128 loader-wave tile, shape 21: all correct, all 5-30 %
     // SLOWER than the two-blocks-per-CU 128 x 192 tile at M = 5760 / 11 520, profiles/round2/gemm_large_tile_*.txt: without a
     // co-resident block the prologue and epilogue of every tile are exposed.  The 1-block shapes 30-32 were removed again.)
+    if (shape == 16) {
+        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_QKV || EPI == EPI_RESID) {
+            GTAV_REQUIRE(gemm_pp_ok(p.M, p.N, p.K, EPI) || (p.K / TK >= 12 && p.M % 8 == 0 && p.N % 8 == 0),
+                         "gemm: the ping-pong kernel needs K >= 768, M %% 8 == 0, N %% 8 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
+            return launch_pp<EPI>(p, stream);
+        } else {
+            GTAV_REQUIRE(false, "gemm: the ping-pong kernel (shape 16) has no epilogue %d", (int)EPI);
+        }
+    }
     if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 2, 3>), grid, dim3(384));

@@ -140,6 +140,9 @@ def parse_args(argv=None):
     ap.add_argument("--batched-clips", type=int, default=2,
                     help="timed clips per algorithm of the bounded batch-8 + actions leg (config2 / config3); 0 disables it")
     ap.add_argument("--batched-batch", type=int, default=8)
+    ap.add_argument("--train-leg-steps", type=int, default=3,
+                    help="timed optimisation steps of the bounded training leg of the default run (SURVEY.md 8(f)1: batch 16, forward + backward "
+                         "+ AdamW on latents resident in HBM; N = 1 only); 0 disables it")
     ap.add_argument("--mode", choices=["generate", "train", "train_step"], default="generate",
                     help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
                          "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline); "
@@ -420,6 +423,47 @@ def bench_generate(args, world, rank, dev, dist, torch):
         batched.update(algo_report(Bb, bres, args.batched_clips))
         del binp
 
+    # ---- bounded training leg (N = 1): the optimisation step of SURVEY.md 8(f)1 on latents already in HBM (the VAE encode of the trainer
+    # is measured by --mode train / train_step) ----
+    train_leg = None
+    if world == 1 and args.train_leg_steps > 0 and args.geometry == "native":
+        from gtav_amd.train import training_step, forward_loss
+        TB = 16
+        tdit = DiT_models["DiT-S/2"](init_weights=False, max_batch=TB, trainable=True)
+        tdit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
+        g = torch.Generator().manual_seed(77)
+        lat = (torch.randn(TB, 5, 16, LH, LW, generator=g) * 0.5).to(dev)
+        tact = torch.zeros(TB, 5, 25, device=dev)
+        tact[:, :, 3] = 1
+        tgt, ctx = torch.randint(1, 51, (TB,), generator=g), torch.randint(1, 41, (TB,), generator=g)
+        cn, nz = torch.randn(TB, 4, 16, LH, LW, generator=g).to(dev), torch.randn(TB, 1, 16, LH, LW, generator=g).to(dev)
+        tstep = lambda: training_step(tdit, lat, tact, tgt, ctx, cn, nz, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0)
+        tstep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_leg_steps):
+            tloss = tstep()
+        torch.cuda.synchronize()
+        t_step = (time.perf_counter() - t0) / args.train_leg_steps
+        for _ in range(2):
+            forward_loss(tdit, lat, tact, tgt, ctx, cn, nz)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            forward_loss(tdit, lat, tact, tgt, ctx, cn, nz)
+        torch.cuda.synchronize()
+        t_fwd = (time.perf_counter() - t0) / 5
+        applied, skipped, gnorm = tdit.train_stats()
+        fl = TB * dit_forward_flops(5 * P_TOK, 5, 15, 1)
+        train_leg = {"workload": "SURVEY.md 8(f)1: DiT-S/2 optimisation step on 5-frame latent clips, batch %d, action-conditioned "
+                                 "(train_dit.py:590-680, 965-970: forward + loss, backward, clip_grad_norm 1.0, AdamW)" % TB,
+                     "steps_timed": args.train_leg_steps, "ms_per_step": round(t_step * 1e3, 2), "samples_per_s": round(TB / t_step, 2),
+                     "achieved_tflops": round(3 * fl / t_step / 1e12, 1), "forward_loss_ms": round(t_fwd * 1e3, 2),
+                     "loss": float(tloss), "last_step_applied": bool(applied), "skipped_steps": skipped, "grad_norm": round(gnorm, 4),
+                     "dtype": "fp16 operands, fp32 accumulate / master weights / gradients / AdamW state, loss scale %g" % tdit.loss_scale}
+        del tdit, lat, cn, nz
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -478,6 +522,8 @@ def bench_generate(args, world, rank, dev, dist, torch):
         line.update(algo_report(B, results, args.steps))
         if batched is not None:
             line["config2" if world == 1 else "config3"] = batched
+        if train_leg is not None:
+            line["train_step"] = train_leg
         print(json.dumps(line))
 
 
