@@ -292,6 +292,9 @@ struct gtav_dit {
         float* grad_arena = nullptr;        // all gradients, contiguous (one all-reduce); caller-owned when passed to train_enable
         size_t grad_count = 0;
         float* ctl = nullptr;               // [8]: sumsq, step coefficient, skipped steps, grad norm
+        AdamParam* adam_params = nullptr;   // device tables of the multi-tensor AdamW launch
+        AdamItem* adam_items = nullptr;
+        int adam_n_items = 0;
         std::vector<float*> res;            // residual states r_0 .. r_4L, fp32 [M][D]
         struct HB { f16 *xnA, *ao, *y1, *xnB, *u, *hh, *y2, *q, *k, *v; };   // per half-block (spatial: q, k = [nb][head][S][64], v = Vt; temporal: q [M][D], k = kv cache)
         std::vector<HB> hb;
@@ -778,6 +781,31 @@ int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena
         }
     }
     RET_IF(a.alloc_t(&t.ctl, 8));
+    {
+        std::vector<AdamParam> ap;
+        std::vector<AdamItem> ai;
+        for (size_t pi = 0; pi < t.params.size(); ++pi) {
+            Slot* sl = t.params[pi];
+            AdamParam d;
+            memset(&d, 0, sizeof(d));
+            const bool f16w = sl->kind == SLOT_F16_PAD;
+            d.p = sl->master; d.ldp = f16w ? sl->C : sl->Cp; d.R = sl->R; d.C = sl->C; d.g = sl->grad; d.m = sl->am; d.v = sl->av;
+            if (f16w) { d.w16 = (f16*)sl->dst; d.Cp16 = sl->Cp; d.wT = sl->wT; d.RpT = round_up(sl->R, 64); }
+            ap.push_back(d);
+            if (f16w) {
+                const unsigned nt = (unsigned)(cdiv(sl->R, 64) * cdiv(sl->C, 64));
+                for (unsigned i = 0; i < nt; ++i) ai.push_back(AdamItem{(int)pi, i});
+            } else {
+                const size_t n = (size_t)sl->R * sl->C;
+                for (size_t st = 0; st < n; st += 4096) ai.push_back(AdamItem{(int)pi, (unsigned)st});
+            }
+        }
+        RET_IF(a.alloc_t(&t.adam_params, ap.size()));
+        RET_IF(a.alloc_t(&t.adam_items, ai.size()));
+        GTAV_CHECK_HIP(hipMemcpy(t.adam_params, ap.data(), ap.size() * sizeof(AdamParam), hipMemcpyHostToDevice));
+        GTAV_CHECK_HIP(hipMemcpy(t.adam_items, ai.data(), ai.size() * sizeof(AdamItem), hipMemcpyHostToDevice));
+        t.adam_n_items = (int)ai.size();
+    }
     const size_t Mx = round_up(h->Mmax, 128), Mp = round_up(h->Mmax, 64), Mm = h->Mmax;
     t.res.resize(4 * L + 1);
     for (auto& r : t.res) RET_IF(a.alloc_t(&r, Mx * D));
@@ -1048,14 +1076,8 @@ int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float e
     RET_IF(launch_clip_coef(tr.ctl, 1.0f / tr.loss_scale, max_grad_norm, s));
     tr.step += 1;
     const float bc1 = 1.0f - powf(beta1, (float)tr.step), bc2 = 1.0f - powf(beta2, (float)tr.step);
-    for (Slot* sl : tr.params) {
-        const int ld = sl->kind == SLOT_F16_PAD ? sl->C : sl->Cp;
-        RET_IF(launch_adamw(sl->master, ld, sl->R, sl->C, sl->grad, sl->am, sl->av, tr.ctl, lr, beta1, beta2, eps, weight_decay, bc1, bc2, s));
-        if (sl->kind == SLOT_F16_PAD) {
-            RET_IF(launch_convert_pad_f16(sl->master, sl->C, sl->R, sl->C, (f16*)sl->dst, sl->Rp, sl->Cp, 1.0f, 1, s));
-            if (sl->wT) RET_IF(launch_convert_T_f16(sl->master, sl->C, sl->R, sl->C, sl->wT, s));
-        }
-    }
+    // one launch: AdamW on every parameter + the fp16 W / W^T operands of the GEMM weights rewritten from the updated masters
+    RET_IF(launch_adamw_multi(tr.adam_params, tr.adam_items, tr.adam_n_items, tr.ctl, lr, beta1, beta2, eps, weight_decay, bc1, bc2, s));
     RET_IF(launch_add_f32(h->b_t2, h->b_ext, h->b_t2a, h->D, s));   // fused bias of c when actions are given (gtav_dit_finalize)
     h->prepared.valid = false;
     h->kvrec.valid = false;

@@ -151,6 +151,16 @@ int launch_silu_bwd(const float* dy, int lddy, const float* x, int ldx, float* d
 int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R, int N, int K, float* dW, int lddw, hipStream_t stream);   // dW += dY^T X
 int launch_gemm_nn_f32(const float* dY, int lddy, const float* W, int ldw, int R, int N, int K, float* dX, int lddx, hipStream_t stream);   // dX = dY W
 int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, hipStream_t stream);                         // dSc += dmod W_ada
+// multi-tensor AdamW: one descriptor per parameter, one work item per 64 x 64 weight tile / 4096-element run (train.hip)
+struct AdamParam {
+    float* p; int ldp, R, C;               // fp32 master (GEMM weights: contiguous [R][C]; fp32 parameters: in place, leading dimension ldp)
+    const float* g; float *m, *v;          // gradient (scaled), AdamW moments, contiguous [R][C]
+    f16* w16; int Cp16;                    // GEMM weights: tile-major fp16 W (logical row length Cp16), else null
+    f16* wT; int RpT;                      // tile-major fp16 W^T (logical row length RpT = round_up(R, 64)), or null
+};
+struct AdamItem { int param; unsigned start; };   // GEMM weight: tile index (row-major over 64 x 64 tiles); fp32 parameter: first element
+int launch_adamw_multi(const AdamParam* params, const AdamItem* items, int n_items, const float* ctl, float lr, float beta1, float beta2, float eps, float wd,
+                       float bc1, float bc2, hipStream_t stream);
 int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream);
 int launch_clip_coef(float* ctl, float inv_scale, float max_norm, hipStream_t stream);
 int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,

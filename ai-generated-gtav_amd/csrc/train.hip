@@ -643,6 +643,73 @@ __global__ void adamw_kernel(float* __restrict__ p, int ldp, int R, int C, const
     }
 }
 
+// Multi-tensor AdamW (one launch for the whole model) fused with the refresh of the fp16 GEMM operands.  The host cuts every parameter
+// into work items (api.hip gtav_dit_train_enable): a 64 x 64 tile of a GEMM weight, or a run of up to 4096 elements of an fp32
+// parameter.  A block updates its item in fp32 and, for a GEMM weight, writes the tile straight into the tile-major fp16 W (16 bytes
+// along c) and, through an LDS transpose, into the tile-major fp16 W^T (16 bytes along r): the separate convert passes (two more reads
+// of the 0.8 GB of masters, 370 launches) and 300 per-parameter AdamW launches are gone.
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamParam* __restrict__ params, const AdamItem* __restrict__ items, const float* __restrict__ ctl,
+                                                          float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+    const float coef = ctl[1];
+    if (coef == 0.f) return;               // overflow: skip the step
+    const AdamItem it = items[blockIdx.x];
+    const AdamParam P = params[it.param];
+    const float decay = 1.0f - lr * wd, step = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+    auto upd = [&](size_t idx, float* pp) -> float {
+        const float gr = P.g[idx] * coef;
+        const float mm = beta1 * P.m[idx] + (1.0f - beta1) * gr;
+        const float vv = beta2 * P.v[idx] + (1.0f - beta2) * gr * gr;
+        P.m[idx] = mm;
+        P.v[idx] = vv;
+        const float w = *pp * decay - step * mm / (sqrtf(vv) * rs2 + eps);
+        *pp = w;
+        return w;
+    };
+    if (!P.w16) {                          // fp32 parameter (trained in place, possibly a strided view): a linear run of elements
+        const size_t total = (size_t)P.R * P.C;
+        const size_t end = (size_t)it.start + 4096 < total ? (size_t)it.start + 4096 : total;
+        for (size_t idx = (size_t)it.start + threadIdx.x; idx < end; idx += 256) {
+            const size_t r = idx / P.C;
+            const int c = (int)(idx - r * P.C);
+            upd(idx, P.p + r * P.ldp + c);
+        }
+        return;
+    }
+    __shared__ f16 t[64][72];
+    const int tiles_c = (P.C + 63) / 64;
+    const int r0 = (int)(it.start / tiles_c) * 64, c0 = (int)(it.start % tiles_c) * 64;
+    for (int q = threadIdx.x; q < 64 * 16; q += 256) {     // 64 rows x 16 float4
+        const int r = q >> 4, c4 = (q & 15) * 4;
+        f16 h4[4] = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (r0 + r < P.R) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = c0 + c4 + e;
+                if (c < P.C) {
+                    const size_t idx = (size_t)(r0 + r) * P.C + c;
+                    float w = upd(idx, P.p + idx);
+                    w = __builtin_amdgcn_fmed3f(w, -F16_MAX, F16_MAX);
+                    h4[e] = (f16)w;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[r][c4 + e] = h4[e];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 512; q += 256) {
+        const int a = q >> 3, ch = q & 7;
+        // W: row r0 + a, columns c0 + 8 ch .. (rows / columns past the logical shape stay zero in both images)
+        if (r0 + a < P.R && c0 + 8 * ch < P.Cp16) *(uint4*)(P.w16 + tiled_off(r0 + a, c0 + 8 * ch, P.Cp16)) = *(const uint4*)&t[a][8 * ch];
+        if (P.wT && c0 + a < P.C && r0 + 8 * ch < P.RpT) {
+            union { f16 h[8]; uint4 u; } o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o.h[i] = t[8 * ch + i][a];
+            *(uint4*)(P.wT + tiled_off(c0 + a, r0 + 8 * ch, P.RpT)) = o.u;
+        }
+    }
+}
+
 static int grid_for(size_t n, int block = 256) { return (int)((n + block - 1) / block < 4096 ? (n + block - 1) / block : 4096); }
 
 }  // namespace
@@ -784,6 +851,12 @@ int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream) {
 }
 int launch_clip_coef(float* ctl, float inv_scale, float max_norm, hipStream_t stream) {
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, ctl, inv_scale, max_norm);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_adamw_multi(const AdamParam* params, const AdamItem* items, int n_items, const float* ctl, float lr, float beta1, float beta2, float eps, float wd,
+                       float bc1, float bc2, hipStream_t stream) {
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_items), dim3(256), 0, stream, params, items, ctl, lr, beta1, beta2, eps, wd, bc1, bc2);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
