@@ -397,7 +397,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
 extern "C" {
 
 const char* gtav_last_error(void) { return gtav::last_error(); }
-int gtav_abi_version(void) { return 2; }
+int gtav_abi_version(void) { return 3; }   // 3: training step (gtav_dit_train_*), collectives (gtav_comm_*)
 
 int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     GTAV_REQUIRE(c && out, "dit_create: null argument");

@@ -24,7 +24,11 @@
  *                            plain launches, which never allocate
  *   gtav_dit_forward         with gtav_dit_profile enabled only: creates events and synchronises at the end of the forward
  *   gtav_dit_check / gtav_vae_check   copy the device error word back and synchronise `stream`
- * The library reads no environment variables.
+ *   gtav_dit_train_enable    hipMalloc + hipMemset of masters, optimizer state, saved-activation and backward workspace, two small
+ *                            synchronous hipMemcpy (the multi-tensor AdamW tables)
+ *   gtav_dit_train_stats     copies four floats back and synchronises `stream`
+ *   gtav_comm_unique_id / gtav_comm_init / gtav_comm_destroy   dlopen of librccl.so on first use; RCCL's own bootstrap (blocking)
+ * The library reads no environment variables (RCCL, once loaded, reads its own NCCL_* / RCCL_* variables).
  */
 #ifndef GTAV_AMD_H
 #define GTAV_AMD_H

@@ -26,7 +26,7 @@ def _setup(B=2, T=3, actions=True, seed=0):
     if actions:
         a = torch.zeros(B, T, 25)
         a[:, :, 3] = 1
-        a[0, 1, 7] = 1
+        a[0, T - 1, 7] = 1
     vt = torch.randn(B, 1, 16, 8, 16, generator=g)
     m = DiT(**KW, max_batch=B, max_frames=T, init_weights=False, trainable=True)
     m.load_state_dict(sd)
@@ -177,3 +177,50 @@ def test_full_size_gradients_match_autograd():
             "blocks.15.s_mlp.fc2.bias", "final_layer.linear.weight", "final_layer.adaLN_modulation.1.bias"]
     worst = {k: rel_l2(m.grad(k), grads[k]) for k in keys}
     assert max(worst.values()) < 1e-2, worst
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (1, 5)])
+def test_gradients_other_windows(B, T):
+    """Windows of 1, 2 and 5 frames (the temporal attention backward is specialised per window length; T = 1 has one key per query)."""
+    from oracle import ref_cpu as O
+    m, sd, cfg, x, t, a, vt = _setup(B=B, T=T)
+    _, v_ref, grads = O.dit_loss_and_grads(sd, cfg, x, t, a, vt)
+    v = m.forward_train(x, t, a)
+    assert rel_l2(v, v_ref) < 2e-3
+    m.zero_grad()
+    m.backward_(v, vt)
+    m.check()
+    worst = {k: rel_l2(m.grad(k), g) for k, g in grads.items() if g.norm() > 0}
+    assert max(worst.values()) < 1e-2, {k: v_ for k, v_ in worst.items() if v_ > 1e-2}
+
+
+def test_loss_scale_is_transparent_and_micro_batches_accumulate():
+    """(1) The unscaled gradients do not depend on the loss scale (256 vs 65536) beyond fp16 rounding.  (2) Two micro-batches with
+    per-micro-batch mean losses accumulate to twice the gradient of... each its own loss: g(b0) + g(b1) equals the sum of separate runs
+    (what gradient_accumulation_steps relies on, train_dit.py:676-680)."""
+    m, sd, cfg, x, t, a, vt = _setup(B=2, T=3)
+    key = "blocks.1.s_mlp.fc1.weight"
+    v = m.forward_train(x, t, a)
+    m.zero_grad()
+    m.backward_(v, vt)
+    g_hi = m.grad(key).clone()
+    m.loss_scale = 256.0
+    v = m.forward_train(x, t, a)
+    m.zero_grad()
+    m.backward_(v, vt)
+    g_lo = m.grad(key).clone()
+    assert rel_l2(g_lo, g_hi) < 5e-3
+    m.loss_scale = 65536.0
+    parts = []
+    for b in range(2):
+        vb = m.forward_train(x[b:b + 1], t[b:b + 1], a[b:b + 1])
+        m.zero_grad()
+        m.backward_(vb, vt[b:b + 1])
+        parts.append(m.grad(key).clone())
+    m.zero_grad()
+    for b in range(2):
+        vb = m.forward_train(x[b:b + 1], t[b:b + 1], a[b:b + 1])
+        m.backward_(vb, vt[b:b + 1])
+    assert rel_l2(m.grad(key), parts[0] + parts[1]) < 1e-5
+    # and the batch-of-two gradient is the mean of the two single-sample gradients (mse 'mean' over B n elements)
+    assert rel_l2(g_hi, 0.5 * (parts[0] + parts[1])) < 5e-3

@@ -27,7 +27,7 @@ def test_cabi_exports_every_declared_symbol():
     # the ctypes binding covers the whole header
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.load()
-    assert lib.gtav_abi_version() == 2
+    assert lib.gtav_abi_version() == 3
     assert lib.gtav_last_error() is not None
 
 
