@@ -940,6 +940,17 @@ int gtav_dit_train_forward(gtav_dit* h, const float* x, const int64_t* t64, cons
     return 0;
 }
 
+// Residual stream of the last training forward after k branch additions (every block adds four branches: spatial attention, spatial
+// MLP, temporal attention, temporal MLP): k = 0 is the patch embedding output, k = 4 (l + 1) the output of block l, k = 4 L the input of
+// the final layer.  fp32 [B T P][D] in token order (b, t, p): per-block parity taps (model/dit.py:370-372).
+int gtav_dit_train_get_residual(gtav_dit* h, int32_t k, float* dst, int64_t numel, void* stream) {
+    GTAV_REQUIRE(h && dst && h->tr.on && h->tr.have_fwd, "train_get_residual: no saved forward");
+    GTAV_REQUIRE(k >= 0 && k <= 4 * h->L, "train_get_residual: k=%d must be in [0, %d]", k, 4 * h->L);
+    GTAV_REQUIRE(numel == (int64_t)h->tr.M * h->D, "train_get_residual: expected %lld elements", (long long)h->tr.M * h->D);
+    GTAV_CHECK_HIP(hipMemcpyAsync(dst, h->tr.res[k], numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 // Backward of loss = mean((v_pred[:, -1] - v_target)^2) through the forward saved by gtav_dit_train_forward.  Gradients are ADDED to the
 // gradient arena (gtav_dit_zero_grad first), multiplied by the loss scale.
 int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_target, void* stream) {

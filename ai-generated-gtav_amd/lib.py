@@ -64,6 +64,7 @@ SIGNATURES = {
     "gtav_dit_train_forward": [_p, _p, _p, _p, _p, _i, _i, _p],
     "gtav_dit_train_backward": [_p, _p, _p, _p],
     "gtav_dit_get_grad": [_p, C.c_char_p, _p, _l, _p],
+    "gtav_dit_train_get_residual": [_p, _i, _p, _l, _p],
     "gtav_dit_adamw_step": [_p, _f, _f, _f, _f, _f, _f, _p],
     "gtav_dit_train_stats": [_p, C.POINTER(C.c_float), _p],
     "gtav_dit_set_graph": [_p, _i],

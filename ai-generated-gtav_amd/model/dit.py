@@ -327,6 +327,15 @@ class DiT(_HipModule):
             _lib.check(_lib.load().gtav_dit_get_grad(self._handle, name.encode(), out.data_ptr(), out.numel(), _lib.current_stream()))
         return out / self._loss_scale
 
+    def residual_after(self, k: int, B: int, T: int) -> torch.Tensor:
+        """Residual stream of the last forward_train after k branch additions (4 per block; k = 4 (i + 1) is the output of block i),
+        as (B, T, h, w, D) like the reference's block outputs."""
+        gh, gw = self.input_h // self.patch_size, self.input_w // self.patch_size
+        out = torch.empty(B * T * gh * gw, self.hidden_size, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_train_get_residual(self._handle, k, out.data_ptr(), out.numel(), _lib.current_stream()))
+        return out.reshape(B, T, gh, gw, self.hidden_size)
+
     def adamw_step(self, lr: float, weight_decay: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-7, max_grad_norm: float = 0.0):
         """clip_grad_norm_ + AdamW.step on the GPU masters (train_dit.py:232-238, 965-968); refreshes the fp16 GEMM operands."""
         with torch.cuda.device(self.device):

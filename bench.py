@@ -461,6 +461,24 @@ def bench_generate(args, world, rank, dev, dist, torch):
                      "achieved_tflops": round(3 * fl / t_step / 1e12, 1), "forward_loss_ms": round(t_fwd * 1e3, 2),
                      "loss": float(tloss), "last_step_applied": bool(applied), "skipped_steps": skipped, "grad_norm": round(gnorm, 4),
                      "dtype": "fp16 operands, fp32 accumulate / master weights / gradients / AdamW state, loss scale %g" % tdit.loss_scale}
+        if rank == 0 and not args.no_cpu_baseline:
+            # the reference's CPU path for the same step: torch autograd + torch.optim.AdamW on the oracle, ONE sample (B = 1, T = 5)
+            from oracle import ref_cpu as O
+            cores = host_cores()
+            torch.set_num_threads(cores)
+            sd = {k: v for k, v in tdit.state_dict().items()}
+            x1, t1, a1, v1 = lat[:1].cpu(), torch.tensor([[15, 15, 15, 15, 500]]), tact[:1].cpu(), nz[:1].cpu()
+            t0 = time.perf_counter()
+            _, _, grads = O.dit_loss_and_grads(sd, O.dit_s_2(), x1, t1, a1, v1)
+            t_bwd = time.perf_counter() - t0
+            params = {k: v for k, v in sd.items() if not k.endswith("freqs")}
+            t0 = time.perf_counter()
+            O.adamw_reference(params, grads, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, steps=1)
+            t_opt = time.perf_counter() - t0
+            train_leg["cpu_baseline"] = {"value": round(1.0 / (t_bwd + t_opt), 4), "unit": "samples/s", "cores": cores, "kind": "port",
+                                         "sample": "oracle/ref_cpu.py: torch autograd forward + backward of ONE 5-frame sample (%.2f s) + clip_grad_norm_ "
+                                                   "+ torch.optim.AdamW over the 608 M parameters (%.2f s)" % (t_bwd, t_opt)}
+            del grads, params, sd
         del tdit, lat, cn, nz
         torch.cuda.empty_cache()
 

@@ -140,6 +140,9 @@ int gtav_dit_train_forward(gtav_dit* h, const float* x_dev, const int64_t* t_dev
 /* Adds loss_scale * d mean((v_pred[:, -1] - v_target)^2) / d theta to the gradient arena.  v_pred (B,T,C,H,W) as returned by
  * gtav_dit_train_forward, v_target (B,C,H,W). */
 int gtav_dit_train_backward(gtav_dit* h, const float* v_pred_dev, const float* v_target_dev, void* stream);
+/* Residual stream of the last training forward: state r_k after k of the 4*depth branch additions (k even: 0 = patch embedding,
+ * 4 = output of block 0, ..., 4*depth = input of the final layer), fp32 [B*T*P][hidden] in token order (b, t, p). */
+int gtav_dit_train_get_residual(gtav_dit* h, int32_t k, float* dst_dev, int64_t numel, void* stream);
 /* Raw (loss-scaled) gradient of one parameter in torch layout. */
 int gtav_dit_get_grad(gtav_dit* h, const char* name, float* dst_dev, int64_t numel, void* stream);
 int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, void* stream);

@@ -239,3 +239,99 @@ def test_initialize_weights_statistics():
     assert w.abs().max().item() <= bound and abs(w.std().item() - bound / 3 ** 0.5) < 0.003
     assert torch.equal(vs["encoder.0.norm1.weight"], torch.ones(128)) and vs["encoder.0.norm1.bias"].abs().max().item() == 0
     assert vs["predictor.bias"].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# G1: per-op vectors captured from the reference's own sub-modules (tools/make_golden.py g1_per_op) — every functional piece of
+# the oracle against the module it restates, on the module's own inputs
+# ------------------------------------------------------------------------------------------------------------------------
+G1_DIT = dict(input_h=4, input_w=8, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+SMALL_VAE_KW = dict(latent_dim=16, input_height=64, input_width=96, patch_size=8, enc_dim=128, enc_depth=2, enc_heads=2, dec_dim=256,
+                    dec_depth=2, dec_heads=4)
+
+
+def test_g1_dit_ops_match_reference_modules():
+    import torch.nn.functional as F
+    g = gold("g1_ops_dit.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**G1_DIT), seed=3)
+    cfg = O.DiTConfig(**G1_DIT)
+    tol = 2e-6
+    # PatchEmbed (model/dit.py:38-76)
+    y = O.patch_embed(g["x_embedder_in0"], sd["x_embedder.proj.weight"], sd["x_embedder.proj.bias"], 2)
+    assert rel(y, g["x_embedder_out"]) < tol
+    # TimestepEmbedder (model/dit.py:79-123)
+    e = O.timestep_embedding(g["t_embedder_in0"], 256)
+    te = F.linear(F.silu(F.linear(e, sd["t_embedder.mlp.0.weight"], sd["t_embedder.mlp.0.bias"])), sd["t_embedder.mlp.2.weight"],
+                  sd["t_embedder.mlp.2.bias"])
+    assert rel(te, g["t_embedder_out"]) < tol
+    # SpatialAxialAttention (model/attention.py:73-136), axial RoPE of the 2 x 4 token grid
+    s_angles = O.rope_angles_axial(2, 4, O.rope_freqs_pixel(32, 256))
+    assert rel(O.spatial_attention(sd, "blocks.0.s_attn.", g["s_attn_in0"], 4, s_angles), g["s_attn_out"]) < tol
+    # TemporalAxialAttention (model/attention.py:13-71), causal, windows of 2 .. 5 frames
+    t_freqs = O.rope_freqs_lang(64)
+    for T in (2, 3, 4, 5):
+        assert rel(O.temporal_attention(sd, "blocks.0.t_attn.", g[f"T{T}_t_attn_in"], 4, t_freqs), g[f"T{T}_t_attn_out"]) < tol, T
+    # timm Mlp with tanh-GELU
+    assert rel(O.mlp(sd, "blocks.0.s_mlp.", g["s_mlp_in0"], "tanh"), g["s_mlp_out"]) < tol
+    # a whole SpatioTemporalDiTBlock: (x, c) -> x (model/dit.py:200-225)
+    assert rel(O.dit_block(sd, cfg, 1, g["block1_in0"], g["block1_in1"], s_angles, t_freqs), g["block1_out"]) < tol
+    # FinalLayer (model/dit.py:126-145): adaLN (shift, scale), LN, modulate, Linear
+    x, c = g["final_layer_in0"], g["final_layer_in1"]
+    m = F.linear(F.silu(c), sd["final_layer.adaLN_modulation.1.weight"], sd["final_layer.adaLN_modulation.1.bias"])
+    shift, scale = m.chunk(2, dim=-1)
+    fl = F.linear(O.modulate(O._ln(x), shift, scale), sd["final_layer.linear.weight"], sd["final_layer.linear.bias"])
+    assert rel(fl, g["final_layer_out"]) < tol
+    # and the composition
+    with torch.no_grad():
+        assert rel(O.dit_forward(sd, cfg, g["x"], g["t"], g["actions"]), g["out"]) < 1e-5
+
+
+def test_g1_vae_ops_match_reference_modules():
+    g = gold("g1_ops_vae.safetensors")
+    sd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE_KW), seed=5)
+    cfg = O.VAEConfig(**SMALL_VAE_KW)
+    ang = O.vae_rope_angles(cfg, cfg.enc_heads, cfg.enc_dim)
+    assert rel(O.vae_attention(sd, "encoder.0.attn.", g["attn_in"], cfg.enc_heads, ang, cfg.seq_h, cfg.seq_w), g["attn_out"]) < 2e-6
+    assert rel(O.vae_block(sd, "encoder.0.", g["block_in"], cfg.enc_heads, ang, cfg.seq_h, cfg.seq_w), g["block_out"]) < 2e-6
+    # patchify / unpatchify (model/vae.py:258-304): the oracle's unpatchify inverts the reference's patchify, the product's host mirror
+    # patchifies like the reference
+    assert torch.equal(O.vae_unpatchify(g["patchify"], cfg), g["img"])
+    assert torch.equal(g["unpatchify_of_patchify"], g["img"])
+    from gtav_amd.model.vae import AutoencoderKL
+    mirror = AutoencoderKL(**SMALL_VAE_KW, init_weights=False)         # host-side layout helpers only: no GPU call
+    assert torch.equal(mirror.patchify(g["img"]), g["patchify"]) and torch.equal(mirror.unpatchify(g["patchify"]), g["img"])
+    with torch.no_grad():
+        assert rel(O.vae_encode_mean(sd, cfg, g["img"]), g["mean"]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# G8: the reference's own training step (autograd through model/dit.py, clip_grad_norm_, torch.optim.AdamW) — pins the
+# training oracle (oracle.dit_loss_and_grads / adamw_reference) to the real module
+# ------------------------------------------------------------------------------------------------------------------------
+SMALL_DIT_KW = dict(input_h=8, input_w=16, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
+
+
+def _g8_sel(v):
+    return v.reshape(-1) if v.numel() <= 4096 else v.reshape(-1)[::97]
+
+
+def test_g8_training_oracle_matches_reference_autograd_and_adamw():
+    g = gold("g8_training.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT_KW), seed=3)
+    loss, v_pred, grads = O.dit_loss_and_grads(sd, O.DiTConfig(**SMALL_DIT_KW), g["x"], g["t"], g["actions"], g["v_target"])
+    assert rel(v_pred, g["v_pred"]) < 1e-5 and abs(float(loss) - float(g["loss"])) < 1e-6
+    names = sorted(grads)
+    assert len(names) == int(g["names_check"])
+    norms = torch.stack([grads[k].norm() for k in names])
+    assert rel(norms, g["grad_norms"]) < 1e-4
+    for k in names:
+        assert rel(_g8_sel(grads[k]), g["grad." + k]) < 2e-4, k
+    params = {k: v for k, v in sd.items() if not k.endswith("freqs")}
+    after, total = O.adamw_reference(params, grads, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, steps=1)
+    assert abs(float(total) - float(g["total_grad_norm"])) < 1e-4 * float(g["total_grad_norm"])
+    for k in names:
+        upd_ref = g["after." + k] - _g8_sel(sd[k])
+        upd = _g8_sel(after[k]) - _g8_sel(sd[k])
+        # first Adam step: |update| ~ lr per element, sign(g): elements whose reference gradient is ~0 may flip; compare where it is not
+        big = _g8_sel(grads[k]).abs() > 1e-3 * _g8_sel(grads[k]).abs().max()
+        assert rel(upd[big], upd_ref[big]) < 1e-3, k

@@ -101,11 +101,105 @@ def g7_harness(rd, rv, ref_denoise_step, ref_schedule):
 
 
 @torch.no_grad()
+def g1_per_op(rd, rv):
+    """G1: per-op input / output pairs of the reference's OWN sub-modules, captured with forward hooks while the
+    small reference models run (weights = synth_state_dict seeds 3 / 5 as in G2, so the tests rebuild them): PatchEmbed,
+    TimestepEmbedder, SpatialAxialAttention, TemporalAxialAttention (windows of 2..5 frames), timm Mlp, one whole
+    SpatioTemporalDiTBlock (x, c -> x), FinalLayer (before unpatchify), and of the VAE: Attention, AttentionBlock, patchify /
+    unpatchify."""
+    cfg = dict(SMALL_DIT, input_h=4, input_w=8)          # 2 x 4 = 8 tokens per frame: keeps every tensor small
+    sd = W.synth_state_dict(W.dit_param_shapes(**cfg), seed=3)
+    m = load_into(rd.DiT(**cfg), sd)
+    out = {}
+    caps = {}
+
+    def hook(name):
+        def f(mod, inp, o):
+            caps[name] = ([i.detach().clone() for i in inp if torch.is_tensor(i)], o.detach().clone())
+        return f
+    names = {"x_embedder": m.x_embedder, "t_embedder": m.t_embedder, "s_attn": m.blocks[0].s_attn, "t_attn": m.blocks[0].t_attn,
+             "s_mlp": m.blocks[0].s_mlp, "block1": m.blocks[1], "final_layer": m.final_layer}
+    hs = [mod.register_forward_hook(hook(n)) for n, mod in names.items()]
+    g = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        for T in (2, 3, 4, 5):
+            x = torch.randn(1, T, 16, 4, 8, generator=g)
+            t = torch.randint(0, 1000, (1, T), generator=g)
+            a = one_hot_actions(1, T, g)
+            y = m(x, t, a)
+            out[f"T{T}_t_attn_in"], out[f"T{T}_t_attn_out"] = caps["t_attn"][0][0], caps["t_attn"][1]
+            if T == 3:
+                out.update({"x": x, "t": t, "actions": a, "out": y})
+                for n in names:
+                    if n == "t_attn":
+                        continue
+                    ins, o = caps[n]
+                    for j, v in enumerate(ins):
+                        out[f"{n}_in{j}"] = v
+                    out[f"{n}_out"] = o
+    for h in hs:
+        h.remove()
+    save("g1_ops_dit.safetensors", out)
+
+    vsd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE), seed=5)
+    v = load_into(rv.AutoencoderKL(**SMALL_VAE), vsd)
+    vout, caps2 = {}, {}
+    hs = [v.encoder[0].attn.register_forward_hook(lambda mod, inp, o: caps2.__setitem__("attn", (inp[0].detach().clone(), o.detach().clone()))),
+          v.encoder[0].register_forward_hook(lambda mod, inp, o: caps2.__setitem__("block", (inp[0].detach().clone(), o.detach().clone())))]
+    g = torch.Generator().manual_seed(22)
+    img = torch.rand(1, 3, 64, 96, generator=g) * 2 - 1
+    with torch.no_grad():
+        post = v.encode(img)
+        pt = v.patchify(img)
+        vout.update({"img": img, "mean": post.mean, "patchify": pt, "unpatchify_of_patchify": v.unpatchify(pt),
+                     "attn_in": caps2["attn"][0], "attn_out": caps2["attn"][1], "block_in": caps2["block"][0], "block_out": caps2["block"][1]})
+    for h in hs:
+        h.remove()
+    save("g1_ops_vae.safetensors", vout)
+
+
+def g8_training(rd):
+    """G8: what `accelerator.backward` + `AdamW.step` produce on the REFERENCE module itself — torch autograd through
+    model/dit.py's DiT (train_dit.py:649-650, :680), clip_grad_norm_ 1.0 and torch.optim.AdamW(betas (0.9, 0.999), eps 1e-7, wd 0.01)
+    (:232-238, :965-968).  Small DiT (seed 3), B = 2, T = 3.  Stored: inputs, v_pred, loss, the gradient norm of EVERY parameter (sorted
+    by name), complete gradients of the small tensors, every 97th element of the large ones, and the same selection of the weights after
+    one optimizer step."""
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=3)
+    m = load_into(rd.DiT(**SMALL_DIT), sd).train()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 16, 8, 16, generator=g)
+    t = torch.randint(0, 1000, (2, 3), generator=g)
+    a = one_hot_actions(2, 3, g)
+    vt = torch.randn(2, 1, 16, 8, 16, generator=g)
+    params = {k: p for k, p in m.named_parameters() if p.requires_grad}
+    opt = torch.optim.AdamW(list(params.values()), lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999), eps=1e-7)
+    v_pred = m(x, t, a)
+    loss = torch.nn.functional.mse_loss(v_pred[:, -1:], vt)
+    loss.backward()
+    names = sorted(k for k in params if params[k].grad is not None)
+    out = {"x": x, "t": t, "actions": a, "v_target": vt, "v_pred": v_pred.detach(), "loss": loss.detach().reshape(1),
+           "grad_norms": torch.stack([params[k].grad.norm() for k in names])}
+    sel = lambda v: v.reshape(-1).clone() if v.numel() <= 4096 else v.reshape(-1)[::97].clone()
+    for k in names:
+        out["grad." + k] = sel(params[k].grad)
+    total = torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+    out["total_grad_norm"] = total.reshape(1)
+    opt.step()
+    for k in names:
+        out["after." + k] = sel(params[k].detach())
+    out["names_check"] = torch.tensor([len(names)])
+    save("g8_training.safetensors", out)
+    print("G8 parameters with gradients:", len(names), "; without:", [k for k in params if params[k].grad is None])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rd, rv, ref_denoise_step, ref_schedule = ref_shim.import_reference()
     if "--only-g7" in sys.argv:
         return g7_harness(rd, rv, ref_denoise_step, ref_schedule)
+    if "--only-g1-g8" in sys.argv:
+        g1_per_op(rd, rv)
+        return g8_training(rd)
     from model.rotary_embedding_torch import RotaryEmbedding
     from dummy_dataset import ImageDataset as RefDummy
     from web_dataset import actions_to_one_hot as ref_one_hot
@@ -255,6 +349,8 @@ def main():
     dec = fv.decode(z)
     del fv, fvsd
     g7_harness(rd, rv, ref_denoise_step, ref_schedule)
+    g1_per_op(rd, rv)
+    g8_training(rd)
     save("g3_full_vae.safetensors", {"mean": post.mean, "logvar": post.logvar, "z": z, "decoded_stride4": dec[:, :, ::4, ::4].clone(),
                                      "decoded_row100": dec[:, :, 100].clone()})
 
