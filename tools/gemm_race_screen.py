@@ -18,11 +18,13 @@ from helpers import dev, gemm, pad_weight_f16, rel_l2, to_tiled_f16, untile  # n
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--shapes", type=int, nargs="*", default=None, help="block shapes to screen (default: every shape the library has)")
     a = ap.parse_args()
     lib = L.load()
     cases = [(720, 4096, 1024), (5760, 1024, 1024), (144, 3072, 1024), (333, 512, 4096), (2880, 3072, 1024)]
     bad = 0
-    for shape in (2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 14):
+    ap_shapes = a.shapes or [2, 3, 7, 8, 9, 11, 12, 14, 16, 20, 21, 23]
+    for shape in ap_shapes:
         for (M, N, K) in cases:
             g = torch.Generator().manual_seed(M + N + K)
             x = (torch.randn(M, K, generator=g)).half()
@@ -40,7 +42,13 @@ def main():
                         out = torch.full((M, N), float("nan"), device=dev())
                     else:
                         out = torch.zeros(((M + 127) // 128 * 128, N), device=dev(), dtype=torch.float16)
-                    gemm(xd, wd, bd, M, N, K, epi, out, N)
+                    try:
+                        gemm(xd, wd, bd, M, N, K, epi, out, N)
+                    except L.GtavError as e:        # a shape that does not take this problem (e.g. the ping-pong kernel's K >= 768)
+                        err = float("nan")
+                        print(f"shape {shape:2d} epi {epi} M={M:5d} N={N:5d} K={K:5d}: skipped ({e})")
+                        ok = None
+                        break
                     if first is None:
                         first = out.clone()
                         got = first.float().cpu() if epi == 0 else untile(first, M, N).float()
@@ -51,6 +59,8 @@ def main():
                         ok = False
                         break
                 lib.gtav_op_gemm_set_wm(0)
+                if ok is None:
+                    continue
                 if not ok:
                     bad += 1
                 print(f"shape {shape:2d} epi {epi} M={M:5d} N={N:5d} K={K:5d}: {'ok' if ok else 'MISMATCH'} (rel-L2 {err:.2e}, {a.reps} reps)")
