@@ -953,9 +953,15 @@ int gtav_dit_train_get_residual(gtav_dit* h, int32_t k, float* dst, int64_t nume
 
 // Backward of loss = mean((v_pred[:, -1] - v_target)^2) through the forward saved by gtav_dit_train_forward.  Gradients are ADDED to the
 // gradient arena (gtav_dit_zero_grad first), multiplied by the loss scale.
-int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_target, void* stream) {
+// Phases of the backward pass (gtav_dit_train_backward_phases): 0 = loss, final projection, final LayerNorm; 1 .. L = the blocks in
+// reverse, phase p = block L - p (both half-blocks and the block's adaLN projection: after phase p every gradient named "blocks.<L-p>.*" is
+// complete, so its slice of the arena can be all-reduced while the earlier blocks are still being differentiated); L + 1 = patch embedding
+// and the shared conditioning path (t_embedder, external_cond).  tr.dres / tr.dmod carry the state from one phase to the next.
+int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float* v_target, int32_t phase_begin, int32_t phase_end, void* stream) {
     GTAV_REQUIRE(h && v_pred && v_target, "train_backward: null argument");
     GTAV_REQUIRE(h->tr.on && h->tr.have_fwd, "train_backward: no saved forward (gtav_dit_train_forward)");
+    GTAV_REQUIRE(phase_begin >= 0 && phase_begin <= phase_end && phase_end <= h->L + 2, "train_backward: phases [%d, %d) outside [0, %d]", phase_begin, phase_end,
+                 h->L + 2);
     hipStream_t s = (hipStream_t)stream;
     gtav_dit::Train& tr = h->tr;
     const int D = h->D, P = h->P, L = h->L, B = tr.B, T = tr.T, M = tr.M, Mp = tr.Mp, NB = B * T, rows = tr.rows, Hp = h->Hm_pad, MODW = h->MODW;
@@ -981,7 +987,13 @@ int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_tar
     GTAV_REQUIRE(h->Nfin <= 64, "train_backward: a final projection wider than 64 features is not implemented");
     const float* mod = h->mod;
     float* dmod = tr.dmod;
-    // ---- loss -> final projection -> final LayerNorm ----
+    // gradient of one adaLN projection (rows [row0, row0 + n) of W_ada / b_ada) from the dmod columns its LayerNorm / gate backward filled
+    auto ada_grads = [&](size_t row0, int n, const std::string& wn, const std::string& bn) -> int {
+        RET_IF(launch_gemm_tn_f32(dmod + row0, MODW, h->Sc, D, rows, n, D, slot(wn).grad, D, s));
+        return launch_colsum_f32(dmod + row0, MODW, rows, n, slot(bn).grad, s);
+    };
+    // ---- phase 0: loss -> final projection -> final LayerNorm ----
+    if (phase_begin <= 0 && 0 < phase_end) {
     RET_IF(launch_mse_bwd_patch(v_pred, v_target, B, T, h->C, h->H, h->W, h->p, scale, tr.dfo, 64, h->err_flag, s));
     {
         Slot& wf = slot("final_layer.linear.weight");
@@ -1002,10 +1014,14 @@ int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_tar
         float* dmf = dmod + (size_t)L * 12 * D;
         RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[4 * L], mf + D, MODW, P, M, D, tr.dres, 0, tr.stats, s));
         RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[4 * L], tr.stats, NB, P, D, dmf, dmf + D, MODW, s));
+        RET_IF(ada_grads((size_t)L * 12 * D, 2 * D, "final_layer.adaLN_modulation.1.weight", "final_layer.adaLN_modulation.1.bias"));
     }
-    // ---- the 2 L half-blocks in reverse; tr.dres = d loss / d (residual state) ----
+    }
+    // ---- phases 1 .. L: the blocks in reverse (temporal half-block, then spatial); tr.dres = d loss / d (residual state) ----
     for (int i = 2 * L - 1; i >= 0; --i) {
         const int l = i / 2, hf = i % 2;
+        const int phase = L - l;
+        if (phase < phase_begin || phase >= phase_end) continue;
         gtav_dit::Train::HB& b = tr.hb[i];
         char pre[64];
         snprintf(pre, sizeof(pre), "blocks.%d.%c_", l, hf == 0 ? 's' : 't');
@@ -1036,8 +1052,11 @@ int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_tar
         RET_IF(gemm_dx(tr.g_qkv, slot(P_ + "attn.to_qkv.weight").wT, D, 3 * D, EPI_F32, tr.dtmp, D));
         RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i], mb + D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
         RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i], tr.stats, NB, P, D, dmb, dmb + D, MODW, s));
+        // all six dmod chunks of this half-block are in place: its adaLN projection's gradients
+        RET_IF(ada_grads((size_t)i * 6 * D, 6 * D, P_ + "adaLN_modulation.1.weight", P_ + "adaLN_modulation.1.bias"));
     }
-    // ---- patch embedding: r_0 = xp W_pe^T + b_pe ----
+    if (!(phase_begin <= L + 1 && L + 1 < phase_end)) return 0;
+    // ---- phase L + 1: patch embedding: r_0 = xp W_pe^T + b_pe ----
     RET_IF(launch_colsum_f32(tr.dres, D, M, D, slot("x_embedder.proj.bias").grad, s));
     RET_IF(launch_to_tiled_f16(tr.dres, M, D, tr.g_d, h->err_flag, s));
     {
@@ -1045,21 +1064,8 @@ int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_tar
         GTAV_REQUIRE(wpe.C == h->Kpe, "train_backward: a patch embedding with padded K (%d of %d) is not implemented", wpe.C, h->Kpe);
         RET_IF(gemm_dw(tr.g_d, D, tr.xp, h->Kpe, wpe.grad));
     }
-    // ---- conditioning path (fp32, `rows` = B T rows): mod = SiLU(c) W_ada^T + b_ada, c = W_2 SiLU(W_0 e + b_0) + b_2 (+ W_ext a + b_ext) ----
-    for (int i = 0; i <= 2 * L; ++i) {
-        const size_t row0 = (size_t)i * 6 * D;
-        const int n = i < 2 * L ? 6 * D : 2 * D;
-        std::string wn, bn;
-        if (i < 2 * L) {
-            char pre[64];
-            snprintf(pre, sizeof(pre), "blocks.%d.%c_adaLN_modulation.1.", i / 2, i % 2 == 0 ? 's' : 't');
-            wn = std::string(pre) + "weight"; bn = std::string(pre) + "bias";
-        } else {
-            wn = "final_layer.adaLN_modulation.1.weight"; bn = "final_layer.adaLN_modulation.1.bias";
-        }
-        RET_IF(launch_gemm_tn_f32(dmod + row0, MODW, h->Sc, D, rows, n, D, slot(wn).grad, D, s));
-        RET_IF(launch_colsum_f32(dmod + row0, MODW, rows, n, slot(bn).grad, s));
-    }
+    // ---- the shared conditioning path (fp32, `rows` = B T rows): c = W_2 SiLU(W_0 e + b_0) + b_2 (+ W_ext a + b_ext), SiLU(c) feeds every adaLN
+    // projection (their own gradients were taken block by block above) ----
     GTAV_CHECK_HIP(hipMemsetAsync(tr.dSc, 0, (size_t)rows * D * sizeof(float), s));
     RET_IF(launch_ada_bwd_dx(dmod, MODW, h->w_ada, D, rows, tr.dSc, s));
     RET_IF(launch_silu_bwd(tr.dSc, D, tr.cpre, D, tr.dc, D, rows, D, s));
@@ -1073,6 +1079,32 @@ int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_tar
     RET_IF(launch_silu_bwd(tr.dh0, D, tr.z0, D, tr.dz0, D, rows, D, s));
     RET_IF(launch_colsum_f32(tr.dz0, D, rows, D, slot("t_embedder.mlp.0.bias").grad, s));
     RET_IF(launch_gemm_tn_f32(tr.dz0, D, h->E, 256, rows, D, 256, slot("t_embedder.mlp.0.weight").grad, 256, s));
+    return 0;
+}
+
+int gtav_dit_train_backward(gtav_dit* h, const float* v_pred, const float* v_target, void* stream) {
+    GTAV_REQUIRE(h, "train_backward: null handle");
+    return gtav_dit_train_backward_phases(h, v_pred, v_target, 0, h->L + 2, stream);
+}
+
+// Slice [offset, offset + count) of the gradient arena that holds the parameters whose names start with `prefix` (names are laid out in
+// lexicographic order, so "blocks.7." is one contiguous slice): the buckets of an all-reduce overlapped with the backward pass.
+int gtav_dit_train_param_range(gtav_dit* h, const char* prefix, int64_t* offset, int64_t* count) {
+    GTAV_REQUIRE(h && prefix && offset && count && h->tr.on, "train_param_range: bad argument / training is not enabled");
+    const size_t plen = strlen(prefix);
+    int64_t off = -1, cnt = 0, last_end = -1;
+    for (auto& kv : h->wt.slots) {
+        Slot& sl = kv.second;
+        if (!sl.grad || kv.first.compare(0, plen, prefix) != 0) continue;
+        const int64_t o = sl.grad - h->tr.grad_arena, n = (int64_t)sl.R * sl.C;
+        if (off < 0) off = o;
+        GTAV_REQUIRE(last_end < 0 || o == last_end, "train_param_range: parameters with prefix '%s' are not contiguous in the arena", prefix);
+        last_end = o + n;
+        cnt += n;
+    }
+    GTAV_REQUIRE(off >= 0, "train_param_range: no trainable parameter starts with '%s'", prefix);
+    *offset = off;
+    *count = cnt;
     return 0;
 }
 

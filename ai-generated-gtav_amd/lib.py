@@ -63,6 +63,8 @@ SIGNATURES = {
     "gtav_dit_zero_grad": [_p, _p],
     "gtav_dit_train_forward": [_p, _p, _p, _p, _p, _i, _i, _p],
     "gtav_dit_train_backward": [_p, _p, _p, _p],
+    "gtav_dit_train_backward_phases": [_p, _p, _p, _i, _i, _p],
+    "gtav_dit_train_param_range": [_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "gtav_dit_get_grad": [_p, C.c_char_p, _p, _l, _p],
     "gtav_dit_train_get_residual": [_p, _i, _p, _l, _p],
     "gtav_dit_adamw_step": [_p, _f, _f, _f, _f, _f, _f, _p],

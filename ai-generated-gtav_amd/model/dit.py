@@ -298,6 +298,19 @@ class DiT(_HipModule):
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().gtav_dit_train_backward(self._handle, v_pred.data_ptr(), vt.data_ptr(), _lib.current_stream()))
 
+    def backward_phases_(self, v_pred: torch.Tensor, v_target: torch.Tensor, phase_begin: int, phase_end: int):
+        """Phases [phase_begin, phase_end) of backward_: 0 = loss + final layer, p in 1..depth = block depth - p, depth + 1 = embedders."""
+        vt = v_target.to(self.device, torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().gtav_dit_train_backward_phases(self._handle, v_pred.data_ptr(), vt.data_ptr(), phase_begin, phase_end,
+                                                                 _lib.current_stream()))
+
+    def param_range(self, prefix: str):
+        """(offset, count) of the gradient-arena slice of the parameters whose names start with `prefix` (lexicographic layout)."""
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().gtav_dit_train_param_range(self._handle, prefix.encode(), C.byref(off), C.byref(cnt)))
+        return off.value, cnt.value
+
     def zero_grad(self):
         if not self._handle:
             self._ensure(self._capacity_b, self._capacity_t)

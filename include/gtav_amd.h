@@ -143,6 +143,14 @@ int gtav_dit_train_backward(gtav_dit* h, const float* v_pred_dev, const float* v
 /* Residual stream of the last training forward: state r_k after k of the 4*depth branch additions (k even: 0 = patch embedding,
  * 4 = output of block 0, ..., 4*depth = input of the final layer), fp32 [B*T*P][hidden] in token order (b, t, p). */
 int gtav_dit_train_get_residual(gtav_dit* h, int32_t k, float* dst_dev, int64_t numel, void* stream);
+/* The same pass in phases [phase_begin, phase_end): 0 = loss + final layer, p in 1..depth = block depth - p (after it every gradient named
+ * "blocks.<depth-p>.*" is complete), depth + 1 = patch embedding + timestep / action embedders.  Lets the host all-reduce one block's
+ * slice of the arena (gtav_dit_train_param_range) on another stream while earlier blocks are still being differentiated (the bucketed,
+ * overlapped gradient all-reduce DDP performs under accelerate). */
+int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred_dev, const float* v_target_dev, int32_t phase_begin, int32_t phase_end,
+                                   void* stream);
+/* Arena slice [offset, offset + count) of the parameters whose state-dict names start with `prefix` (e.g. "blocks.7."). */
+int gtav_dit_train_param_range(gtav_dit* h, const char* prefix, int64_t* offset, int64_t* count);
 /* Raw (loss-scaled) gradient of one parameter in torch layout. */
 int gtav_dit_get_grad(gtav_dit* h, const char* name, float* dst_dev, int64_t numel, void* stream);
 int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, void* stream);

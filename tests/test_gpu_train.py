@@ -270,3 +270,57 @@ def test_per_block_residual_taps_match_reference_fixture_g2():
     assert rel_l2(v, g["out_actions"]) < 1e-3
     for i in range(2):
         assert rel_l2(m.residual_after(4 * (i + 1), 2, 3), g[f"block{i}_actions"]) < 1e-3, i
+
+
+def test_phased_backward_equals_monolithic_and_buckets_cover_the_arena():
+    """gtav_dit_train_backward_phases one phase at a time gives the single call's gradients (to fp32 rounding: bias gradients and the
+    conditioning path accumulate with float atomics, whose order is not fixed); the all-reduce buckets
+    (final layer, one per block in reverse, embedders) are disjoint, contiguous and cover the arena; each bucket's gradients are final
+    after the phase it is attached to (later phases do not touch them)."""
+    from gtav_amd.train import gradient_buckets
+    m, sd, cfg, x, t, a, vt = _setup()
+    v = m.forward_train(x, t, a)
+    m.zero_grad()
+    m.backward_(v, vt)
+    whole = m.grad_arena.clone()
+    m.zero_grad()
+    buckets = gradient_buckets(m)
+    spans = sorted((off, off + cnt) for _, off, cnt in buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == m.grad_arena.numel() and all(a_[1] == b_[0] for a_, b_ in zip(spans, spans[1:]))
+    L = m.depth
+    for phase in range(L + 2):
+        m.backward_phases_(v, vt, phase, phase + 1)
+        for ph, off, cnt in buckets:
+            if ph == phase:
+                assert rel_l2(m.grad_arena[off: off + cnt], whole[off: off + cnt]) < 1e-6, (phase, off)
+    assert rel_l2(m.grad_arena, whole) < 1e-6
+
+
+def test_overlapped_all_reduce_path_single_rank_process_group():
+    """backward_overlapped with a real process group (RCCL, world size 1 on this one-GPU box) forced through the multi-rank code path
+    (world_size=2 arithmetic with an all-reduce that doubles, standing in for a second rank with identical gradients): events, the
+    communication stream, bucket slicing and the final averaging; result = the plain backward's gradients."""
+    import os
+    import torch.distributed as dist
+    from gtav_amd.train import backward_overlapped
+    m, sd, cfg, x, t, a, vt = _setup()
+    v = m.forward_train(x, t, a)
+    m.zero_grad()
+    m.backward_(v, vt)
+    whole = m.grad_arena.clone()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    try:
+        def fake_two_rank_sum(tensor):
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)      # the real collective on this rank's slice (identity at world size 1) ...
+            tensor.mul_(2.0)                                   # ... plus the contribution of an identical second rank
+        m.zero_grad()
+        backward_overlapped(m, v, vt, world_size=2, all_reduce=fake_two_rank_sum)
+        torch.cuda.synchronize()
+        assert rel_l2(m.grad_arena, whole) < 1e-6
+    finally:
+        if created:
+            dist.destroy_process_group()
