@@ -238,7 +238,7 @@ struct gtav_dit {
     WeightTable wt;
     // fp16 GEMM weights
     f16 *w_pe = nullptr, *w_final = nullptr;
-    struct Half { f16 *w_qkv, *w_out, *w_fc1, *w_fc2; float *b_out, *b_fc1, *b_fc2; };
+    struct Half { f16 *w_qkv, *w_out, *w_fc1, *w_fc2; float *b_out, *b_fc1, *b_fc2; f16* w_qkv_hm; };   // w_qkv_hm: temporal halves only, head-major rows (fused QKV + attention GEMM), made by finalize
     std::vector<Half> halves;  // [L*2]
     float *b_pe = nullptr, *b_final = nullptr;
     // fp32 conditioning path
@@ -272,6 +272,11 @@ struct gtav_dit {
     };
     std::map<GraphKey, hipGraphExec_t> graphs;   // nullptr value = shape seen once (eager warm-up done), not yet captured
     bool use_graph = true;
+    // window steps at batch 1: temporal QKV projection + temporal attention in one launch (gemm.hip gemm_qkvt_attn_kernel; bit-identical
+    // to the split path).  OFF by default: measured 1-2 % SLOWER per forward than the two kernels (profiles/round2/
+    // forward_ab_B1_fused_temporal.txt).  gtav_dit_set_fused_temporal() is the switch (it allocates the head-major weight copies);
+    // handles with training enabled keep the split path (the copies are not refreshed by the optimizer).
+    bool fuse_tattn = false;
     int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
     hipStream_t cap_stream = nullptr;            // private stream the step is captured on (the caller's may be the null stream)
     ~gtav_dit() {
@@ -360,21 +365,31 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         for (int hf = 0; hf < 2; ++hf) {
             const gtav_dit::Half& w = h->halves[l * 2 + hf];
             const float* mb = mod + (size_t)(l * 2 + hf) * 6 * D;
+            // temporal half of a batch-1 window step: QKV projection and attention in one launch, on LayerNorm rows written in
+            // (b, 16 positions, frame) tile order
+            const bool fused_t = hf == 1 && h->fuse_tattn && !h->tr.on && w.w_qkv_hm && have_pend && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
+            if (fused_t) { pend.tperm_T = Tq; pend.tperm_P = P; }
             PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
-            if (hf == 0) {
-                g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
-                g.rope_cs = h->rope_s.cs_dev;
+            if (fused_t) {
+                g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
+                g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
+                PROF(h, PC_QKV, s, launch_gemm_qkvt_attn(g, s));
             } else {
-                g.qkv_mode = QKV_TEMPORAL; g.q = h->qt; g.k = h->kvcache[l]; g.v = h->kvcache[l];
-                g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
-                g.rope_cs = h->rope_t.cs_dev;
+                if (hf == 0) {
+                    g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
+                    g.rope_cs = h->rope_s.cs_dev;
+                } else {
+                    g.qkv_mode = QKV_TEMPORAL; g.q = h->qt; g.k = h->kvcache[l]; g.v = h->kvcache[l];
+                    g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
+                    g.rope_cs = h->rope_t.cs_dev;
+                }
+                PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
+                if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
+                else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             }
-            PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
-            if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
-            else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
             PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
             have_pend = false;
@@ -452,6 +467,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
             snprintf(pre, sizeof(pre), "blocks.%d.%c_", l, hf == 0 ? 's' : 't');
             std::string P_(pre);
             A_(a.alloc_t(&w.w_qkv, (size_t)3 * D * D)); wt.add_f16(P_ + "attn.to_qkv.weight", 3 * D, D, w.w_qkv, 3 * D, D);
+            w.w_qkv_hm = nullptr;   // allocated by gtav_dit_set_fused_temporal(h, 1)
             A_(a.alloc_t(&w.w_out, (size_t)D * D)); wt.add_f16(P_ + "attn.to_out.weight", D, D, w.w_out, D, D);
             A_(a.alloc_t(&w.b_out, D)); wt.add_f32(P_ + "attn.to_out.bias", 1, D, w.b_out, D);
             A_(a.alloc_t(&w.w_fc1, (size_t)h->Hm_pad * D)); wt.add_f16(P_ + "mlp.fc1.weight", h->Hm, D, w.w_fc1, h->Hm_pad, D);
@@ -564,6 +580,8 @@ int gtav_dit_finalize(gtav_dit* h, void* stream) {
         }
         RET_IF(upload(h->sincos, tab));
     }
+    for (auto& w : h->halves)
+        if (w.w_qkv_hm) RET_IF(launch_qkv_head_major(w.w_qkv, w.w_qkv_hm, D, s));
     RET_IF(launch_rope_interleave(h->rope_s.cos_dev, h->rope_s.sin_dev, h->rope_s.cs_dev, h->P, s));
     RET_IF(launch_rope_interleave(h->rope_t.cos_dev, h->rope_t.sin_dev, h->rope_t.cs_dev, h->maxT, s));
     GTAV_CHECK_HIP(hipStreamSynchronize(s));
@@ -714,6 +732,28 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
 int gtav_dit_set_graph(gtav_dit* h, int32_t enable) {
     GTAV_REQUIRE(h, "dit_set_graph: null handle");
     h->use_graph = enable != 0;
+    return 0;
+}
+
+int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable) {
+    GTAV_REQUIRE(h, "dit_set_fused_temporal: null handle");
+    if (h->fuse_tattn != (enable != 0)) {   // captured sampler steps contain the other kernel sequence
+        for (auto& kv : h->graphs)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+    }
+    if (enable && h->P % 16 == 0 && h->D % 256 == 0 && h->maxT >= 5) {
+        // first enable: head-major copies of the temporal to_qkv weights (3 D^2 halves per block); filled here if the weights are
+        // already final, otherwise by gtav_dit_finalize
+        for (int l = 0; l < h->L; ++l) {
+            gtav_dit::Half& w = h->halves[l * 2 + 1];
+            if (w.w_qkv_hm) continue;
+            RET_IF(h->arena.alloc_t(&w.w_qkv_hm, (size_t)3 * h->D * h->D));
+            if (h->finalized) RET_IF(launch_qkv_head_major(w.w_qkv, w.w_qkv_hm, h->D, nullptr));
+        }
+        if (h->finalized) GTAV_CHECK_HIP(hipDeviceSynchronize());
+    }
+    h->fuse_tattn = enable != 0;
     return 0;
 }
 
@@ -1459,6 +1499,18 @@ int gtav_op_attn_spatial(const void* q, const void* k, const void* vt, void* o, 
 int gtav_op_attn_temporal(const void* q, const void* kv, void* o, int32_t B, int32_t P, int32_t D, int32_t Tq, int32_t t0,
                           int32_t Tmax, void* stream) {
     return launch_attn_temporal((const f16*)q, (const f16*)kv, (f16*)o, B, P, D, Tq, t0, Tmax, (hipStream_t)stream);
+}
+int gtav_op_qkv_head_major(const void* w, void* w_hm, int32_t D, void* stream) {
+    return launch_qkv_head_major((const f16*)w, (f16*)w_hm, D, (hipStream_t)stream);
+}
+int gtav_op_gemm_qkvt_attn(const void* x_tperm, const void* w_hm, int32_t M, int32_t D, int32_t P, int32_t Tq, int32_t t0,
+                           int32_t Tmax, const float* rope_cs, void* kv, void* o, void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)x_tperm; g.ldx = D; g.W = (const f16*)w_hm; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
+    g.qkv_mode = QKV_TEMPORAL; g.k = (f16*)kv; g.v = (f16*)kv; g.out = o; g.ldo = D; g.Tq = Tq; g.t0 = t0; g.Tmax = Tmax;
+    g.rope_cs = rope_cs;
+    return launch_gemm_qkvt_attn(g, (hipStream_t)stream);
 }
 int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t N, int32_t K,
                            int32_t splitk, float* parts, float* resid, const float* gate, int32_t gate_stride,

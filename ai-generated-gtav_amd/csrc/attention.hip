@@ -200,17 +200,6 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
     }
 }
 
-// Sum over the 8 lanes of a head group with DPP moves (quad xor 1, quad xor 2, half-row mirror) instead of three
-// ds_bpermute-based shuffles: every lane of the group ends up with the group's total.
-__device__ __forceinline__ float group8_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
-    return v;
-}
-
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
 // One thread per 8 consecutive features (16-byte loads / stores; 8 lanes per head), D/8 threads per (b, p) column and as many
 // columns per block as fit in 256 threads; grid = (column groups, query-frame group): with `split` every query frame of a column
 // gets its own block, which loads only the K / V frames its causal mask admits — five times as many independent blocks for the
@@ -270,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
                 const float pr = __builtin_amdgcn_exp2f((s[t] - mx) * 1.4426950408889634f);   // argument <= 0
                 den += pr;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v8[t].v[e];
+                for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(pr, (float)v8[t].v[e], acc[e]);   // explicit fma: the fused QKV + attention GEMM (gemm.hip) must round identically
             }
         }
         const float inv = 1.0f / den;

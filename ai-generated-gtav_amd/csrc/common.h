@@ -11,6 +11,7 @@ namespace gtav {
 typedef _Float16 f16;
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -96,6 +97,15 @@ __device__ __forceinline__ f16x4 sat4(float a, float b, float c, float d, float&
 // NaN-safe: a NaN input compares false and is not reported here (it stays a NaN in the output)
 __device__ __forceinline__ void sat_report(float amax, int* err_flag) {
     if (err_flag && amax > F16_MAX) atomicOr(err_flag, ERR_F16_SAT);
+}
+
+// Sum over the 8 lanes of an aligned lane group with DPP moves (quad xor 1, quad xor 2, half-row mirror) instead of three
+// ds_bpermute-based shuffles: every lane of the group ends up with the group's total (temporal attention: 8 lanes per head row).
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
 }
 
 // ---- small device math ------------------------------------------------------------------

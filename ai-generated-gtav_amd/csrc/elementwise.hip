@@ -213,7 +213,12 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
             yv[e] = xh * av[e] + bv[e];
         }
     }
-    store_f16x4_paired<1>(out + tiled_off(m, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
+    int mo = m;
+    if (pd.tperm_T > 0) {   // block-uniform: (b, t, p) -> (b, p / 16, t, p % 16), see LnPending
+        const int fr = m / pd.tperm_P, pp = m - fr * pd.tperm_P, bb = fr / pd.tperm_T, tt = fr - bb * pd.tperm_T;
+        mo = ((bb * (pd.tperm_P >> 4) + (pp >> 4)) * pd.tperm_T + tt) * 16 + (pp & 15);
+    }
+    store_f16x4_paired<1>(out + tiled_off(mo, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
     sat_report(amax, pd.err_flag);
 }
 
@@ -553,6 +558,18 @@ inline int grid_for(size_t total, int block = 256) {
     return (int)g;
 }
 
+// to_qkv weight rows [q D | k D | v D] (tile-major fp16, K = D) -> head-major rows [head][q 64 | k 64 | v 64]: 16-byte chunks keep
+// their place inside the row (both row indices are congruent mod 8, so the tile swizzle maps chunk to chunk)
+__global__ void qkv_head_major_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cpr = D >> 3;
+    if (i >= (size_t)3 * D * cpr) return;
+    const int nd = (int)(i / cpr), kc = (int)(i - (size_t)nd * cpr);
+    const int hd = nd / 192, rem = nd - hd * 192, which = rem >> 6, d = rem & 63;
+    const int ns = which * D + hd * 64 + d;
+    *(uint4*)(dst + tiled_off(nd, kc * 8, D)) = *(const uint4*)(src + tiled_off(ns, kc * 8, D));
+}
+
 }  // namespace
 
 // -DGTAV_EXPERIMENTS builds: GTAV_LN_FLAGS (see LnPending::flags)
@@ -575,6 +592,7 @@ static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
         pd_.flags = g_ln_flags;                                                                           \
         pd_.err_flag = err_flag;                                                                          \
         const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
+        GTAV_REQUIRE(pd_.tperm_T == 0 || (M <= g_ln_rowblock_max && pd_.tperm_P % 16 == 0 && M % (pd_.tperm_T * pd_.tperm_P) == 0), "ln: bad output row permutation"); \
         if (M <= g_ln_rowblock_max) { /* small M: one block per row */                                                \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
             if (pend) GTAV_LAUNCH((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
@@ -641,6 +659,13 @@ int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, in
     GTAV_REQUIRE(!tiled || (Rp % 128 == 0 && Cp % 64 == 0), "convert_pad: tile-major needs Rp %% 128 == 0 and Cp %% 64 == 0");
     hipLaunchKernelGGL(convert_pad_f16_kernel, dim3(grid_for((size_t)Rp * Cp)), dim3(256), 0, stream, src, lds, R, C, dst,
                        Rp, Cp, scale, tiled);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_qkv_head_major(const f16* src, f16* dst, int D, hipStream_t stream) {
+    GTAV_REQUIRE(D % 128 == 0, "qkv_head_major: D=%d must be a multiple of 128", D);
+    hipLaunchKernelGGL(qkv_head_major_kernel, dim3(grid_for((size_t)3 * D * (D / 8))), dim3(256), 0, stream, src, dst, D);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

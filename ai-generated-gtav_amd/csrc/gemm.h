@@ -63,6 +63,10 @@ struct GemmParams {
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+// Temporal QKV projection + causal temporal attention in one launch (gemm.hip: gemm_qkvt_attn_kernel): X rows in the LayerNorm's
+// tperm order, W = head-major to_qkv weight; writes the temporal K/V cache (p.k) and the attention output (p.out, f16 tile-major).
+bool gemm_qkvt_attn_ok(int M, int D, int S, int Tq, int t0);
+int launch_gemm_qkvt_attn(const GemmParams& p, hipStream_t stream);
 // True when launch_gemm would run this shape on the persistent ping-pong kernel (large M): residual GEMMs then use the in-place
 // EPI_RESID epilogue (hidden under the other wave group's main loop) instead of split-K slabs.
 bool gemm_pp_ok(int M, int N, int K, int epi);

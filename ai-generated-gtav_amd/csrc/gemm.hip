@@ -65,6 +65,19 @@ __device__ __forceinline__ uint2 pack4(float& amax, float a, float b, float c, f
 // every second K-step: the reads' full LDS round trip exposed (gemm.s of round 2).  The barrier stays inline asm with a memory
 // clobber: no LDS or global access may move across it.
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+// Interleaved-pair RoPE of four consecutive features (two pairs) by (cos, sin, cos, sin): explicit fused multiply-adds in ONE fixed
+// order.  Left as `a * c - b * s` the compiler picks which product to fuse per call site (the -DGTAV_EXPERIMENTS build fused the other
+// one in the fused temporal kernel: 23 of 737 280 k values one fp16 ulp apart), and every QKV epilogue must produce the same bits
+// (window step == context-cached step == fused temporal kernel).
+__device__ __forceinline__ f32x4 rope4(const f32x4 v, const f32x4 cs) {
+    f32x4 r;
+    r[0] = __builtin_fmaf(v[0], cs[0], -(v[1] * cs[1]));
+    r[1] = __builtin_fmaf(v[1], cs[0], v[0] * cs[1]);
+    r[2] = __builtin_fmaf(v[2], cs[2], -(v[3] * cs[3]));
+    r[3] = __builtin_fmaf(v[3], cs[2], v[2] * cs[3]);
+    return r;
+}
+
 template <int VM>
 __device__ __forceinline__ void wait_vm() {
     static_assert(VM >= 0 && VM < 64, "vmcnt is a 6-bit field");
@@ -666,12 +679,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
                     f32x4 v = acc[i][j] + bv;
                     if (rope) {
                         const f32x4 cs = *(const f32x4*)(p.rope_cs + pos[j] * 64 + d);
-                        f32x4 r;
-                        r[0] = v[0] * cs[0] - v[1] * cs[1];
-                        r[1] = v[1] * cs[0] + v[0] * cs[1];
-                        r[2] = v[2] * cs[2] - v[3] * cs[3];
-                        r[3] = v[3] * cs[2] + v[2] * cs[3];
-                        v = r;
+                        v = rope4(v, cs);
                     }
                     char* dst = smem + ml * PN + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
                     *(uint2*)dst = pack4(amax, v[0], v[1], v[2], v[3]);
@@ -880,12 +888,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 if (which < 2) {
                     // interleaved table: (cos, sin) of pair d/2 and of pair d/2+1 in one 16-byte load
                     const f32x4 cs = *(const f32x4*)(p.rope_cs + tok_pos[j] * 64 + d);
-                    f32x4 r;
-                    r[0] = v[0] * cs[0] - v[1] * cs[1];
-                    r[1] = v[1] * cs[0] + v[0] * cs[1];
-                    r[2] = v[2] * cs[2] - v[3] * cs[3];
-                    r[3] = v[3] * cs[2] + v[2] * cs[3];
-                    v = r;
+                    v = rope4(v, cs);
                 }
                 const uint2 pk = pack4(amax, v[0], v[1], v[2], v[3]);
                 if (p.qkv_mode == QKV_SPATIAL) {
@@ -1240,6 +1243,139 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Temporal QKV projection + causal temporal attention in ONE launch (the window step at batch 1).
+//
+// The temporal attention of one (batch item, position, head) needs q, k, v of that head for the <= 5 frames of the window at that
+// position and nothing else (model/attention.py:41-71).  So with
+//   * the activation rows in (b, position group of 16, frame, position in group) order — written that way by the LayerNorm in
+//     front (launch_ln_modulate's tperm): an 80-row tile holds all 5 frames of 16 positions;
+//   * the to_qkv weight rows in head-major order [head][q 64 | k 64 | v 64] (a copy made by gtav_dit_finalize): a 192-feature
+//     tile holds one head's q, k and v;
+// a block of the loader-wave GEMM (4 loader waves + 4 compute waves of 48 features x 80 tokens) owns every operand of 16 x 5
+// attention rows of its head.  Epilogue: RoPE in registers -> fp16 q | k | v image in LDS (exactly the values the split path stores
+// to memory) -> K / V rows to the temporal cache (a later context-cached step reads them) -> the attention with the arithmetic of
+// attn_temporal_kernel, operand for operand (same fp16 inputs, same order of the fdot2 / DPP / exp2 / fma chain: bit-identical
+// outputs) -> the out-projection's tile-major X operand.  One launch and the q / kv round trip through memory fewer per block:
+// 16 launches per forward.  Grid = (M / 80) x heads = 144 blocks at batch 1; larger batches keep the split path (several rounds
+// of one-block-per-CU tiles lose to the two-blocks-per-CU QKV GEMM there).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
+    constexpr int FI = 3, FJ = 5, WN = 4, WM = 1, NL = 4, TNB = 192, TM = 80, TMAX = 5;
+    constexpr int PN = 384;   // LDS bytes per token row of the q | k | v image: 24 16-byte chunks, XOR-swizzled inside groups of 8
+    extern __shared__ __attribute__((aligned(16))) char smem_l[];
+    static_assert(NS * (2 * FI * WN + 2 * FJ * WM) * 1024 >= TM * PN, "the ring must cover the epilogue's LDS image");
+    char* smem = smem_l;
+#define GTAV_PIN_S(x) asm volatile("" ::"s"(x))
+    GTAV_PIN_S(p.X); GTAV_PIN_S(p.W); GTAV_PIN_S(p.M); GTAV_PIN_S(p.N); GTAV_PIN_S(p.K);
+    GTAV_PIN_S(p.tm.tiles_m); GTAV_PIN_S(p.tm.tiles_n); GTAV_PIN_S(p.tm.gn); GTAV_PIN_S(p.tm.group); GTAV_PIN_S(p.tm.tiles);
+    GTAV_PIN_S(p.tm.rcp_group); GTAV_PIN_S(p.tm.rcp_gn); GTAV_PIN_S(p.tm.rcp_gnlast);
+#undef GTAV_PIN_S
+    BlockStamps bs;
+    bs.begin(p);
+    int n0, m0, ks, kt0, nkt;
+    tile_map_fast<false, TNB, TM>(p, n0, m0, ks, kt0, nkt);
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, []() {});
+    GTAV_STAMP(bs.t[2]);
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) - NL, li = lane & 15, g = lane >> 4;
+    const int head = n0 / TNB;
+    const int pgs = p.S >> 4, tile_m = m0 / TM, b = tile_m / pgs, pg = tile_m - b * pgs;   // the tile = (batch item b, positions 16 pg ..)
+    float amax = 0.f;
+    __syncthreads();   // every wave is done reading the last K-step's stage
+    if (w >= 0) {
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int nl = 16 * FI * w + 16 * i + 4 * g;          // feature inside [q | k | v] of this head
+            const bool rope = nl < 128;
+            const int d = nl & 63;
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {                      // token group j = frame j of the window, lane li = position in the group
+                const int ml = 16 * j + li;
+                f32x4 v = acc[i][j];
+                if (rope) {
+                    const f32x4 cs = *(const f32x4*)(p.rope_cs + (p.t0 + j) * 64 + d);
+                    v = rope4(v, cs);
+                }
+                char* dst = smem + ml * PN + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
+                *(uint2*)dst = pack4(amax, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    sat_report(amax, p.err_flag);
+    __syncthreads();
+    // K / V rows of this head into the temporal cache ([b][frame][position][k D | v D]): 80 rows x 16 chunks of 16 bytes
+    for (int q = tid; q < TM * 16 && !GTAV_DBG(p, 512); q += 512) {   // (experiments build, debug bit 9: no cache rows, timing only)
+        const int r = q >> 4, cc = q & 15, t = r >> 4, pl = r & 15;
+        const uint4 val = *(const uint4*)(smem + r * PN + (((8 + cc) ^ (r & 7)) << 4));
+        const size_t slot = ((size_t)b * p.Tmax + p.t0 + t) * p.S + 16 * pg + pl;
+        f16* dst = p.k + slot * 2 * p.D + (cc >= 8 ? p.D : 0) + head * 64 + (cc & 7) * 8;
+        if (p.out_sc1) store16q_sc1(dst, val);
+        else *(uint4*)dst = val;
+    }
+    // attention: one thread per (position pl, 8-feature chunk c) and query-frame PAIR — frames (0, 4), (1, 3), (2): 6 + 6 + 3 keys, one
+    // round of 384 threads instead of 512 + 128; the 8 lanes of a head row are an aligned lane group (DPP reduction)
+    union H8 { f16x8 v; f16x2 h[4]; };
+    if (tid < 3 * 128) {
+        const int c = tid & 7, pl = (tid >> 3) & 15, grp = tid >> 7;     // wave-uniform grp
+        H8 k8[TMAX], v8[TMAX];
+        const int thi = TMAX - 1 - grp;                                    // the later query frame of the pair: keys 0 .. thi
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t <= thi) {
+                const int r = 16 * t + pl;
+                k8[t].v = *(const f16x8*)(smem + r * PN + (((8 + c) ^ (r & 7)) << 4));
+                v8[t].v = *(const f16x8*)(smem + r * PN + (((16 + c) ^ (r & 7)) << 4));
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tl = half == 0 ? thi : grp;
+            if (half == 1 && grp == thi) break;                            // the middle frame is its own pair
+            H8 q8;
+            {
+                const int r = 16 * tl + pl;
+                q8.v = *(const f16x8*)(smem + r * PN + ((c ^ (r & 7)) << 4));
+            }
+            float sc[TMAX];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                sc[t] = -INFINITY;
+                if (t <= tl) {   // causal (model/attention.py:62-64)
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dsum = __builtin_amdgcn_fdot2(q8.h[e], k8[t].h[e], dsum, false);
+                    sc[t] = group8_sum(dsum) * 0.125f;
+                    mx = fmaxf(mx, sc[t]);
+                }
+            }
+            float den = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                if (t <= tl) {
+                    const float pr = __builtin_amdgcn_exp2f((sc[t] - mx) * 1.4426950408889634f);
+                    den += pr;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(pr, (float)v8[t].v[e], o[e]);
+                }
+            }
+            const float inv = 1.0f / den;
+            union { f16x8 h; u32x4 u; } o8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8.h[e] = (f16)(o[e] * inv);
+            const int row = (b * p.Tq + tl) * p.S + 16 * pg + pl;   // the token's row in (b, frame, position) order: the out-projection's X
+            store16_sc1((f16*)p.out + tiled_off(row, head * 64 + c * 8, p.D), o8.u);
+        }
+    }
+    bs.end(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Persistent ping-pong GEMM for large M (shape 16): one 1024-thread block per CU, two groups of 8 waves.
 //
 // What the stamps of round 2 showed for the two-blocks-per-CU shape at M = 5760 (profiles/round2/stamps_*.txt): the 512
@@ -1504,12 +1640,7 @@ __global__ __launch_bounds__(1024, 1) void gemm_pp_kernel(GemmParams p) {
                     const int which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
                     const int nn = n - which * p.D;
                     if (which < 2) {
-                        f32x4 r;
-                        r[0] = v[0] * r1[0] - v[1] * r1[1];
-                        r[1] = v[1] * r1[0] + v[0] * r1[1];
-                        r[2] = v[2] * r1[2] - v[3] * r1[3];
-                        r[3] = v[3] * r1[2] + v[2] * r1[3];
-                        v = r;
+                        v = rope4(v, r1);
                     }
                     const uint2 pk = pack4(amax, v[0], v[1], v[2], v[3]);
                     f16* dst;
@@ -1579,6 +1710,9 @@ void gemm_set_stamps(unsigned long long* buf, int max_blocks) { g_stamps = buf; 
 #endif
 
 int gemm_choose_splitk(int M, int N, int K) {
+#ifdef GTAV_EXPERIMENTS
+    if (g_debug & 256) return 1;   // A/B with GTAV_RESID_INPLACE_MIN_M=1: full-K residual GEMMs on 64 x 48 tiles + in-place epilogue (measured slower, profiles/round2/forward_ab_B1_inplace_fullK.txt)
+#endif
     const int tiles = cdiv(M, 128) * cdiv(N, TN);
     int s = 1;
     while (tiles * s < 192 && s < 8 && (K / TK) % (s * 2) == 0 && K / (s * 2) >= 256) s *= 2;
@@ -1644,6 +1778,24 @@ static int launch_pp(const GemmParams& p, hipStream_t stream) {
 }
 
 // loader-wave kernels: dynamic LDS above 64 KiB needs the per-device opt-in once per instantiation
+// block -> tile map constants of the loader-wave kernels (tile_map_fast)
+static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int tmb, int tnb, int splitk) {
+    tm.tiles_m = cdiv(M, tmb);
+    tm.tiles_n = cdiv(N, tnb);
+    tm.tiles = tm.tiles_m * tm.tiles_n;
+    tm.gn = tm.tiles_n >= 8 ? tm.tiles_n >> 3 : 1;
+    tm.group = tm.tiles_m * tm.gn;
+    const int gnlast = tm.tiles_n % tm.gn ? tm.tiles_n % tm.gn : tm.gn;
+    auto rcp = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };   // ceil(2^32 / d), d >= 2
+    GTAV_REQUIRE((long long)tm.tiles * splitk < 65536, "gemm: grid of %d tiles x %d slices is too large for the 32-bit reciprocal tile map", tm.tiles, splitk);
+    // a divisor of 1 has no 32-bit reciprocal (it would be 2^32): 0 encodes it, div_rcp() then returns its argument
+    tm.rcp_tiles = tm.tiles > 1 ? rcp(tm.tiles) : 0;
+    tm.rcp_group = tm.group > 1 ? rcp(tm.group) : 0;
+    tm.rcp_gn = tm.gn > 1 ? rcp(tm.gn) : 0;
+    tm.rcp_gnlast = gnlast > 1 ? rcp(gnlast) : 0;
+    return 0;
+}
+
 template <int EPI, int NS, int FI, int FJ, int WN, int WM, int NL>
 static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
     constexpr int LDS = NS * (2 * FI * WN + 2 * FJ * WM) * 1024;
@@ -1655,22 +1807,7 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
         attr_devs |= 1ull << (dev & 63);
     }
     GemmParams q = p;
-    {
-        GemmParams::TileMap& tm = q.tm;
-        tm.tiles_m = cdiv(p.M, 16 * FJ * WM);
-        tm.tiles_n = cdiv(p.N, 16 * FI * WN);
-        tm.tiles = tm.tiles_m * tm.tiles_n;
-        tm.gn = tm.tiles_n >= 8 ? tm.tiles_n >> 3 : 1;
-        tm.group = tm.tiles_m * tm.gn;
-        const int gnlast = tm.tiles_n % tm.gn ? tm.tiles_n % tm.gn : tm.gn;
-        auto rcp = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };   // ceil(2^32 / d), d >= 2
-        GTAV_REQUIRE((long long)tm.tiles * splitk < 65536, "gemm: grid of %d tiles x %d slices is too large for the 32-bit reciprocal tile map", tm.tiles, splitk);
-        // a divisor of 1 has no 32-bit reciprocal (it would be 2^32): 0 encodes it, div_rcp() then returns its argument
-        tm.rcp_tiles = tm.tiles > 1 ? rcp(tm.tiles) : 0;
-        tm.rcp_group = tm.group > 1 ? rcp(tm.group) : 0;
-        tm.rcp_gn = tm.gn > 1 ? rcp(tm.gn) : 0;
-        tm.rcp_gnlast = gnlast > 1 ? rcp(gnlast) : 0;
-    }
+    if (int rc_ = fill_tile_map(q.tm, p.M, p.N, 16 * FJ * WM, 16 * FI * WN, splitk)) return rc_;
     const dim3 grid(q.tm.tiles * splitk);
     GTAV_LAUNCH((gemm_l_kernel<EPI, NS, FI, FJ, WN, WM, NL>), grid, dim3(64 * (WN * WM + NL)), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
@@ -1728,6 +1865,38 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
         if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 2, 4>), grid, dim3(256));
         else GEMM_LAUNCH((gemm_kernel<EPI, 4, 2, 4>), grid, dim3(256));
     }
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Fused temporal QKV GEMM + attention (gemm_qkvt_attn_kernel).  p: X = the LayerNorm output in tperm order, W = head-major to_qkv
+// weight, M tokens = B * 5 * S, N = 3 D, K = D, D, S (positions per frame, % 16 == 0), Tq = 5, t0 = 0, Tmax, rope_cs, k = the
+// temporal K/V cache, out = the attention output (f16, tile-major, logical row length D).
+static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int tmb, int tnb, int splitk);
+bool gemm_qkvt_attn_ok(int M, int D, int S, int Tq, int t0) {
+    return Tq == 5 && t0 == 0 && S % 16 == 0 && D % 64 == 0 && M % (Tq * S) == 0 && (M / 80) * (D / 64) <= 256;
+}
+int launch_gemm_qkvt_attn(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams q = p_in;
+    GTAV_REQUIRE(gemm_qkvt_attn_ok(q.M, q.D, q.S, q.Tq, q.t0), "gemm/qkvt_attn: unsupported geometry M=%d D=%d S=%d Tq=%d t0=%d", q.M, q.D, q.S, q.Tq, q.t0);
+    GTAV_REQUIRE(q.N == 3 * q.D && q.K % TK == 0 && q.k && q.out && q.rope_cs && q.Tmax >= q.Tq, "gemm/qkvt_attn: missing buffers");
+    GTAV_REQUIRE(((uintptr_t)q.X & 15) == 0 && ((uintptr_t)q.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    constexpr int NS = 4, LDS = NS * 34 * 1024;
+    static unsigned long long attr_devs = 0;
+    int dev = 0;
+    GTAV_REQUIRE(device_cus(&dev) > 0, "gemm: no current device");
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_qkvt_attn_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_devs |= 1ull << (dev & 63);
+    }
+#ifdef GTAV_EXPERIMENTS
+    q.debug = g_debug & (3 | 32 | 512);
+    q.stamps = g_stamps;
+#endif
+    q.out_sc1 = 1;
+    q.splitk = 1;
+    if (int rc_ = fill_tile_map(q.tm, q.M, q.N, 80, 192, 1)) return rc_;
+    GTAV_LAUNCH((gemm_qkvt_attn_kernel<NS>), dim3(q.tm.tiles), dim3(512), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -52,11 +52,16 @@ struct LnPending {
     // y = sum_s parts[s] + bias (before the gate) is kept as fp16 rows of ld elements in y_save.  Both may be null.
     float* x_out;
     f16* y_save;
+    // Row order of the fp16 output (row-block kernel only).  tperm_T > 0: token row m = (b * tperm_T + t) * tperm_P + p is written
+    // to row ((b * (tperm_P / 16) + p / 16) * tperm_T + t) * 16 + p % 16 — 16 positions x all frames of the window contiguous, the
+    // X-tile order of the fused temporal QKV + attention GEMM (gemm.hip gemm_qkvt_attn_kernel).  0 = identity.
+    int tperm_T, tperm_P;
 };
 
 // LayerNorm outputs are GEMM A-operands: fp16 TILE-MAJOR with logical row length D (buffer rows padded to 128).
 // LayerNorm(eps=1e-6, no affine) + adaLN modulate -> fp16  (model/dit.py:19-27,163-181)
 //   out[m] = LN(x[m]) * (1 + (scale[row] + 1e-6)) + shift[row],  row = rows ? rows[m / rows_per_mod] : m / rows_per_mod
+// (pend->tperm_T / tperm_P select a permuted OUTPUT row order, see LnPending)
 int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
                        int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, int* err_flag, hipStream_t stream);
 // LayerNorm(eps=1e-6) with affine weight/bias -> fp16   (model/vae.py:139,146,174)
@@ -92,6 +97,8 @@ int launch_latents_to_tokens(const float* lat, float* z, int N, int hw, int late
 int launch_resize_aa(const void* src, int src_is_u8_strip, float* dst, int n, int H, int W, int OH, int OW, hipStream_t stream);
 // fp32 strided copy with padding (used to build concatenated fp32 weights): dst[r][c0 + c] = src[r][c]
 int launch_copy_f32(const float* src, int lds, int R, int C, float* dst, int ldd, int c0, hipStream_t stream);
+// tile-major to_qkv weight [3 D][D] -> head-major row order [head][q 64 | k 64 | v 64] (the fused temporal QKV + attention GEMM's W)
+int launch_qkv_head_major(const f16* src, f16* dst, int D, hipStream_t stream);
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
 // cs[pos][k] = (cos[pos][2k], sin[pos][2k]) for k < 32: the GEMM epilogue's interleaved RoPE table
 int launch_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int npos, hipStream_t stream);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "gtav_dit_adamw_step": [_p, _f, _f, _f, _f, _f, _f, _p],
     "gtav_dit_train_stats": [_p, C.POINTER(C.c_float), _p],
     "gtav_dit_set_graph": [_p, _i],
+    "gtav_dit_set_fused_temporal": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_comm_unique_id": [_p],
@@ -103,6 +104,8 @@ SIGNATURES = {
     "gtav_op_ln_affine": [_p, _p, _i, _i, _p, _p, _p],
     "gtav_op_attn_spatial": [_p, _p, _p, _p, _i, _i, _i, _p],
     "gtav_op_attn_temporal": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "gtav_op_qkv_head_major": [_p, _p, _i, _p],
+    "gtav_op_gemm_qkvt_attn": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _i, _p],
     "gtav_op_gemm_splitk_ln": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],

@@ -22,6 +22,7 @@
  *                            (once per handle), captures the step on it and instantiates a hipGraph (host work only, nothing
  *                            executes during capture); later calls are one hipGraphLaunch.  gtav_dit_set_graph(h, 0) selects
  *                            plain launches, which never allocate
+ *   gtav_dit_set_fused_temporal   first enable: hipMalloc of the head-major weight copies, device synchronise
  *   gtav_dit_forward         with gtav_dit_profile enabled only: creates events and synchronises at the end of the forward
  *   gtav_dit_check / gtav_vae_check   copy the device error word back and synchronise `stream`
  *   gtav_dit_train_enable    hipMalloc + hipMemset of masters, optimizer state, saved-activation and backward workspace, two small
@@ -106,6 +107,14 @@ int gtav_dit_prepare_frame(gtav_dit* h, int32_t B, int32_t F, int32_t start, int
 /* The fused step replays a captured hipGraph per (shape, buffers) key by default; this call switches to plain
  * launches (results are identical). */
 int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
+
+/* Optional (default OFF): full-window steps / forwards of up to 256 (80-token tile, head) pairs — batch 1 with a 5-frame window —
+ * run the temporal half's to_qkv projection and its causal temporal attention (model/attention.py:41-71) as ONE kernel.  Outputs
+ * are bit-identical to the two-kernel path, which every other shape always uses; on MI355X the fused kernel measured 1-2 % slower
+ * per forward, so it is kept as a tested alternative, not the default.  The first enabling call allocates
+ * head-major copies of the temporal to_qkv weights (6 D^2 bytes per block) and, on a finalized handle, fills them and
+ * synchronises the device; every call drops the captured graphs of the handle.  Ignored on handles with training enabled. */
+int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
 
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
  * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).
@@ -255,6 +264,13 @@ int gtav_op_attn_spatial(const void* q_dev, const void* k_dev, const void* vt_de
                          int32_t heads, int32_t S, void* stream);
 int gtav_op_attn_temporal(const void* q_dev, const void* kv_dev, void* o_dev, int32_t B, int32_t P, int32_t D,
                           int32_t Tq, int32_t t0, int32_t Tmax, void* stream);
+/* Temporal half of a full-window step as ONE kernel (gtav_dit_set_fused_temporal): x rows in (b, 16 positions, frame, position in
+ * group) order, w = the to_qkv weight in head-major row order (gtav_op_qkv_head_major of the tile-major [3 D][D] weight); writes K / V
+ * of every token to the temporal cache kv [B][Tmax][P][2 D] and the attention output o (f16 tile-major, rows in (b, frame, position)
+ * order).  Requires Tq == 5, t0 == 0, P % 16 == 0, (M / 80) * (D / 64) <= 256 (model/attention.py:41-71). */
+int gtav_op_qkv_head_major(const void* w_f16_dev, void* w_hm_f16_dev, int32_t D, void* stream);
+int gtav_op_gemm_qkvt_attn(const void* x_tperm_f16_dev, const void* w_hm_f16_dev, int32_t M, int32_t D, int32_t P, int32_t Tq,
+                           int32_t t0, int32_t Tmax, const float* rope_cs_dev, void* kv_dev, void* o_dev, void* stream);
 /* Residual GEMM as the model runs it: split-K partial slabs (parts: splitk*M*N floats; splitk 0 = heuristic) followed by
  * the LayerNorm kernel that reduces them: resid += gate * (sum parts + bias); out = LN(resid) * (1 + scale + 1e-6) + shift. */
 int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,

@@ -95,6 +95,47 @@ def test_full_dit_forward_b2_t3_no_actions(full_dit):
     assert e < 1e-3
 
 
+def test_fused_temporal_qkv_attention_is_bit_identical(full_dit):
+    """gtav_dit_set_fused_temporal(h, 1): batch-1 five-frame windows run the temporal to_qkv projection + temporal attention as
+    one kernel (gemm_qkvt_attn_kernel); every other shape, and the default, the two-kernel path.  Same fp16
+    operands and the same arithmetic order: the outputs must be EQUAL, at full size (144 blocks) and on a toy model with two
+    batch items (tile -> (batch item, position group) indexing), through the plain forward and the captured sampler step."""
+    from gtav_amd.utils import alphas_cumprod
+    m, sd, cfg = full_dit
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 5, 16, 18, 32, generator=g)
+    t = torch.tensor([[15, 15, 15, 15, 700]])
+    a = torch.zeros(1, 5, 25)
+    a[:, :, 7] = 1
+    try:
+        m.set_fused_temporal(False)
+        split = m(x, t, a).clone()
+        m.set_fused_temporal(True)
+        fused = m(x, t, a).clone()
+    finally:
+        m.set_fused_temporal(False)
+    assert torch.isfinite(fused).all() and torch.equal(fused, split)
+    with torch.no_grad():
+        assert rel_l2(fused, O.dit_forward(sd, cfg, x, t, a)) < TOL_FULL
+    ms, _, _ = _mk_dit(SMALL_DIT, seed=9)
+    xs, ts, as_ = _inputs(O.DiTConfig(**SMALL_DIT), 2, 5, seed=13)
+    ms.set_fused_temporal(False)
+    split = ms(xs, ts, as_).clone()
+    ms.set_fused_temporal(True)
+    assert torch.equal(ms(xs, ts, as_), split)
+    # sampler steps (eager warm-up, capture, replay) and a context-cached step on the K/V cache the fused kernel wrote
+    ms.set_schedule(alphas_cumprod(1e-4))
+    outs = []
+    for fused_on in (False, True):
+        ms.set_fused_temporal(fused_on)
+        xd = xs.to(dev()).contiguous()
+        for _ in range(3):
+            ms.denoise_step_(xd, 0, 4, 15, 600, 500, False, as_.to(dev()))
+        ms.denoise_step_(xd, 0, 4, 15, 500, 400, False, as_.to(dev()), cached=True)
+        outs.append(xd.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_denoise_step_mirror_and_fused_and_cached():
     from gtav_amd.sampler import denoise_step
     from gtav_amd.utils import alphas_cumprod

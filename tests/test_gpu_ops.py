@@ -210,6 +210,62 @@ def test_attention_temporal(Tq, t0):
     assert rel_l2(untile(o, B * Tq * P, D).float(), ref) < 6e-4
 
 
+@pytest.mark.parametrize("B,P,D", [(1, 144, 1024), (2, 32, 256), (3, 16, 256)])
+def test_fused_temporal_qkv_attention_equals_the_two_kernel_path(B, P, D):
+    """gemm_qkvt_attn_kernel (to_qkv projection + RoPE + causal temporal attention + K/V cache rows in one launch) against
+    gtav_op_gemm_qkv + gtav_op_attn_temporal on the same operands: BIT-EQUAL cache rows and attention output (same fp16 q / k / v,
+    same arithmetic order), and both within fp16 rounding of fp32 math (model/attention.py:41-71).  Repeated launches must agree too
+    (race screen: the fused kernel's LDS image reuses the ring)."""
+    Tq, t0, Tmax = 5, 0, 5
+    M = B * Tq * P
+    lib = L.load()
+    x = _rand(M, D, seed=1).half()
+    w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
+    ang = (_rand(Tmax, 32, seed=3) * 3).repeat_interleave(2, dim=-1)
+    cd, sd_ = ang.cos().to(dev()).contiguous(), ang.sin().to(dev()).contiguous()
+    cs = torch.empty_like(cd)
+    L.check(lib.gtav_op_rope_interleave(cd.data_ptr(), sd_.data_ptr(), cs.data_ptr(), Tmax, stream()))
+    w16 = pad_weight_f16(w)
+    Mp = (M + 127) // 128 * 128
+    # two-kernel path
+    q = torch.zeros(M, D, device=dev(), dtype=torch.float16)
+    kv = torch.zeros(B, Tmax, P, 2, D, device=dev(), dtype=torch.float16)
+    o = torch.zeros(Mp, D, device=dev(), dtype=torch.float16)
+    L.check(lib.gtav_op_gemm_qkv(to_tiled_f16(x).data_ptr(), D, w16.data_ptr(), 0, M, D, 1, q.data_ptr(), kv.data_ptr(), kv.data_ptr(), P, Tq,
+                                 t0, Tmax, cs.data_ptr(), stream()))
+    L.check(lib.gtav_op_attn_temporal(q.data_ptr(), kv.data_ptr(), o.data_ptr(), B, P, D, Tq, t0, Tmax, stream()))
+    # fused: rows (b, t, p) -> (b, p // 16, t, p % 16), head-major weight rows
+    xp = x.reshape(B, Tq, P // 16, 16, D).permute(0, 2, 1, 3, 4).reshape(M, D)
+    w_hm = torch.empty_like(w16)
+    L.check(lib.gtav_op_qkv_head_major(w16.data_ptr(), w_hm.data_ptr(), D, stream()))
+    xpd = to_tiled_f16(xp)
+    first = None
+    for rep in range(20):
+        kv2 = torch.zeros_like(kv)
+        o2 = torch.zeros_like(o)
+        L.check(lib.gtav_op_gemm_qkvt_attn(xpd.data_ptr(), w_hm.data_ptr(), M, D, P, Tq, t0, Tmax, cs.data_ptr(), kv2.data_ptr(), o2.data_ptr(),
+                                           stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = (kv2.clone(), o2.clone())
+            assert torch.equal(kv2, kv), "K / V cache rows differ from the two-kernel path"
+            assert torch.equal(untile(o2, M, D), untile(o, M, D)), "attention output differs from the two-kernel path"
+        else:
+            assert torch.equal(kv2, first[0]) and torch.equal(o2, first[1]), f"launch {rep} differs from launch 0"
+    # and against fp32 math
+    h = D // 64
+    y = (x.float() @ w.half().float().t()).reshape(B, Tq, P, 3, h, 64)
+    pos = torch.arange(Tq)
+    c, s = ang.cos()[pos][None, :, None, None, :], ang.sin()[pos][None, :, None, None, :]
+    qf = _rope_ref(y[:, :, :, 0], c, s).half().float().permute(0, 2, 3, 1, 4)     # B P h T d
+    kf = _rope_ref(y[:, :, :, 1], c, s).half().float().permute(0, 2, 3, 1, 4)
+    vf = y[:, :, :, 2].half().float().permute(0, 2, 3, 1, 4)
+    sc = qf @ kf.transpose(-1, -2) / 8.0
+    sc = sc.masked_fill(torch.arange(Tq)[None, :] > torch.arange(Tq)[:, None], float("-inf"))
+    ref = (sc.softmax(-1) @ vf).permute(0, 3, 1, 2, 4).reshape(M, D)
+    assert rel_l2(untile(first[1], M, D).float(), ref) < 6e-4
+
+
 def test_ddim_update_matches_reference_formula():
     rows, n = 6, 1000
     x, v = _rand(rows, n, seed=1), _rand(rows, n, seed=2)

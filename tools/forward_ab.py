@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--variants", type=int, nargs="+", default=[0, 64])
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--actions", action="store_true")
+    ap.add_argument("--fused-ab", action="store_true", help="A/B the fused temporal QKV + attention kernel instead: variant 0 = two-kernel path, 1 = fused")
     ap.add_argument("--depth", type=int, default=16, help="fewer blocks: the weights then stay in the 256 MiB Infinity Cache between forwards")
     a = ap.parse_args()
     lib = L.load_experiments()
@@ -38,7 +39,11 @@ def main():
     ref = None
     for r in range(a.rounds):
         for v in a.variants:
-            lib.gtav_op_gemm_set_debug(v)
+            if a.fused_ab:
+                dit.set_fused_temporal(bool(v & 1))
+                lib.gtav_op_gemm_set_debug(v & ~1)    # e.g. 513 = fused + debug bit 9 (no K/V cache rows: timing only)
+            else:
+                lib.gtav_op_gemm_set_debug(v)
             for _ in range(3):
                 out = dit(x, t, act)
             torch.cuda.synchronize()
