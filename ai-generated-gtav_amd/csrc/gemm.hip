@@ -553,11 +553,12 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
 }
 
 // XCD-aware, bijective block -> tile map: blocks that share an XCD (equal bid % 8) get a contiguous run of tiles.
-// Inside an XCD's run the order is (m, n) with n FASTEST over a group of `gn` n-panels (gn = tiles_n / 8, the panels one
-// XCD owns): co-resident blocks then share X row-tiles as well as W panels in that XCD's 4 MiB L2.  With m fastest, X
-// (11.8 MB at M = 5760) was re-streamed from the fabric once per n-panel: rocprofv3 FETCH_SIZE 301 MB per fc1 launch
-// against 20 MB algorithmic (profiles/round1/pmc).  Split-K: the K slice is the slowest index, so the slices of one W
-// panel stay on one XCD.
+// Inside an XCD's run the order is (m, n) with n FASTEST over a group of `gn` n-panels: co-resident blocks then share X
+// row-tiles as well as W panels in that XCD's 4 MiB L2.  With m fastest, X (11.8 MB at M = 5760) was re-streamed from the
+// fabric once per n-panel: rocprofv3 FETCH_SIZE 301 MB per fc1 launch against 20 MB algorithmic (profiles/round1/pmc).
+// Split-K: the K slice is the slowest index, so the slices of one W panel stay on one XCD.  gn is chosen on the host
+// (choose_gn): round 1 fixed it at tiles_n / 8 — every XCD then owns an eighth of the n-panels and streams ALL of X, which for
+// the N = 1024 GEMMs at large M is 8 x X from the fabric (fc2 at M = 5760: 385 MB per launch against 55 MB algorithmic).
 template <bool SPLITK, int TNB, int TMB>
 __device__ __forceinline__ void tile_map(const GemmParams& p, int& n0, int& m0, int& ks, int& kt0, int& nkt) {
     const int tiles_m = (p.M + TMB - 1) / TMB, tiles_n = (p.N + TNB - 1) / TNB;
@@ -573,7 +574,7 @@ __device__ __forceinline__ void tile_map(const GemmParams& p, int& n0, int& m0, 
         nkt = nkt / p.splitk;
         kt0 = ks * nkt;
     }
-    int gn = tiles_n >= 8 ? tiles_n >> 3 : 1;
+    int gn = p.tm.gn;                                      // host: choose_gn() (every launcher fills it)
     const int group = tiles_m * gn;
     const int ng = tile_id / group, rem = tile_id - ng * group;
     const int n_first = ng * gn;
@@ -1403,7 +1404,7 @@ __device__ __forceinline__ void pp_tile_of(const GemmParams& p, int v, int tiles
     const int T = tiles_m * tiles_n;
     const int xcd = v & 7, qq = T >> 3, rr = T & 7;
     const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (v >> 3);
-    int gn = tiles_n >= 8 ? tiles_n >> 3 : 1;
+    int gn = p.tm.gn;                                      // host: choose_gn() (every launcher fills it)
     const int group = tiles_m * gn;
     const int ng = tile_id / group, rem = tile_id - ng * group;
     const int n_first = ng * gn;
@@ -1772,18 +1773,51 @@ static int launch_pp(const GemmParams& p, hipStream_t stream) {
     }
     const int T = cdiv(p.M, PP_TM) * cdiv(p.N, PP_TN);
     const dim3 grid(T < cus ? T : cus);
-    GTAV_LAUNCH((gemm_pp_kernel<EPI, NS>), grid, dim3(1024), NS * PP_STAGE, stream, p);
+    GemmParams q = p;
+    const int tiles_n = cdiv(p.N, PP_TN);
+    q.tm.gn = tiles_n >= 8 ? tiles_n >> 3 : 1;   // pp_tile_of: an eighth of the n-panels per group (the persistent walk strides over XCD runs)
+    GTAV_LAUNCH((gemm_pp_kernel<EPI, NS>), grid, dim3(1024), NS * PP_STAGE, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // loader-wave kernels: dynamic LDS above 64 KiB needs the per-device opt-in once per instantiation
 // block -> tile map constants of the loader-wave kernels (tile_map_fast)
-static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int tmb, int tnb, int splitk) {
+// Width (in n-panels) of the tile groups of the block -> tile map (tile_map): the linear tile order is (K slice, group of gn
+// n-panels, m-tile, panel in group) and every XCD takes a contiguous eighth of it.  One pass over a group streams the K slice of X
+// once (its co-resident blocks share X row-tiles and W panels in the XCD's L2), so with G = tiles_n / gn groups and C = 8 / splitk
+// XCDs per K slice the fabric sees  G x X  +  max(1, C / G) x W  bytes per slice: narrow groups re-stream X, wide groups make
+// several XCDs fetch the same W panels.  Pick the minimum, with the W panels of a group capped at 2 MiB (they must survive in the
+// 4 MiB L2 while the group's m-tiles sweep past).  Round 1's fixed gn = tiles_n / 8 is the G = 8 corner: right at M = 720 (X is
+// small), 3.5x too much traffic for the N = 1024 GEMMs at M = 5760.
+static int g_force_gn = GTAV_ENV_INT("GTAV_GEMM_GN", 0);   // experiments build: > 0 forces the group width, < 0 = round-1 rule (A/B runs)
+static int choose_gn(int M, int N, int K, int tmb, int tnb, int splitk) {
+    const int tiles_n = cdiv(N, tnb);
+#ifdef GTAV_EXPERIMENTS
+    if (g_debug & 1024) return tiles_n >= 8 ? tiles_n >> 3 : 1;   // debug bit 10: round-1 rule, for A/B runs in one process
+#endif
+    if (g_force_gn < 0) return tiles_n >= 8 ? tiles_n >> 3 : 1;
+    if (g_force_gn > 0) return g_force_gn < tiles_n ? g_force_gn : tiles_n;
+    const double ks = (double)K / (splitk > 0 ? splitk : 1);
+    const double xs = 2.0 * M * ks, ws = 2.0 * N * ks, wpanel = 2.0 * tnb * ks;
+    const double c = splitk >= 8 ? 1.0 : 8.0 / (splitk > 0 ? splitk : 1);
+    int best = 1;
+    double best_cost = 1e300;
+    for (int gn = 1; gn <= tiles_n; ++gn) {
+        if (gn > 1 && gn * wpanel > 2.0 * 1024 * 1024) break;
+        const int g = cdiv(tiles_n, gn);
+        const double cost = g * xs + ws * (c > g ? c / g : 1.0);
+        if (cost < best_cost * 0.999) best_cost = cost, best = gn;   // ties keep the narrower group (more XCD-local W)
+    }
+    (void)tmb;
+    return best;
+}
+
+static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int K, int tmb, int tnb, int splitk) {
     tm.tiles_m = cdiv(M, tmb);
     tm.tiles_n = cdiv(N, tnb);
     tm.tiles = tm.tiles_m * tm.tiles_n;
-    tm.gn = tm.tiles_n >= 8 ? tm.tiles_n >> 3 : 1;
+    tm.gn = choose_gn(M, N, K, tmb, tnb, splitk);
     tm.group = tm.tiles_m * tm.gn;
     const int gnlast = tm.tiles_n % tm.gn ? tm.tiles_n % tm.gn : tm.gn;
     auto rcp = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };   // ceil(2^32 / d), d >= 2
@@ -1807,7 +1841,7 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
         attr_devs |= 1ull << (dev & 63);
     }
     GemmParams q = p;
-    if (int rc_ = fill_tile_map(q.tm, p.M, p.N, 16 * FJ * WM, 16 * FI * WN, splitk)) return rc_;
+    if (int rc_ = fill_tile_map(q.tm, p.M, p.N, p.K, 16 * FJ * WM, 16 * FI * WN, splitk)) return rc_;
     const dim3 grid(q.tm.tiles * splitk);
     GTAV_LAUNCH((gemm_l_kernel<EPI, NS, FI, FJ, WN, WM, NL>), grid, dim3(64 * (WN * WM + NL)), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
@@ -1815,7 +1849,9 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
 }
 
 template <int EPI>
-static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStream_t stream) {
+static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hipStream_t stream) {
+    GemmParams p = p_in;
+    auto set_gn = [&](int tmb, int tnb) { p.tm.gn = choose_gn(p.M, p.N, p.K, tmb, tnb, splitk); };
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
     if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
     if (shape == 23) return launch_l<EPI, 4, 4, 3, 2, 2, 4>(p, splitk, stream);   // 128 x 96, 4 compute waves of 64 x 48 + 4 loader waves
@@ -1834,33 +1870,41 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
         }
     }
     if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
+        set_gn(96, 64);
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 2, 3>), grid, dim3(384));
     } else if (shape == 12) {  // 128 features x 192 tokens, 8 waves of 64 x 48, two blocks per CU (4 waves per SIMD)
+        set_gn(192, 128);
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 2, 4, 3, 4>), grid, dim3(512));
     } else if (shape == 11) {  // 64 features x 48 tokens, 6 waves: skinny M (context-cached sampling, M = 144)
+        set_gn(48, 64);
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384));   // 6 stages measured 6-8 % slower
     } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
+        set_gn(96, 128);
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384));   // 3 stages 1-3 % and 5 stages 4-5 % slower
     } else if (shape == 8) {   // 96 x 96, 6 waves
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
         } else {
+            set_gn(96, 96);
             const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 96) * splitk);
             GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 3, 2, 3>), grid, dim3(384));
         }
     } else if (shape == 7) {
+        set_gn(256, 256);
         const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
         GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
     } else if (shape == 3) {
+        set_gn(128, TN);
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
         if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 4, 2>), grid, dim3(512));
         else GEMM_LAUNCH((gemm_kernel<EPI, 4, 4, 2>), grid, dim3(512));
     } else {
         GTAV_REQUIRE(shape == 2, "gemm: unknown block shape %d", shape);
+        set_gn(128, TN);
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
         if (ns <= 2) GEMM_LAUNCH((gemm_kernel<EPI, 2, 2, 4>), grid, dim3(256));
         else GEMM_LAUNCH((gemm_kernel<EPI, 4, 2, 4>), grid, dim3(256));
@@ -1872,7 +1916,7 @@ static int launch_epi(const GemmParams& p, int ns, int shape, int splitk, hipStr
 // Fused temporal QKV GEMM + attention (gemm_qkvt_attn_kernel).  p: X = the LayerNorm output in tperm order, W = head-major to_qkv
 // weight, M tokens = B * 5 * S, N = 3 D, K = D, D, S (positions per frame, % 16 == 0), Tq = 5, t0 = 0, Tmax, rope_cs, k = the
 // temporal K/V cache, out = the attention output (f16, tile-major, logical row length D).
-static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int tmb, int tnb, int splitk);
+static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int K, int tmb, int tnb, int splitk);
 bool gemm_qkvt_attn_ok(int M, int D, int S, int Tq, int t0) {
     return Tq == 5 && t0 == 0 && S % 16 == 0 && D % 64 == 0 && M % (Tq * S) == 0 && (M / 80) * (D / 64) <= 256;
 }
@@ -1895,7 +1939,7 @@ int launch_gemm_qkvt_attn(const GemmParams& p_in, hipStream_t stream) {
 #endif
     q.out_sc1 = 1;
     q.splitk = 1;
-    if (int rc_ = fill_tile_map(q.tm, q.M, q.N, 80, 192, 1)) return rc_;
+    if (int rc_ = fill_tile_map(q.tm, q.M, q.N, q.K, 80, 192, 1)) return rc_;
     GTAV_LAUNCH((gemm_qkvt_attn_kernel<NS>), dim3(q.tm.tiles), dim3(512), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
