@@ -423,7 +423,13 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
         woff[s] = (16 * FI * wn + li) * 128 + ch;
         xoff[s] = WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
     }
-    const bool late = w >= 4;                           // second wave of a SIMD: fills after its MFMAs
+    // second wave of a SIMD: fills after its MFMAs (small-M shapes, deep ring: the partners' fill / MFMA phases overlap).  With the
+    // two-stage ring of the large-M tile (two blocks per CU) a late fill sits on the K-step's critical path — it is awaited at the
+    // very next barrier — so there every wave fills right after the barrier: QKV 57.6 -> 48.5 us, out-proj 20.5 -> 18.2 back to back
+    // at M = 5760, B = 8 forward -2.5 % (profiles/round2/gemm_M5760_l2_prefetch_wave_and_early_fills.txt; debug bit 11 of the
+    // experiments build restores the late fills for A/B runs).  An L2 prefetch wave (one load per 128-byte line of K-step t + 3)
+    // changed nothing in the same runs: the K-step is not waiting for the fabric.
+    const bool late = w >= 4 && (NS > 2 || GTAV_DBG(p, 2048));
     const int npro = nkt < NS - 1 ? nkt : NS - 1;
     for (int t = 0; t < npro; ++t) stage(t);
     after_prologue();   // register loads the epilogue wants early (bias): behind the first fills, not in front of them
@@ -1947,7 +1953,7 @@ int launch_gemm_qkvt_attn(const GemmParams& p_in, hipStream_t stream) {
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_debug & (3 | 16 | 32);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
+    p.debug = g_debug & (3 | 16 | 32 | 2048);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
     p.stamps = nullptr;
 #ifdef GTAV_EXPERIMENTS
     p.stamps = g_stamps;            // the tool sizes the buffer for the largest grid it launches (g_stamp_blocks)

@@ -26,8 +26,10 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--wm", type=int, nargs="+", default=[0])
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--debug", type=int, default=0, help="gemm debug bits (1 = no refills, 2 = no LDS reads / MFMAs: wrong results, timing only)")
     a = ap.parse_args()
     lib = L.load_experiments()
+    lib.gtav_op_gemm_set_debug(a.debug)
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     shapes = [("qkv", 3072, 1024, 5), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]
