@@ -1807,14 +1807,22 @@ static int choose_gn(int M, int N, int K, int tmb, int tnb, int splitk) {
     const double ks = (double)K / (splitk > 0 ? splitk : 1);
     const double xs = 2.0 * M * ks, ws = 2.0 * N * ks, wpanel = 2.0 * tnb * ks;
     const double c = splitk >= 8 ? 1.0 : 8.0 / (splitk > 0 ? splitk : 1);
+    auto cost_of = [&](int gn) {
+        const int g = cdiv(tiles_n, gn);
+        return g * xs + ws * (c > g ? c / g : 1.0);
+    };
     int best = 1;
     double best_cost = 1e300;
     for (int gn = 1; gn <= tiles_n; ++gn) {
         if (gn > 1 && gn * wpanel > 2.0 * 1024 * 1024) break;
-        const int g = cdiv(tiles_n, gn);
-        const double cost = g * xs + ws * (c > g ? c / g : 1.0);
+        const double cost = cost_of(gn);
         if (cost < best_cost * 0.999) best_cost = cost, best = gn;   // ties keep the narrower group (more XCD-local W)
     }
+    // The model ignores how the groups line up with the XCDs' runs of tiles: where it predicts less than a 20 % saving keep round 1's
+    // eighth-of-the-panels groups, which do line up (fc1 at M = 720: gn = 5 instead of 4 was predicted 1 % better and measured
+    // 34.1 MB per launch against 27.4 MB)
+    const int gn1 = tiles_n >= 8 ? tiles_n >> 3 : 1;
+    if (best_cost > 0.8 * cost_of(gn1)) best = gn1;
     (void)tmb;
     return best;
 }

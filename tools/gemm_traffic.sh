@@ -17,3 +17,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/$c" -- ./tools/gemm_pmc 16 > "$OUT/$c.log" 2>&1
 done
 python3 tools/gemm_traffic.py "$OUT"
+cp profiles/traffic.json gpurun_out/traffic.json   # the GPU box only sends gpurun_out/ back: copy it to profiles/ in the repo
