@@ -1512,6 +1512,11 @@ int gtav_op_gemm_qkvt_attn(const void* x_tperm, const void* w_hm, int32_t M, int
     g.rope_cs = rope_cs;
     return launch_gemm_qkvt_attn(g, (hipStream_t)stream);
 }
+int gtav_op_attn_spatial_bwd(const void* q, const void* k, const void* vt, const void* d_o, int32_t NB, int32_t heads, int32_t S,
+                             const float* rope_cs, void* dqkv, void* stream) {
+    return launch_attn_spatial_bwd((const f16*)q, (const f16*)k, (const f16*)vt, (const f16*)d_o, NB, heads, S, heads * 64, rope_cs, (f16*)dqkv, nullptr,
+                                   (hipStream_t)stream);
+}
 int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t N, int32_t K,
                            int32_t splitk, float* parts, float* resid, const float* gate, int32_t gate_stride,
                            int32_t rows_per_gate, void* out_f16, const float* shift, const float* scale, int32_t mod_stride,

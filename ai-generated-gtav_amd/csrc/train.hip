@@ -430,6 +430,224 @@ __global__ __launch_bounds__(NT) void attn_spatial_bwd_kernel(const f16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The same on the matrix cores (the default; the VALU kernel above stays for the experiments build's A/B runs).  One block of three
+// waves per (frame, head); Q, K, V, dO as fp16 rows in LDS (pitch 72 halves), 16 x 16 tiles (S = 144: 9 tiles).
+//   pre-pass (wave w: query tiles w, w + 3, ...): S_i = Q_i K^T and dP_i = dO_i V^T for the whole key row (v_mfma_f32_16x16x32_f16: lane
+//     (g = l / 16, c = l % 16) holds rows 4 g + r, column c), row statistics over the 16 lanes of a group -> lse2[q] = max c + log2 sum
+//     (c = log2(e) / 8) and Dq[q] = sum_j P dP to LDS;
+//   main (wave w: key tiles j = w, w + 3, ...; dK_j / dV_j in registers): for every query tile i recompute S_ij, dP_ij (2 + 2 MFMAs), P =
+//     exp2(S c - lse2), dS = P (dP - Dq) / 8.  The accumulator layout of a 16 x 16 tile IS the A-operand layout of its transpose for the
+//     K = 16 MFMA (lane: row c, k = 4 g + r), so dV_j += P^T dO_i and dK_j += dS^T Q_i take P / dS straight from registers; their B
+//     operands (4 query rows x 16 features, a column gather) are transposing LDS reads (ds_read_b64_tr_b16) of the row-major images.
+//     dQ_i^T += K_j^T dS^T needs dS with queries along lanes: the wave writes the tile to a private [key][query] scratch (8 bytes per lane)
+//     and reads it back transposed; dQ accumulates in an fp32 LDS image through ds_add_f32 (three waves add to every row).
+//   epilogue: RoPE^T (the transpose of a rotation is the rotation by the negative angle), dK_j / dV_j into the LDS rows of K_j / V_j (no other
+//     wave reads them), dQ from the fp32 image, then 16-byte stores into the tile-major [M][3 D] gradient of the to_qkv output.
+// fp16 rounding of P and dS (the MFMA operands) is the only arithmetic difference to the VALU kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 lds_read_tr(const f16* p) {   // lane 4 q + p' of a 16-lane group passes row q, columns 4 p' ..; lane i gets column i of the 4 rows
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+constexpr int ABM_LP = 72, ABM_DQP = 68, ABM_NW = 3, ABM_MAXT = AB_MAXS / 16;
+template <int DBG>   // experiments: 1 = no dQ atomics, 2 = no K = 16 MFMAs / transposed reads, 4 = no RoPE / LDS write-back of dK, dV (timing only)
+__global__ __launch_bounds__(64 * ABM_NW) void attn_spatial_bwd_mfma_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+                                                                            const f16* __restrict__ dO, int heads, int S, int D,
+                                                                            const float* __restrict__ rope_cs, f16* __restrict__ dqkv, int* err_flag) {
+    constexpr int LP = ABM_LP, DQP = ABM_DQP, NW = ABM_NW, NT = 64 * ABM_NW;
+    extern __shared__ __attribute__((aligned(16))) char smraw[];
+    f16* sQ = (f16*)smraw;                 // [S][LP]
+    f16* sK = sQ + S * LP;
+    f16* sV = sK + S * LP;
+    f16* sdO = sV + S * LP;
+    float* sdQ = (float*)(sdO + S * LP);   // [S][DQP]
+    float* slse = sdQ + S * DQP;           // [S]
+    float* sDq = slse + S;                 // [S]
+    f16* sscr = (f16*)(sDq + S);           // [NW][16][16]: dS tile of the wave as [key][query]
+    const int item = blockIdx.x, nb = item / heads, head = item % heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int nt = S >> 4;
+    const f16* q = Q + (size_t)item * S * 64;
+    const f16* k = K + (size_t)item * S * 64;
+    const f16* vt = Vt + (size_t)item * 64 * S;
+    for (int i = tid; i < S * 8; i += NT) {        // 16-byte chunks
+        const int srow = i >> 3, ch = i & 7;
+        *(uint4*)(sQ + srow * LP + 8 * ch) = ((const uint4*)q)[i];
+        *(uint4*)(sK + srow * LP + 8 * ch) = ((const uint4*)k)[i];
+        *(uint4*)(sdO + srow * LP + 8 * ch) = *(const uint4*)(dO + ((size_t)nb * S + srow) * D + head * 64 + 8 * ch);
+    }
+    for (int i = tid; i < S * 8; i += NT) {        // V^T rows (one feature, S tokens) in 8-token chunks -> [token][feature]; lanes along the feature: conflict-free 2-byte LDS stores
+        const int d = i & 63, s0 = (i >> 6) << 3;
+        const f16x8 v8 = *(const f16x8*)(vt + (size_t)d * S + s0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sV[(s0 + e) * LP + d] = v8[e];
+    }
+    __syncthreads();
+    const float cexp = 0.125f * 1.4426950408889634f;
+    // ---- pre-pass: row statistics ----
+    for (int i = w; i < nt; i += NW) {
+        f16x8 qa[2], ga[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            qa[h] = *(const f16x8*)(sQ + (16 * i + c) * LP + 32 * h + 8 * g);
+            ga[h] = *(const f16x8*)(sdO + (16 * i + c) * LP + 32 * h + 8 * g);
+        }
+        f32x4 sa[ABM_MAXT], da[ABM_MAXT];
+#pragma unroll
+        for (int j = 0; j < ABM_MAXT; ++j) {
+            sa[j] = da[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < nt) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f16x8 kb = *(const f16x8*)(sK + (16 * j + c) * LP + 32 * h + 8 * g);
+                    const f16x8 vb = *(const f16x8*)(sV + (16 * j + c) * LP + 32 * h + 8 * g);
+                    sa[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[h], kb, sa[j], 0, 0, 0);
+                    da[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga[h], vb, da[j], 0, 0, 0);
+                }
+            }
+        }
+        f32x4 mx = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int j = 0; j < ABM_MAXT; ++j)
+            if (j < nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], sa[j][r]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], o, 64));
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f}, pd = sum;
+#pragma unroll
+        for (int j = 0; j < ABM_MAXT; ++j)
+            if (j < nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pe = __builtin_amdgcn_exp2f((sa[j][r] - mx[r]) * cexp);
+                    sum[r] += pe;
+                    pd[r] = __builtin_fmaf(pe, da[j][r], pd[r]);
+                }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sum[r] += __shfl_xor(sum[r], o, 64);
+                pd[r] += __shfl_xor(pd[r], o, 64);
+            }
+        f32x4 lse, dqr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lse[r] = mx[r] * cexp + __builtin_amdgcn_logf(sum[r]);   // v_log_f32 = log2
+            dqr[r] = pd[r] / sum[r];
+        }
+        if (c == 0) {
+            *(f32x4*)(slse + 16 * i + 4 * g) = lse;
+            *(f32x4*)(sDq + 16 * i + 4 * g) = dqr;
+        }
+        // dQ_i^T[feature][query] = sum_j K_j^T dS_ij^T while the whole row of S_i / dP_i is still in registers (one wave owns the query tile:
+        // no cross-wave accumulation; an fp32 LDS image fed by ds_add_f32 from the key-tile loop cost 500 us of a 650 us launch)
+        f32x4 dqa[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) dqa[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f16* scr0 = sscr + w * 256;
+#pragma unroll
+        for (int j = 0; j < ABM_MAXT; ++j) {
+            if (j < nt) {
+                f16x4 dsh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pe = __builtin_amdgcn_exp2f(sa[j][r] * cexp - lse[r]);
+                    dsh[r] = (f16)__builtin_amdgcn_fmed3f(pe * (da[j][r] - dqr[r]) * 0.125f, -F16_MAX, F16_MAX);
+                }
+                *(f16x4*)(scr0 + c * 16 + 4 * g) = dsh;                                       // scratch[key c][queries 4 g ..]
+                const f16x4 dsT = lds_read_tr(scr0 + (4 * g + (c >> 2)) * 16 + 4 * (c & 3));    // B[k = key 4 g + e][col = query c]
+                if (!(DBG & 2)) {
+#pragma unroll
+                    for (int ft = 0; ft < 4; ++ft) {
+                        const f16x4 kT = lds_read_tr(sK + (16 * j + 4 * g + (c >> 2)) * LP + 16 * ft + 4 * (c & 3));   // A[row = feature 16 ft + c][k = key 4 g + e]
+                        dqa[ft] = __builtin_amdgcn_mfma_f32_16x16x16f16(kT, dsT, dqa[ft], 0, 0, 0);           // rows: features 16 ft + 4 g + r; column: query c
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) *(f32x4*)(sdQ + (16 * i + c) * DQP + 16 * ft + 4 * g) = dqa[ft];
+    }
+    __syncthreads();
+    // ---- main: key tiles of this wave ----
+    float amax = 0.f;
+    for (int j = w; j < nt; j += NW) {
+        f16x8 kb[2], vb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            kb[h] = *(const f16x8*)(sK + (16 * j + c) * LP + 32 * h + 8 * g);
+            vb[h] = *(const f16x8*)(sV + (16 * j + c) * LP + 32 * h + 8 * g);
+        }
+        f32x4 dKa[4], dVa[4];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) dKa[ft] = dVa[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < nt; ++i) {
+            f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, da = sa;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f16x8 qa = *(const f16x8*)(sQ + (16 * i + c) * LP + 32 * h + 8 * g);
+                const f16x8 ga = *(const f16x8*)(sdO + (16 * i + c) * LP + 32 * h + 8 * g);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kb[h], sa, 0, 0, 0);     // rows: queries 16 i + 4 g + r; column: key 16 j + c
+                da = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, vb[h], da, 0, 0, 0);
+            }
+            const f32x4 l4 = *(const f32x4*)(slse + 16 * i + 4 * g), d4 = *(const f32x4*)(sDq + 16 * i + 4 * g);
+            f16x4 ph, dsh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pe = __builtin_amdgcn_exp2f(sa[r] * cexp - l4[r]);
+                const float dsv = pe * (da[r] - d4[r]) * 0.125f;
+                amax = fmaxf(amax, fabsf(dsv));
+                ph[r] = (f16)pe;
+                dsh[r] = (f16)__builtin_amdgcn_fmed3f(dsv, -F16_MAX, F16_MAX);
+            }
+            if (DBG & 2) { amax = fmaxf(amax, (float)ph[0] + (float)dsh[0]); continue; }
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const f16x4 goT = lds_read_tr(sdO + (16 * i + 4 * g + (c >> 2)) * LP + 16 * ft + 4 * (c & 3));   // B[k = query 4 g + e][col = feature 16 ft + c]
+                const f16x4 qT = lds_read_tr(sQ + (16 * i + 4 * g + (c >> 2)) * LP + 16 * ft + 4 * (c & 3));
+                dVa[ft] = __builtin_amdgcn_mfma_f32_16x16x16f16(ph, goT, dVa[ft], 0, 0, 0);     // rows: keys 16 j + 4 g + r; column: feature 16 ft + c
+                dKa[ft] = __builtin_amdgcn_mfma_f32_16x16x16f16(dsh, qT, dKa[ft], 0, 0, 0);
+            }
+        }
+        // dK_j (RoPE^T: the pair partner of feature 16 ft + c is the neighbouring lane c ^ 1) and dV_j -> LDS rows of K_j / V_j
+        if (DBG & 4) { amax = fmaxf(amax, dKa[0][0] + dVa[1][1]); continue; }
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int d = 16 * ft + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * j + 4 * g + r;
+                const float mine = dKa[ft][r], other = __shfl_xor(mine, 1, 64);
+                const float co = rope_cs[(size_t)key * 64 + (d & ~1)], si = rope_cs[(size_t)key * 64 + (d | 1)];
+                const float dk = (d & 1) ? mine * co - other * si : mine * co + other * si;
+                amax = fmaxf(amax, fmaxf(fabsf(dk), fabsf(dVa[ft][r])));
+                sK[key * LP + d] = (f16)__builtin_amdgcn_fmed3f(dk, -F16_MAX, F16_MAX);
+                sV[key * LP + d] = (f16)__builtin_amdgcn_fmed3f(dVa[ft][r], -F16_MAX, F16_MAX);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: 16-byte stores of dq | dk | dv rows ----
+    for (int i = tid; i < S * 8; i += NT) {
+        const int srow = i >> 3, ch = i & 7;
+        const size_t m = (size_t)nb * S + srow;
+        const f32x4 a = *(const f32x4*)(sdQ + srow * DQP + 8 * ch), b = *(const f32x4*)(sdQ + srow * DQP + 8 * ch + 4);
+        const f32x4 cs0 = *(const f32x4*)(rope_cs + (size_t)srow * 64 + 8 * ch), cs1 = *(const f32x4*)(rope_cs + (size_t)srow * 64 + 8 * ch + 4);
+        union { f16x4 h[2]; uint4 u; } o;
+        o.h[0] = sat4(a[0] * cs0[0] + a[1] * cs0[1], a[1] * cs0[0] - a[0] * cs0[1], a[2] * cs0[2] + a[3] * cs0[3], a[3] * cs0[2] - a[2] * cs0[3], amax);
+        o.h[1] = sat4(b[0] * cs1[0] + b[1] * cs1[1], b[1] * cs1[0] - b[0] * cs1[1], b[2] * cs1[2] + b[3] * cs1[3], b[3] * cs1[2] - b[2] * cs1[3], amax);
+        *(uint4*)(dqkv + tiled_off((int)m, head * 64 + 8 * ch, 3 * D)) = o.u;
+        *(uint4*)(dqkv + tiled_off((int)m, D + head * 64 + 8 * ch, 3 * D)) = *(const uint4*)(sK + srow * LP + 8 * ch);
+        *(uint4*)(dqkv + tiled_off((int)m, 2 * D + head * 64 + 8 * ch, 3 * D)) = *(const uint4*)(sV + srow * LP + 8 * ch);
+    }
+    sat_report(amax, err_flag);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Temporal (causal) attention backward (model/attention.py:41-71): per (b, position p, head) a T x T lower-triangular problem,
 // T <= 8.  16 lanes per item, 4 head features per lane, dot products by 4 xor-shuffles inside the 16-lane group.
 // q fp16 [M][D] (m = (b T + t) P + p), kv cache [B][Tmax][P][2][D] (k with RoPE, v), dO fp16 row-major [M][D];
@@ -790,20 +1008,40 @@ int launch_mse_bwd_patch(const float* vpred, const float* vtarget, int B, int T,
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
+static int g_attn_bwd_valu = GTAV_ENV_INT("GTAV_ATTN_BWD_VALU", 0);   // experiments build: 1 = the VALU kernel (A/B runs)
+static int g_attn_bwd_dbg = GTAV_ENV_INT("GTAV_ATTN_BWD_DBG", 0);     // experiments build: timing variants of the MFMA kernel (wrong results)
 int launch_attn_spatial_bwd(const f16* Q, const f16* K, const f16* Vt, const f16* dO, int NB, int heads, int S, int D, const float* rope_cs, f16* dqkv,
                             int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(S > 0 && S <= AB_MAXS && S % 16 == 0 && D == heads * 64, "attn_spatial_bwd: S=%d (<= %d, %% 16), D=%d", S, AB_MAXS, D);
     constexpr int NT = 512;
-    const size_t lds = (size_t)4 * S * 72 * 2 + (size_t)2 * (NT / 16) * (S + 4) * 4;
+    const size_t lds_valu = (size_t)4 * S * 72 * 2 + (size_t)2 * (NT / 16) * (S + 4) * 4;
+    const size_t lds_mfma = (size_t)4 * S * ABM_LP * 2 + (size_t)S * ABM_DQP * 4 + (size_t)2 * S * 4 + (size_t)ABM_NW * 256 * 2;
     static unsigned long long attr_devs = 0;
     int dev = 0;
     GTAV_CHECK_HIP(hipGetDevice(&dev));
     if (!(attr_devs >> (dev & 63) & 1)) {
         GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_mfma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef GTAV_EXPERIMENTS
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_bwd_mfma_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
         attr_devs |= 1ull << (dev & 63);
     }
-    GTAV_REQUIRE(lds <= 160 * 1024, "attn_spatial_bwd: S=%d needs %zu bytes of LDS", S, lds);
-    hipLaunchKernelGGL(attn_spatial_bwd_kernel<NT>, dim3(NB * heads), dim3(NT), lds, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+    GTAV_REQUIRE(lds_valu <= 160 * 1024 && lds_mfma <= 160 * 1024, "attn_spatial_bwd: S=%d needs %zu bytes of LDS", S, lds_valu > lds_mfma ? lds_valu : lds_mfma);
+    if (g_attn_bwd_valu)
+        hipLaunchKernelGGL(attn_spatial_bwd_kernel<NT>, dim3(NB * heads), dim3(NT), lds_valu, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+#ifdef GTAV_EXPERIMENTS
+    else if (g_attn_bwd_dbg == 1)
+        hipLaunchKernelGGL(attn_spatial_bwd_mfma_kernel<1>, dim3(NB * heads), dim3(64 * ABM_NW), lds_mfma, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+    else if (g_attn_bwd_dbg == 3)
+        hipLaunchKernelGGL(attn_spatial_bwd_mfma_kernel<3>, dim3(NB * heads), dim3(64 * ABM_NW), lds_mfma, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+    else if (g_attn_bwd_dbg == 7)
+        hipLaunchKernelGGL(attn_spatial_bwd_mfma_kernel<7>, dim3(NB * heads), dim3(64 * ABM_NW), lds_mfma, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
+#endif
+    else
+        hipLaunchKernelGGL(attn_spatial_bwd_mfma_kernel<0>, dim3(NB * heads), dim3(64 * ABM_NW), lds_mfma, stream, Q, K, Vt, dO, heads, S, D, rope_cs, dqkv, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

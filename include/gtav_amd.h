@@ -271,6 +271,11 @@ int gtav_op_attn_temporal(const void* q_dev, const void* kv_dev, void* o_dev, in
 int gtav_op_qkv_head_major(const void* w_f16_dev, void* w_hm_f16_dev, int32_t D, void* stream);
 int gtav_op_gemm_qkvt_attn(const void* x_tperm_f16_dev, const void* w_hm_f16_dev, int32_t M, int32_t D, int32_t P, int32_t Tq,
                            int32_t t0, int32_t Tmax, const float* rope_cs_dev, void* kv_dev, void* o_dev, void* stream);
+/* Backward of the spatial attention (model/attention.py:99-136) for NB x heads (frame, head) items of S tokens: q, k [item][S][64]
+ * (RoPE applied), vt [item][64][S], d_o fp16 row-major [NB S][heads 64]; writes the gradient of the to_qkv output, fp16 tile-major
+ * logical [NB S][3 heads 64] (dq | dk | dv, dq / dk rotated back through the RoPE).  S % 16 == 0, S <= 160. */
+int gtav_op_attn_spatial_bwd(const void* q_dev, const void* k_dev, const void* vt_dev, const void* d_o_dev, int32_t NB, int32_t heads,
+                             int32_t S, const float* rope_cs_dev, void* dqkv_dev, void* stream);
 /* Residual GEMM as the model runs it: split-K partial slabs (parts: splitk*M*N floats; splitk 0 = heuristic) followed by
  * the LayerNorm kernel that reduces them: resid += gate * (sum parts + bias); out = LN(resid) * (1 + scale + 1e-6) + shift. */
 int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,

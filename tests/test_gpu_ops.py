@@ -266,6 +266,41 @@ def test_fused_temporal_qkv_attention_equals_the_two_kernel_path(B, P, D):
     assert rel_l2(untile(first[1], M, D).float(), ref) < 6e-4
 
 
+@pytest.mark.parametrize("NB,heads,S", [(3, 2, 144), (2, 4, 32), (1, 1, 160)])
+def test_attention_spatial_backward_mfma(NB, heads, S):
+    """attn_spatial_bwd_mfma_kernel (train.hip) against torch.autograd of softmax(q k^T / 8) v on the same fp16 q / k / v / dO
+    (model/attention.py:99-136): dv, and dq / dk rotated back through the RoPE the forward applied (cos / sin per (position, pair)).
+    The kernel rounds P and dS to fp16 for its MFMA operands: 2e-3."""
+    lib = L.load()
+    D = heads * 64
+    q = _rand(NB, heads, S, 64, seed=1).half()
+    k = _rand(NB, heads, S, 64, seed=2).half()
+    v = _rand(NB, heads, S, 64, seed=3).half()
+    do = _rand(NB * S, D, seed=4).half()
+    ang = (_rand(S, 32, seed=5) * 3)
+    cs = torch.stack([ang.cos(), ang.sin()], dim=-1).reshape(S, 64).contiguous()          # [pos][pair][cos, sin]
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    o = torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf                            # NB h S 64
+    o.backward(do.float().reshape(NB, S, heads, 64).permute(0, 2, 1, 3))
+    co, si = ang.cos()[None, None], ang.sin()[None, None]                                      # RoPE^T: rotation by the negative angle
+
+    def unrope(gr):
+        a, b = gr[..., 0::2], gr[..., 1::2]
+        return torch.stack([a * co + b * si, b * co - a * si], dim=-1).reshape(gr.shape)
+
+    ref = torch.cat([unrope(qf.grad), unrope(kf.grad), vf.grad], dim=1)                        # NB (3 h) S 64
+    ref = ref.reshape(NB, 3, heads, S, 64).permute(0, 3, 1, 2, 4).reshape(NB * S, 3 * D)
+    Mp = (NB * S + 127) // 128 * 128
+    out = torch.zeros(Mp, 3 * D, device=dev(), dtype=torch.float16)
+    qd, kd, vtd, dod, csd = (t.to(dev()).contiguous() for t in (q, k, v.transpose(-1, -2), do, cs))   # keep the device copies alive over the call
+    L.check(lib.gtav_op_attn_spatial_bwd(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), dod.data_ptr(), NB, heads, S, csd.data_ptr(), out.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    got = untile(out, NB * S, 3 * D).float()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = rel_l2(got[:, sl], ref[:, sl])
+        assert e < 2e-3, (name, e)
+
+
 def test_ddim_update_matches_reference_formula():
     rows, n = 6, 1000
     x, v = _rand(rows, n, seed=1), _rand(rows, n, seed=2)
