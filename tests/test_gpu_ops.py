@@ -295,6 +295,10 @@ def test_attention_spatial_backward_mfma(NB, heads, S):
     qd, kd, vtd, dod, csd = (t.to(dev()).contiguous() for t in (q, k, v.transpose(-1, -2), do, cs))   # keep the device copies alive over the call
     L.check(lib.gtav_op_attn_spatial_bwd(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), dod.data_ptr(), NB, heads, S, csd.data_ptr(), out.data_ptr(), stream()))
     torch.cuda.synchronize()
+    out2 = torch.zeros_like(out)
+    L.check(lib.gtav_op_attn_spatial_bwd(qd.data_ptr(), kd.data_ptr(), vtd.data_ptr(), dod.data_ptr(), NB, heads, S, csd.data_ptr(), out2.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)          # no atomics: launches are bitwise reproducible
     got = untile(out, NB * S, 3 * D).float()
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         e = rel_l2(got[:, sl], ref[:, sl])
