@@ -305,7 +305,7 @@ struct gtav_dit {
         std::vector<HB> hb;
         f16 *xnF = nullptr, *xp = nullptr;
         float *z0 = nullptr, *cpre = nullptr;                   // pre-SiLU values of the conditioning path
-        float *dres = nullptr, *dtmp = nullptr, *stats = nullptr, *dmod = nullptr, *dSc = nullptr, *dc = nullptr, *dh0 = nullptr, *dz0 = nullptr;
+        float *dres = nullptr, *dtmp = nullptr, *stats = nullptr, *dmod = nullptr, *dSc = nullptr, *ada_part = nullptr, *dc = nullptr, *dh0 = nullptr, *dz0 = nullptr;
         f16 *g_d = nullptr, *g_h = nullptr, *g_u = nullptr, *g_qkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dfo = nullptr;
     } tr;
 };
@@ -862,7 +862,7 @@ int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena
     const size_t R = h->max_rows;
     RET_IF(a.alloc_t(&t.z0, R * D)); RET_IF(a.alloc_t(&t.cpre, R * D));
     RET_IF(a.alloc_t(&t.dres, Mx * D)); RET_IF(a.alloc_t(&t.dtmp, Mx * D)); RET_IF(a.alloc_t(&t.stats, 2 * Mx));
-    RET_IF(a.alloc_t(&t.dmod, R * h->MODW)); RET_IF(a.alloc_t(&t.dSc, R * D)); RET_IF(a.alloc_t(&t.dc, R * D)); RET_IF(a.alloc_t(&t.dh0, R * D));
+    RET_IF(a.alloc_t(&t.dmod, R * h->MODW)); RET_IF(a.alloc_t(&t.dSc, R * D)); RET_IF(a.alloc_t(&t.ada_part, ada_bwd_dx_workspace(h->MODW, D, (int)R))); RET_IF(a.alloc_t(&t.dc, R * D)); RET_IF(a.alloc_t(&t.dh0, R * D));
     RET_IF(a.alloc_t(&t.dz0, R * D));
     RET_IF(a.alloc_t(&t.g_d, Mx * D)); RET_IF(a.alloc_t(&t.g_h, Mx * Hp)); RET_IF(a.alloc_t(&t.g_u, Mx * Hp)); RET_IF(a.alloc_t(&t.g_qkv, Mx * 3 * D));
     RET_IF(a.alloc_t(&t.dao, Mm * D)); RET_IF(a.alloc_t(&t.dfo, Mx * 64));
@@ -1106,8 +1106,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     }
     // ---- the shared conditioning path (fp32, `rows` = B T rows): c = W_2 SiLU(W_0 e + b_0) + b_2 (+ W_ext a + b_ext), SiLU(c) feeds every adaLN
     // projection (their own gradients were taken block by block above) ----
-    GTAV_CHECK_HIP(hipMemsetAsync(tr.dSc, 0, (size_t)rows * D * sizeof(float), s));
-    RET_IF(launch_ada_bwd_dx(dmod, MODW, h->w_ada, D, rows, tr.dSc, s));
+    RET_IF(launch_ada_bwd_dx(dmod, MODW, h->w_ada, D, rows, tr.dSc, tr.ada_part, s));
     RET_IF(launch_silu_bwd(tr.dSc, D, tr.cpre, D, tr.dc, D, rows, D, s));
     RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("t_embedder.mlp.2.bias").grad, s));
     RET_IF(launch_gemm_tn_f32(tr.dc, D, h->HC, ldhc, rows, D, D, slot("t_embedder.mlp.2.weight").grad, D, s));

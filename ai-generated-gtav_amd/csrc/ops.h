@@ -157,7 +157,10 @@ int launch_silu(const float* x, int ldx, float* y, int ldy, int R, int C, hipStr
 int launch_silu_bwd(const float* dy, int lddy, const float* x, int ldx, float* dx, int lddx, int R, int C, hipStream_t stream);
 int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R, int N, int K, float* dW, int lddw, hipStream_t stream);   // dW += dY^T X
 int launch_gemm_nn_f32(const float* dY, int lddy, const float* W, int ldw, int R, int N, int K, float* dX, int lddx, hipStream_t stream);   // dX = dY W
-int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, hipStream_t stream);                         // dSc += dmod W_ada
+// dSc [R][D] = dmod [R][MODW] x W_ada [MODW][D].  `part` = workspace of ada_bwd_dx_workspace(MODW, D, R) floats (fp32 MFMA path: per-chunk partial
+// sums reduced in a fixed order); nullptr selects the VALU kernel, which accumulates with atomics.  dSc is overwritten.
+size_t ada_bwd_dx_workspace(int MODW, int D, int R);
+int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, float* part, hipStream_t stream);                         // dSc += dmod W_ada
 // multi-tensor AdamW: one descriptor per parameter, one work item per 64 x 64 weight tile / 4096-element run (train.hip)
 struct AdamParam {
     float* p; int ldp, R, C;               // fp32 master (GEMM weights: contiguous [R][C]; fp32 parameters: in place, leading dimension ldp)

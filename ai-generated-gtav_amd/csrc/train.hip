@@ -774,6 +774,49 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
     for (int i = 0; i < 8; ++i)
         if (n0 + i < N) dW[(size_t)(n0 + i) * lddw + k] += a[i];
 }
+// The same on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an fp32 fma chain): a wave owns 64 rows n x 64 columns k (4 x 4 tiles); per
+// step of 4 conditioning rows r it loads 4 + 4 operand values per lane (64-byte row segments of dY and X, both L2-resident) for 16 MFMAs.
+// N % 64 == 0, K % 64 == 0.  The VALU kernel above spent 78 us per half-block slice (6144 x 1024) on 3 load instructions per 8 FMAs;
+// the read-modify-write of the 25 MB gradient slice is 13 us of that.
+__global__ __launch_bounds__(256) void gemm_tn_f32_mfma_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ X, int ldx, int R, int N, int K,
+                                                               float* __restrict__ dW, int lddw) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * 64, n0 = (blockIdx.y * 4 + w) * 64;
+    if (n0 >= N) return;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* dy = dY + n0 + li;
+    const float* x = X + k0 + li;
+#pragma unroll 2
+    for (int r0 = 0; r0 < R; r0 += 4) {
+        const int r = r0 + g;
+        const bool ok = r < R;
+        const size_t rr = ok ? r : 0;
+        float av[4], bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            av[t] = dy[rr * lddy + 16 * t];
+            bv[t] = x[rr * ldx + 16 * t];
+            if (!ok) av[t] = 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    // D[row = n 16 a + 4 g + e][col = k 16 b + li]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float* o = dW + (size_t)(n0 + 16 * a + 4 * g + e) * lddw + k0 + li;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o[16 * b] += acc[a][b][e];
+        }
+}
 // dX[r][k] = sum_n dY[r][n] W[n][k]       (one thread per (r, k))
 __global__ void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ W, int ldw, int R, int N, int K, float* __restrict__ dX,
                                    int lddx) {
@@ -817,6 +860,65 @@ __global__ __launch_bounds__(256) void ada_bwd_dx_kernel(const float* __restrict
             for (int i = 0; i < ADA_RB; ++i)
                 if (rb + i < R) atomicAdd(dSc + (size_t)(rb + i) * D + n, acc[i]);
     }
+}
+// dSc on the fp32 matrix cores.  One block of D / 64 waves per chunk of 1024 rows k of W_ada: W_ada is read ONCE (the VALU kernel
+// above needs one pass per 40 conditioning rows and is FMA-bound: 2.2 ms per step at full size), every wave owns 64 columns n (4 tiles) x
+// all R <= 80 rows (5 tiles); the dmod chunk goes through LDS 64 columns at a time (A operand: lane (li, g) reads row 16 t + li, column
+// 4 s + g), W rows stream straight into registers (B operand: 64-byte row segments).  The partial sums of a chunk are stored, not
+// added: ada_reduce_kernel sums the chunks in a fixed order (deterministic, no atomics).
+constexpr int ADA_KC = 1024, ADA_RT = 5, ADA_PITCH = 68;
+__global__ __launch_bounds__(1024) void ada_bwd_dx_mfma_kernel(const float* __restrict__ dmod, int MODW, const float* __restrict__ W, int D, int R,
+                                                               float* __restrict__ part) {
+    __shared__ float sd[16 * ADA_RT * ADA_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, g = lane >> 4, nthr = blockDim.x;
+    const int n0 = w * 64;
+    const int kc0 = blockIdx.x * ADA_KC, kc1 = min(MODW, kc0 + ADA_KC);
+    f32x4 acc[ADA_RT][4];
+#pragma unroll
+    for (int t = 0; t < ADA_RT; ++t)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = kc0; kb < kc1; kb += 64) {
+        __syncthreads();
+        for (int i = tid; i < 16 * ADA_RT * 64; i += nthr) {
+            const int r = i >> 6, kk = i & 63;
+            sd[r * ADA_PITCH + kk] = (r < R && kb + kk < kc1) ? dmod[(size_t)r * MODW + kb + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            int krow = kb + 4 * s4 + g;
+            krow = krow < MODW ? krow : MODW - 1;           // rows past the chunk end meet zero dmod values
+            const float* wp = W + (size_t)krow * D + n0 + li;
+            float bv[4], av[ADA_RT];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = wp[16 * b];
+#pragma unroll
+            for (int t = 0; t < ADA_RT; ++t) av[t] = sd[(16 * t + li) * ADA_PITCH + 4 * s4 + g];
+#pragma unroll
+            for (int t = 0; t < ADA_RT; ++t)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[b], acc[t][b], 0, 0, 0);
+        }
+    }
+    // D[row = r 16 t + 4 g + e][col = n 16 b + li]
+    float* o = part + (size_t)blockIdx.x * R * D;
+#pragma unroll
+    for (int t = 0; t < ADA_RT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 16 * t + 4 * g + e;
+            if (r < R)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) o[(size_t)r * D + n0 + 16 * b + li] = acc[t][b][e];
+        }
+}
+__global__ void ada_reduce_kernel(const float* __restrict__ part, int nchunk, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int c = 0; c < nchunk; ++c) a += part[(size_t)c * n + i];
+    out[i] = a;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1067,7 +1169,10 @@ int launch_silu_bwd(const float* dy, int lddy, const float* x, int ldx, float* d
     return 0;
 }
 int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R, int N, int K, float* dW, int lddw, hipStream_t stream) {
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(cdiv(K, 256), cdiv(N, 8)), dim3(256), 0, stream, dY, lddy, X, ldx, R, N, K, dW, lddw);
+    if (N % 64 == 0 && K % 64 == 0)
+        hipLaunchKernelGGL(gemm_tn_f32_mfma_kernel, dim3(K / 64, cdiv(N, 256)), dim3(256), 0, stream, dY, lddy, X, ldx, R, N, K, dW, lddw);
+    else
+        hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(cdiv(K, 256), cdiv(N, 8)), dim3(256), 0, stream, dY, lddy, X, ldx, R, N, K, dW, lddw);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1076,9 +1181,19 @@ int launch_gemm_nn_f32(const float* dY, int lddy, const float* W, int ldw, int R
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, hipStream_t stream) {
-    const int KC = 2048;
-    hipLaunchKernelGGL(ada_bwd_dx_kernel, dim3(cdiv(D, 256), cdiv(MODW, KC)), dim3(256), 0, stream, dmod, MODW, W, D, R, KC, dSc);
+size_t ada_bwd_dx_workspace(int MODW, int D, int R) { return (size_t)cdiv(MODW, ADA_KC) * R * D; }
+int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R, float* dSc, float* part, hipStream_t stream) {
+    if (part && D % 64 == 0 && D <= 1024 && R <= 16 * ADA_RT) {
+        const int nchunk = cdiv(MODW, ADA_KC);
+        hipLaunchKernelGGL(ada_bwd_dx_mfma_kernel, dim3(nchunk), dim3(D), 0, stream, dmod, MODW, W, D, R, part);
+        GTAV_CHECK_HIP(hipGetLastError());
+        const size_t n = (size_t)R * D;
+        hipLaunchKernelGGL(ada_reduce_kernel, dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, stream, part, nchunk, n, dSc);
+    } else {
+        GTAV_CHECK_HIP(hipMemsetAsync(dSc, 0, (size_t)R * D * sizeof(float), stream));
+        const int KC = 2048;
+        hipLaunchKernelGGL(ada_bwd_dx_kernel, dim3(cdiv(D, 256), cdiv(MODW, KC)), dim3(256), 0, stream, dmod, MODW, W, D, R, KC, dSc);
+    }
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
