@@ -179,9 +179,10 @@ def test_full_size_gradients_match_autograd():
     assert max(worst.values()) < 1e-2, worst
 
 
-@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (1, 5)])
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (1, 5), (5, 5)])
 def test_gradients_other_windows(B, T):
-    """Windows of 1, 2 and 5 frames (the temporal attention backward is specialised per window length; T = 1 has one key per query)."""
+    """Windows of 1, 2 and 5 frames (the temporal attention backward is specialised per window length; T = 1 has one key per query);
+    B = 5, T = 5 gives 25 conditioning rows: two ragged 16-row tiles in the fp32-MFMA adaLN backward kernels."""
     from oracle import ref_cpu as O
     m, sd, cfg, x, t, a, vt = _setup(B=B, T=T)
     _, v_ref, grads = O.dit_loss_and_grads(sd, cfg, x, t, a, vt)
