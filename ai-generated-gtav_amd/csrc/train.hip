@@ -430,17 +430,19 @@ __global__ __launch_bounds__(NT) void attn_spatial_bwd_kernel(const f16* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The same on the matrix cores (the default; the VALU kernel above stays for the experiments build's A/B runs).  One block of three
-// waves per (frame, head); Q, K, V, dO as fp16 rows in LDS (pitch 72 halves), 16 x 16 tiles (S = 144: 9 tiles).
-//   pre-pass (wave w: query tiles w, w + 3, ...): S_i = Q_i K^T and dP_i = dO_i V^T for the whole key row (v_mfma_f32_16x16x32_f16: lane
-//     (g = l / 16, c = l % 16) holds rows 4 g + r, column c), row statistics over the 16 lanes of a group -> lse2[q] = max c + log2 sum
-//     (c = log2(e) / 8) and Dq[q] = sum_j P dP to LDS;
-//   main (wave w: key tiles j = w, w + 3, ...; dK_j / dV_j in registers): for every query tile i recompute S_ij, dP_ij (2 + 2 MFMAs), P =
-//     exp2(S c - lse2), dS = P (dP - Dq) / 8.  The accumulator layout of a 16 x 16 tile IS the A-operand layout of its transpose for the
-//     K = 16 MFMA (lane: row c, k = 4 g + r), so dV_j += P^T dO_i and dK_j += dS^T Q_i take P / dS straight from registers; their B
-//     operands (4 query rows x 16 features, a column gather) are transposing LDS reads (ds_read_b64_tr_b16) of the row-major images.
-//     dQ_i^T += K_j^T dS^T needs dS with queries along lanes: the wave writes the tile to a private [key][query] scratch (8 bytes per lane)
-//     and reads it back transposed; dQ accumulates in an fp32 LDS image through ds_add_f32 (three waves add to every row).
+// The same on the matrix cores (the default; the VALU kernel above stays for the experiments build's A/B runs).  One block of nine
+// waves (one query / key tile each at S = 144) per (frame, head); Q, K, V, dO as fp16 rows in LDS (pitch 72 halves), 16 x 16 tiles (S = 144: 9 tiles).
+//   query-tile pass (wave w: query tiles w, w + 9, ...): S_i = Q_i K^T and dP_i = dO_i V^T for the whole key row (v_mfma_f32_16x16x32_f16:
+//     lane (g = l / 16, c = l % 16) holds rows 4 g + r, column c), row statistics over the 16 lanes of a group -> lse2[q] = max c + log2 sum
+//     (c = log2(e) / 8) and Dq[q] = sum_j P dP to LDS; then, with the row still in registers, dS_ij = P (dP - Dq) / 8 per key tile and
+//     dQ_i^T += K_j^T dS_ij^T with the K = 16 MFMA: K_j^T is a transposing LDS read (ds_read_b64_tr_b16) of the row-major K image, dS^T goes
+//     through a private [key][query] scratch (8 bytes per lane out, one transposing read back).  One wave owns the whole dQ row: no
+//     cross-wave accumulation (a first version added dQ tiles from the key-tile pass into an fp32 LDS image with ds_add_f32: 650 us per
+//     launch, 500 of them in the atomics);
+//   key-tile pass (wave w: key tiles j = w, w + 9, ...; dK_j / dV_j in registers): for every query tile i recompute S_ij, dP_ij (2 + 2
+//     MFMAs), P = exp2(S c - lse2), dS.  The accumulator layout of a 16 x 16 tile IS the A-operand layout of its transpose for the K = 16
+//     MFMA (lane: row c, k = 4 g + r), so dV_j += P^T dO_i and dK_j += dS^T Q_i take P / dS straight from registers; their B operands (4
+//     query rows x 16 features, a column gather) are transposing LDS reads of the row-major dO / Q images;
 //   epilogue: RoPE^T (the transpose of a rotation is the rotation by the negative angle), dK_j / dV_j into the LDS rows of K_j / V_j (no other
 //     wave reads them), dQ from the fp32 image, then 16-byte stores into the tile-major [M][3 D] gradient of the to_qkv output.
 // fp16 rounding of P and dS (the MFMA operands) is the only arithmetic difference to the VALU kernel.
@@ -449,7 +451,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x4 lds_read_tr(const f16* p) {   // lane 4 q + p' of a 16-lane group passes row q, columns 4 p' ..; lane i gets column i of the 4 rows
     return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
 }
-constexpr int ABM_LP = 72, ABM_DQP = 68, ABM_NW = 3, ABM_MAXT = AB_MAXS / 16;
+constexpr int ABM_LP = 72, ABM_DQP = 68, ABM_NW = 9, ABM_MAXT = AB_MAXS / 16;   // 9 waves: one query / key tile each at S = 144 (3 waves: 170 us per launch of 1280 items, 9 waves: 99 us)
 template <int DBG>   // experiments: 1 = no dQ atomics, 2 = no K = 16 MFMAs / transposed reads, 4 = no RoPE / LDS write-back of dK, dV (timing only)
 __global__ __launch_bounds__(64 * ABM_NW) void attn_spatial_bwd_mfma_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                                             const f16* __restrict__ dO, int heads, int S, int D,
