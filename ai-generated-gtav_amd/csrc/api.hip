@@ -1016,6 +1016,12 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     };
     // dW[n][k] += sum_m dY[m][n] X[m][k]: both operands transposed to [.][Mp] (tokens are the contraction), accumulating epilogue
     auto gemm_dw = [&](const f16* dY, int N, const f16* X, int K, float* grad) -> int {
+        if (gemm_tn_pays(N, K, M)) {   // contraction over the rows of the tile-major operands themselves (transposing LDS reads): no transposes
+            GemmParams q;
+            memset(&q, 0, sizeof(q));
+            q.X = dY; q.ldx = N; q.W = X; q.M = N; q.N = K; q.K = M; q.out = grad; q.ldo = K;
+            return launch_gemm_tn(q, s);
+        }
         RET_IF(launch_transpose_tiled_f16(dY, M, N, tr.tA, s));
         RET_IF(launch_transpose_tiled_f16(X, M, K, tr.tB, s));
         GemmParams q;
@@ -1515,6 +1521,12 @@ int gtav_op_attn_spatial_bwd(const void* q, const void* k, const void* vt, const
                              const float* rope_cs, void* dqkv, void* stream) {
     return launch_attn_spatial_bwd((const f16*)q, (const f16*)k, (const f16*)vt, (const f16*)d_o, NB, heads, S, heads * 64, rope_cs, (f16*)dqkv, nullptr,
                                    (hipStream_t)stream);
+}
+int gtav_op_gemm_tn(const void* x, const void* w, int32_t M, int32_t N, int32_t K, float* out, int32_t ldo, void* stream) {
+    GemmParams q;
+    memset(&q, 0, sizeof(q));
+    q.X = (const f16*)x; q.ldx = M; q.W = (const f16*)w; q.M = M; q.N = N; q.K = K; q.out = out; q.ldo = ldo;
+    return launch_gemm_tn(q, (hipStream_t)stream);
 }
 int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t N, int32_t K,
                            int32_t splitk, float* parts, float* resid, const float* gate, int32_t gate_stride,

@@ -67,6 +67,12 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 // tperm order, W = head-major to_qkv weight; writes the temporal K/V cache (p.k) and the attention output (p.out, f16 tile-major).
 bool gemm_qkvt_attn_ok(int M, int D, int S, int Tq, int t0);
 int launch_gemm_qkvt_attn(const GemmParams& p, hipStream_t stream);
+// Weight-gradient GEMM without operand transposes: out[m][n] (f32 row-major, ldo) += sum_t X[t][m] W[t][n]; X, W tile-major fp16
+// [tokens][features] (p.M = X features, p.N = W features, p.K = tokens).  M, N multiples of 128, K of 64 (gemm_tn_ok); gemm_tn_pays: also at
+// least 128 output tiles (where it beats two operand transposes + the NT kernel).
+bool gemm_tn_ok(int M, int N, int K);
+bool gemm_tn_pays(int M, int N, int K);
+int launch_gemm_tn(const GemmParams& p, hipStream_t stream);
 // True when launch_gemm would run this shape on the persistent ping-pong kernel (large M): residual GEMMs then use the in-place
 // EPI_RESID epilogue (hidden under the other wave group's main loop) instead of split-K slabs.
 bool gemm_pp_ok(int M, int N, int K, int epi);

@@ -947,6 +947,136 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 :
     bs.end(p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// "TN" GEMM for weight gradients:  out[m][n] += sum_t Xop[t][m] * Wop[t][n]  — both operands are the ordinary tile-major activations
+// [tokens][features]; the contraction runs over their ROWS.  (The NT kernels above need K contiguous, so dW = dY^T X used to transpose both
+// operands first: 260 transposes = 4.5 ms of a 63 ms training step.)  128 x 128 output tile, 8 waves of 64 x 32, K-step = 64 tokens:
+//   * a stage is the 64-token slab of the two 64-feature column tiles of each operand: four contiguous 8 KiB runs of the tile-major image
+//     (8 pieces of 8 rows each), copied verbatim by LDS-DMA like every other fill — the LDS image is [64 tokens][64 features] per column
+//     tile with the 16-byte chunks XOR-swizzled by (row & 7);
+//   * an MFMA fragment needs 8 consecutive TOKENS of one feature per lane — a column of that image: two transposing LDS reads
+//     (ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group passes the address of token row q, features 4 p .. 4 p + 3, and receives its own
+//     feature's four tokens) per fragment instead of one ds_read_b128; same bytes through the LDS, twice the read instructions.
+// p.X = Xop (its features are the output rows m: the "token" role of the epilogue), p.W = Wop (features = output columns n), p.K = tokens.
+// ---------------------------------------------------------------------------------------------------------------------
+// The transposing reads are inline asm: behind the builtin hipcc's wait-count pass assumes they may alias the LDS-DMA fills in flight and puts
+// an s_waitcnt vmcnt(0) in front of the first read of every K-step — the ring's prefetch was gone and the K-step cost a whole fill round trip
+// (1.05 us against 0.6 us).  With asm the LDS waits are counted by hand: LDS returns in order, so lgkmcnt(N) retires all but the newest N reads.
+typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_read_tr_asm(u32x2_& dst, unsigned lds_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(lds_addr));
+}
+union TnFrag { f16x8 h; u32x2_ u[2]; };
+template <int NS>
+__global__ __launch_bounds__(512, 1) void gemm_tn_kernel(GemmParams p) {
+    // stage: 32 pieces of 8 token rows x 64 features [W ct0 | W ct1 | X ct0 | X ct1], each piece at a stride of 1088 bytes: the 64 bytes of
+    // padding shift consecutive pieces by 16 banks, so the two 16-lane groups of a transposing read's 32-lane half (token rows 8 apart =
+    // adjacent pieces, same swizzle) do not meet on the same banks (with a 1024-byte stride every such read was 2-way conflicted and the
+    // K-step LDS-bound: 195 us per 4096 x 1024 x 11520 launch against 110 us for transposes + the NT kernel)
+    constexpr int WM = 4, FJ = 2, HALF = 8192, PSTR = 1088, STAGE_BYTES = 32 * PSTR, G = 4;
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE_BYTES];
+    BlockStamps bs;
+    bs.begin(p);
+    int n0, m0, ks, kt0, nkt;
+    tile_map<false, 128, 128>(p, n0, m0, ks, kt0, nkt);   // nkt = p.K / 64 token steps
+    f32x4 acc[4][FJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wm = w >> 1;
+    // ---- fills: wave w copies pieces 4 w .. 4 w + 3 of the stage's 32 (piece q: operand q / 16, column tile (q / 8) & 1, 8-row piece q & 7) ----
+    const int nct_w = p.N >> 6, nct_x = p.M >> 6;        // 64-feature column tiles per row tile of each operand
+    const char* src[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int q = 4 * w + i, isx = q >> 4, ct = (q >> 3) & 1, pc = q & 7;
+        const char* base = (const char*)(isx ? (const void*)p.X : (const void*)p.W);
+        const int ct0 = ((isx ? m0 : n0) >> 6) + ct, nct = isx ? nct_x : nct_w;
+        src[i] = base + (size_t)ct0 * TILE_BYTES + pc * 1024 + lane * 16 + (size_t)0 * nct;
+    }
+    auto stage = [&](int t) {   // token step t: rows 64 t .. 64 t + 63 = row tile t / 2, pieces 8 (t & 1) ..
+        char* base = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int q = 4 * w + i, isx = q >> 4;
+            const size_t rowtile = (size_t)(t >> 1) * (isx ? nct_x : nct_w) * TILE_BYTES + (size_t)(t & 1) * HALF;
+            glds16(src[i] + rowtile, base + q * PSTR);
+        }
+    };
+    // ---- transposing fragment reads: lane (li = 4 q + pp, group g): token row 32 s + 8 g + 4 h + q, features 16 tile + 4 pp .. ----
+    const int li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+    int woff[2][2][4], xoff[2][2][FJ];                   // [half-step s][h][tile]
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int row = 32 * sh + 8 * g + 4 * hh + qq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = 2 * i + (pp >> 1);        // 16-byte chunk of the 64-feature row: features 16 i + 4 pp ..
+                woff[sh][hh][i] = (wn * 8 + (row >> 3)) * PSTR + (row & 7) * 128 + ((ch ^ (row & 7)) << 4) + (pp & 1) * 8;
+            }
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int f = 32 * (wm & 1) + 16 * j + 4 * pp, ch = f >> 3;
+                xoff[sh][hh][j] = ((2 + (wm >> 1)) * 8 + (row >> 3)) * PSTR + (row & 7) * 128 + ((ch ^ (row & 7)) << 4) + (pp & 1) * 8;
+            }
+        }
+    const bool late = w >= 4;
+    const int npro = nkt < NS - 1 ? nkt : NS - 1;
+    for (int t = 0; t < npro; ++t) stage(t);
+    for (int t = 0; t < nkt; ++t) {
+        const int rem = nkt - 1 - t;
+        kstep_sync_ring<NS, G>(rem);
+        if (t == 0) GTAV_STAMP(bs.t[1]);
+        const bool refill = t + NS - 1 < nkt;
+        if (refill && !late) stage(t + NS - 1);
+        const unsigned b = lds_offset(smem) + (unsigned)(t % NS) * STAGE_BYTES;
+        TnFrag wf[2][4], xf[2][FJ];
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {   // 12 reads per half-step, all 24 issued up front
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lds_read_tr_asm(wf[sh][i].u[0], b + woff[sh][0][i]);
+                lds_read_tr_asm(wf[sh][i].u[1], b + woff[sh][1][i]);
+            }
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                lds_read_tr_asm(xf[sh][j].u[0], b + xoff[sh][0][j]);
+                lds_read_tr_asm(xf[sh][j].u[1], b + xoff[sh][1][j]);
+            }
+        }
+        // the waits name the fragments they retire as in / out operands, so no MFMA that reads them can be scheduled above its wait
+#define GTAV_TN_FRAGS(sh) "+v"(wf[sh][0].u[0]), "+v"(wf[sh][0].u[1]), "+v"(wf[sh][1].u[0]), "+v"(wf[sh][1].u[1]), "+v"(wf[sh][2].u[0]), "+v"(wf[sh][2].u[1]), \
+                          "+v"(wf[sh][3].u[0]), "+v"(wf[sh][3].u[1]), "+v"(xf[sh][0].u[0]), "+v"(xf[sh][0].u[1]), "+v"(xf[sh][1].u[0]), "+v"(xf[sh][1].u[1])
+        static_assert(FJ == 2, "the wait statements list the fragments of FJ == 2");
+        asm volatile("s_waitcnt lgkmcnt(12)" : GTAV_TN_FRAGS(0));   // LDS returns in order: the first half-step's 12 reads have landed
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][i].h, xf[0][j].h, acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : GTAV_TN_FRAGS(1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][i].h, xf[1][j].h, acc[i][j], 0, 0, 0);
+#undef GTAV_TN_FRAGS
+        if (refill && late) {
+            asm volatile("" ::: "memory");
+            stage(t + NS - 1);
+        }
+    }
+    GTAV_STAMP(bs.t[2]);
+    f32x4 pbias[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    epilogue<EPI_RESID, 4, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, false);
+    bs.end(p);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES + (EPI == EPI_QKV ? 2048 : 0)];   // + qkv_staged's token table
@@ -1813,8 +1943,13 @@ static int choose_gn(int M, int N, int K, int tmb, int tnb, int splitk) {
     };
     int best = 1;
     double best_cost = 1e300;
+    // the 2 MiB cap protects W panels that must SURVIVE in L2 while further m-tiles of the group sweep past; a grid that is resident all at
+    // once (<= 512 block slots) has no sweep — its blocks walk K in step and share the current K window only — so the cap does not apply
+    // (weight gradients of the training step, K = 11 520 tokens: a 2.9 MB W panel forced gn = 1 = every XCD streaming ALL of the 94 MB X
+    // operand, 778 MB per launch at 7 TB/s; uncapped gn = 4: 282 MB)
+    const bool one_round = (long long)cdiv(M, tmb) * tiles_n * (splitk > 0 ? splitk : 1) <= 512;
     for (int gn = 1; gn <= tiles_n; ++gn) {
-        if (gn > 1 && gn * wpanel > 2.0 * 1024 * 1024) break;
+        if (!one_round && gn > 1 && gn * wpanel > 2.0 * 1024 * 1024) break;
         const double cost = cost_of(gn);
         if (cost < best_cost * 0.999) best_cost = cost, best = gn;   // ties keep the narrower group (more XCD-local W)
     }
@@ -1823,7 +1958,6 @@ static int choose_gn(int M, int N, int K, int tmb, int tnb, int splitk) {
     // 34.1 MB per launch against 27.4 MB)
     const int gn1 = tiles_n >= 8 ? tiles_n >> 3 : 1;
     if (best_cost > 0.8 * cost_of(gn1)) best = gn1;
-    (void)tmb;
     return best;
 }
 
@@ -1870,6 +2004,8 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
     if (shape == 23) return launch_l<EPI, 4, 4, 3, 2, 2, 4>(p, splitk, stream);   // 128 x 96, 4 compute waves of 64 x 48 + 4 loader waves
     if (shape == 25) return launch_l<EPI, 5, 2, 3, 4, 2, 4>(p, splitk, stream);   // shape 20 with a 5-stage ring (140 KiB)
+    // (a 128 x 128 loader-wave tile — 8 compute waves of 32 x 64 — was 12 % faster than shape 3 back to back and equal in the training step's
+    // weight-gradient GEMMs, which are bound by the fabric traffic of their 118 MB of operands: not kept)
     // (Round 2 also measured one-block-per-CU large tiles on mainloop_g's half-K-step pipeline — 256 x 192, 192 x 192 and
     // 256 x 144 with 8 / 6 waves of 128 x 48 / 96 x 48 — and the 256 x 128 loader-wave tile, shape 21: all correct, all 5-30 %
     // SLOWER than the two-blocks-per-CU 128 x 192 tile at M = 5760 / 11 520, profiles/round2/gemm_large_tile_*.txt: without a
@@ -1959,6 +2095,29 @@ int launch_gemm_qkvt_attn(const GemmParams& p_in, hipStream_t stream) {
     return 0;
 }
 
+// out[m][n] += sum_t X[t][m] W[t][n] (gemm_tn_kernel): X tile-major [tokens][M features], W tile-major [tokens][N features], K = tokens.
+bool gemm_tn_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && K % 64 == 0; }
+// at least 128 tiles of 128 x 128: smaller grids stay on transposes + the NT kernels, which pick smaller tiles for them
+static int g_tn_enable = GTAV_ENV_INT("GTAV_GEMM_TN", 0);   // experiments build: 1 = use it for the weight gradients (A/B runs)
+bool gemm_tn_pays(int M, int N, int K) { return g_tn_enable && gemm_tn_ok(M, N, K) && (M / 128) * (N / 128) >= 128; }
+int launch_gemm_tn(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    GTAV_REQUIRE(gemm_tn_ok(p.M, p.N, p.K), "gemm_tn: M=%d, N=%d must be multiples of 128 and K=%d of 64", p.M, p.N, p.K);
+    GTAV_REQUIRE(p.out && p.ldo >= p.N && p.ldo % 4 == 0, "gemm_tn: bad output ldo=%d", p.ldo);
+    GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm_tn: operands must be 16-byte aligned");
+#ifdef GTAV_EXPERIMENTS
+    p.debug = 0;
+    p.stamps = g_stamps;
+#endif
+    p.splitk = 1;
+    p.bias = nullptr; p.gate = nullptr;
+    p.tm.gn = choose_gn(p.M, p.N, p.K, 128, 128, 1);
+    const dim3 grid((p.M / 128) * (p.N / 128));
+    GTAV_LAUNCH((gemm_tn_kernel<4>), grid, dim3(512), 0, stream, p);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
     p.debug = g_debug & (3 | 16 | 32 | 2048);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
@@ -2032,7 +2191,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
         if (t256 * 10 >= rounds * 256 * 7) wm = 7;
     }
-    int ns = g_force_stages ? g_force_stages : (wm == 12 ? 2 : wm >= 8 ? 4 : wm == 3 ? 4 : 2);
+    int ns = g_force_stages ? g_force_stages : (wm == 12 ? 2 : wm >= 8 ? 4 : wm == 3 ? 4 : 2);   // (shapes 20+ carry their ring depth in the template)
     switch (epi) {
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);

@@ -276,6 +276,10 @@ int gtav_op_gemm_qkvt_attn(const void* x_tperm_f16_dev, const void* w_hm_f16_dev
  * logical [NB S][3 heads 64] (dq | dk | dv, dq / dk rotated back through the RoPE).  S % 16 == 0, S <= 160. */
 int gtav_op_attn_spatial_bwd(const void* q_dev, const void* k_dev, const void* vt_dev, const void* d_o_dev, int32_t NB, int32_t heads,
                              int32_t S, const float* rope_cs_dev, void* dqkv_dev, void* stream);
+/* Weight-gradient GEMM (train_dit.py:680 accelerator.backward, the dW = dY^T X of every Linear): out[m][n] += sum_t x[t][m] * w[t][n] with
+ * both operands the ordinary tile-major fp16 activations [K tokens][features] (x: M features, w: N features); out f32 row-major [M][ldo],
+ * accumulated in place.  M, N multiples of 128, K a multiple of 64. */
+int gtav_op_gemm_tn(const void* x_f16_dev, const void* w_f16_dev, int32_t M, int32_t N, int32_t K, float* out_dev, int32_t ldo, void* stream);
 /* Residual GEMM as the model runs it: split-K partial slabs (parts: splitk*M*N floats; splitk 0 = heuristic) followed by
  * the LayerNorm kernel that reduces them: resid += gate * (sum parts + bias); out = LN(resid) * (1 + scale + 1e-6) + shift. */
 int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,

@@ -305,6 +305,26 @@ def test_attention_spatial_backward_mfma(NB, heads, S):
         assert e < 2e-3, (name, e)
 
 
+@pytest.mark.parametrize("T,M,N", [(320, 1024, 2048), (64, 128, 128), (1152, 384, 256)])
+def test_gemm_tn_weight_gradient(T, M, N):
+    """gemm_tn_kernel: out[m][n] += sum_t x[t][m] w[t][n] on the tile-major [tokens][features] operands (transposing LDS reads; the dW of every
+    Linear in the training step) against fp32 math on the same fp16 values, accumulating into a non-zero output, twice (bitwise equal)."""
+    lib = L.load()
+    x = _rand(T, M, seed=1).half()
+    w = _rand(T, N, seed=2).half()
+    base = _rand(M, N, seed=3)
+    xd, wd = to_tiled_f16(x), to_tiled_f16(w)
+    outs = []
+    for _ in range(2):
+        out = base.to(dev()).clone()
+        L.check(lib.gtav_op_gemm_tn(xd.data_ptr(), wd.data_ptr(), M, N, T, out.data_ptr(), N, stream()))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    ref = base + x.float().t() @ w.float()
+    assert rel_l2(outs[0], ref) < 2e-5
+
+
 def test_ddim_update_matches_reference_formula():
     rows, n = 6, 1000
     x, v = _rand(rows, n, seed=1), _rand(rows, n, seed=2)
