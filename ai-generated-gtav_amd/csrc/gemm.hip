@@ -542,6 +542,33 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
         } else if (!GTAV_DBG(p, 2)) {
             mm(wB, xB);
         }
+    } else if (NS == 2 && !GTAV_DBG(p, 8192)) {
+        // Two-stage ring (large M, two blocks per CU).  A wave that issues LDS-DMA is held until the address pipe takes the instruction; with the
+        // whole block's 40 KiB issued in one burst right after the barrier, every wave queued for up to 640 cycles BEFORE its fragment reads
+        // and MFMAs (alone on a CU a block ran its K-step in 1 590 cycles for 768 cycles of MFMA issue, tools/gemm_stamps.py).  Here the G fills
+        // of a wave are spread between its MFMAs (sched_group_barrier: 4 MFMAs, 1 fill, ...): the queue never backs up, the fill costs issue
+        // slots inside the MFMA shadows.  The last K-step has no refill and is peeled so that the loop body is branch-free.
+        constexpr int NMF = 2 * FI * FJ, PERF = NMF / (G + 1) > 0 ? NMF / (G + 1) : 1;
+        for (int t = 0; t + 1 < nkt; ++t) {
+            sync(t);
+            f16x8 wf[2][FI], xf[2][FJ];
+            rd(t, wf, xf);
+            if (!GTAV_DBG(p, 1)) stage(t + 1);
+            mm(wf, xf);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PERF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            if constexpr (NMF > PERF * G) __builtin_amdgcn_sched_group_barrier(0x008, NMF - PERF * G, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            sync(nkt - 1);
+            f16x8 wf[2][FI], xf[2][FJ];
+            rd(nkt - 1, wf, xf);
+            mm(wf, xf);
+        }
     } else {
         for (int t = 0; t < nkt; ++t) {
             sync(t);
@@ -2120,7 +2147,7 @@ int launch_gemm_tn(const GemmParams& p_in, hipStream_t stream) {
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_debug & (3 | 16 | 32 | 2048);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
+    p.debug = g_debug & (3 | 16 | 32 | 2048 | 8192);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
     p.stamps = nullptr;
 #ifdef GTAV_EXPERIMENTS
     p.stamps = g_stamps;            // the tool sizes the buffer for the largest grid it launches (g_stamp_blocks)
