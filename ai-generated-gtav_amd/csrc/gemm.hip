@@ -800,7 +800,16 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                     char* dst = smem + ((nl >> 6) * TM + ml) * 128 + (((c >> 3) ^ (ml & 7)) << 4) + (c & 7) * 2;
                     const f32x4 v = acc[i][j] + bv;
                     if constexpr (EPI == EPI_GELU_TANH)
-                        *(uint2*)dst = pack4(amax, gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+                        {
+                            if (GTAV_DBG(p, 16384)) {   // experiments build: the scalar form, for A/B runs
+                                *(uint2*)dst = pack4(amax, gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
+                            } else {
+                                const float xin[4] = {v[0], v[1], v[2], v[3]};
+                                float yo[4];
+                                gelu_tanh_f4(xin, yo);
+                                *(uint2*)dst = pack4(amax, yo[0], yo[1], yo[2], yo[3]);
+                            }
+                        }
                     else if constexpr (EPI == EPI_GELU_ERF)
                         *(uint2*)dst = pack4(amax, gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
                     else
@@ -2147,7 +2156,7 @@ int launch_gemm_tn(const GemmParams& p_in, hipStream_t stream) {
 
 int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     GemmParams p = p_in;
-    p.debug = g_debug & (3 | 16 | 32 | 2048 | 8192);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
+    p.debug = g_debug & (3 | 16 | 32 | 2048 | 8192 | 16384);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
     p.stamps = nullptr;
 #ifdef GTAV_EXPERIMENTS
     p.stamps = g_stamps;            // the tool sizes the buffer for the largest grid it launches (g_stamp_blocks)
