@@ -257,6 +257,10 @@ struct gtav_dit {
     int* frame_idx = nullptr;   // [maxB * maxT]
     StepParams* step_dev = nullptr;
     int* mod_rows_dev = nullptr;   // [maxB * maxT] rows of the per-frame conditioning table used by the current step
+    // prepared steps read the modulation from mod_cur [maxB * maxT][MODW]: slot i holds row mod_rows_dev[i] of the table (gathered per step,
+    // only the slots whose row changed: mod_last / mod_changed), so the kernels index it by frame slot without the row indirection
+    float* mod_cur = nullptr;
+    int *mod_last = nullptr, *mod_changed = nullptr;
     int* t_steps_dev = nullptr;    // [1024]
     struct { bool valid = false; int B = 0, F = 0, start = 0, cur = 0, n_steps = 0; const float* actions = nullptr; } prepared;
     // which window the per-layer temporal K/V caches currently describe: written by a full-window (mode 0) sampler step,
@@ -510,7 +514,8 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     const size_t R = h->max_rows;
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
     A_(a.alloc_t(&h->err_flag, 4)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
-    A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
+    A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT));
+    A_(a.alloc_t(&h->mod_cur, (size_t)h->maxB * h->maxT * h->MODW)); A_(a.alloc_t(&h->mod_last, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->mod_changed, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
     h->use_graph = GTAV_ENV_INT("GTAV_GRAPH", 1) != 0;   // the shipped library reads no environment: gtav_dit_set_graph() is the switch
 #undef A_
     if (rc) {
@@ -617,7 +622,7 @@ static int denoise_step_body(gtav_dit* h, float* x, int B, int F, int T, const f
     const size_t fsz = (size_t)h->C * h->H * h->W;
     const int Tq = mode == 1 ? 1 : T, t0 = mode == 1 ? T - 1 : 0;
     if (!prepared) RET_IF(dit_cond(h, nullptr, B * Tq, Tq, h->step_dev, mode == 1, actions, (int64_t)F * h->A, h->A, s));
-    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, h->mod, prepared ? h->mod_rows_dev : nullptr, h->vout, s));
+    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, prepared ? h->mod_cur : h->mod, nullptr, h->vout, s));
     // DDIM update of frame `cur` (train_dit.py:110-125, generate.py:220)
     const float* vlast = h->vout + (size_t)(Tq - 1) * fsz;
     RET_IF(launch_ddim_update_step(x, F, vlast, (size_t)Tq * fsz, B, (int)fsz, h->step_dev, s));
@@ -645,6 +650,7 @@ int gtav_dit_prepare_frame(gtav_dit* h, int32_t B, int32_t F, int32_t start, int
     RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, h->HC, ldhc, rows, h->D, 256, 1, s));
     RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, h->Sc, h->D, rows, h->D, ldhc, 1, s));
     RET_IF(launch_skinny_f32(h->Sc, h->D, h->w_ada, h->b_ada, h->mod, h->MODW, rows, h->MODW, h->D, 0, s));
+    GTAV_CHECK_HIP(hipMemsetAsync(h->mod_last, 0xFF, (size_t)h->maxB * h->maxT * sizeof(int), s));   // the table changed: every slot of mod_cur is stale
     h->prepared.valid = true; h->prepared.B = B; h->prepared.F = F; h->prepared.start = start; h->prepared.cur = cur;
     h->prepared.n_steps = n_steps; h->prepared.actions = actions;
     return 0;
@@ -679,7 +685,9 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
     StepParams sp;
     sp.first = start; sp.cur = cur; sp.t_ctx = t_ctx; sp.t_cur = t_cur; sp.is_final = is_final != 0;
     sp.alpha_t = h->ac_host[t_cur]; sp.alpha_next = h->ac_host[t_next]; sp.cond_step = cond_step;
-    RET_IF(launch_step_setup(h->step_dev, sp, h->frame_idx, h->mod_rows_dev, B, mode == 1 ? 1 : T, T, F, mode == 1, s));
+    RET_IF(launch_step_setup(h->step_dev, sp, h->frame_idx, h->mod_rows_dev, prepared ? h->mod_last : nullptr, h->mod_changed, B, mode == 1 ? 1 : T, T, F,
+                             mode == 1, s));
+    if (prepared) RET_IF(launch_gather_rows(h->mod, h->mod_rows_dev, h->mod_changed, h->mod_cur, B * (mode == 1 ? 1 : T), h->MODW, s));
     if (!h->use_graph || h->prof.on) return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
 
     // hipGraph path: the first step of a new (shape, buffers) key runs eagerly (warm-up: lazy module load, function

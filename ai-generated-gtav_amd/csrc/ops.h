@@ -25,8 +25,10 @@ struct StepParams {
 // One launch ahead of the (possibly graph-replayed) step: *dst = v, frame_idx[b*Tq+tl] = b*F + first + tl
 // (first = use_cur ? v.cur : v.first) and, when v.cond_step >= 0, the conditioning-table row of every processed frame:
 // context frame (b, tl < T-1) -> b*(T-1)+tl, frame `cur` of sample b -> B*(T-1) + cond_step*B + b.
-int launch_step_setup(StepParams* dst, const StepParams& v, int* frame_idx, int* mod_rows, int B, int Tq, int T, int F,
+int launch_step_setup(StepParams* dst, const StepParams& v, int* frame_idx, int* mod_rows, int* last_rows, int* changed, int B, int Tq, int T, int F,
                       int use_cur, hipStream_t stream);
+// current-step conditioning table: cur[slot] <- table[rows[slot]] (W floats) for the slots step_setup flagged in `changed`
+int launch_gather_rows(const float* table, const int* rows, const int* changed, float* cur, int slots, int W, hipStream_t stream);
 // Conditioning inputs for a whole generated frame (rows laid out as above, n_steps row sets for frame `cur`).
 int launch_cond_inputs_frame(int rows, int B, int T, int F, int start, int cur, int t_ctx, const int* t_steps, const float* sincos,
                              float* E, const float* actions, int A, float* HC, int ldhc, int D, int Apad, int* err_flag,
