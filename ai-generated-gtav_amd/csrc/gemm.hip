@@ -647,8 +647,31 @@ __device__ __forceinline__ void tile_map_fast(const GemmParams& p, int& n0, int&
 // stores — a whole 128-byte head row of one token (or 8 consecutive tokens of one V^T row) per 8 lanes — instead of 8-byte
 // stores scattered over 16 rows per wave-instruction.  tab[] holds the per-token destination coordinates (one integer
 // division per token instead of one per lane and token).
-template <int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
-__device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, bool tr) {
+// The (cos, sin) values of the RoPE rotation a compute wave will apply in qkv_staged, fetched BEFORE the main loop (loader-wave kernels:
+// behind the first fills, like the bias): in the epilogue those loads were a memory round trip at the head of every QKV launch's tail.
+template <int FI, int FJ, int WM, int WN, int WOFF>
+__device__ __forceinline__ void prefetch_rope(const GemmParams& p, int n0, int m0, f32x4 (&prope)[FI][FJ]) {
+    const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6) - WOFF;
+    const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
+    const bool spatial = p.qkv_mode == QKV_SPATIAL;
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+        int m = m0 + 16 * FJ * wm + 16 * j + li;
+        m = m < p.M ? m : p.M - 1;
+        const int fr = m / p.S;
+        const int pos = spatial ? m - fr * p.S : p.t0 + fr % p.Tq;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
+            prope[i][j] = f32x4{1.f, 0.f, 1.f, 0.f};
+            if (w >= 0 && w < WN * WM && n < 2 * p.D) prope[i][j] = *(const f32x4*)(p.rope_cs + pos * 64 + (n & 63));
+        }
+    }
+}
+
+template <int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false>   // PRE: prope holds the prefetched (cos, sin) values (registers, static indexing)
+__device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, bool tr,
+                                           const f32x4 (&prope)[FI][FJ]) {
     constexpr int TM = WM * 16 * FJ, TNB = 16 * FI * WN;
     const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6) - WOFF;   // WOFF leading waves are loader waves (mainloop_l)
     const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
@@ -712,7 +735,9 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
                     const int ml = 16 * FJ * wm + 16 * j + li;
                     f32x4 v = acc[i][j] + bv;
                     if (rope) {
-                        const f32x4 cs = *(const f32x4*)(p.rope_cs + pos[j] * 64 + d);
+                        f32x4 cs;
+                        if constexpr (PRE) cs = prope[i][j];
+                        else cs = *(const f32x4*)(p.rope_cs + pos[j] * 64 + d);
                         v = rope4(v, cs);
                     }
                     char* dst = smem + ml * PN + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
@@ -773,8 +798,9 @@ __device__ __forceinline__ void prefetch_bias(const GemmParams& p, int n0, f32x4
     }
 }
 
-template <int EPI, int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
-__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr) {
+template <int EPI, int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr,
+                                         const f32x4 (&prope)[FI][FJ]) {
     constexpr int TM = WM * 16 * FJ;
     constexpr int CT = 16 * FI * WN / 64;           // 64-feature sub-tiles per block tile row
     const int lane = threadIdx.x & 63, wraw = threadIdx.x >> 6, w = wraw - WOFF;   // WOFF leading waves are loader waves (mainloop_l)
@@ -836,7 +862,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     if constexpr (EPI == EPI_QKV) {
         // block-uniform: 8-token groups of a V^T row must not straddle attention items
         if (!GTAV_DBG(p, 16) && (p.qkv_mode == QKV_TEMPORAL || p.S % 8 == 0)) {
-            qkv_staged<FI, FJ, WM, WN, WOFF>(p, acc, pbias, smem, n0, m0, tr);
+            qkv_staged<FI, FJ, WM, WN, WOFF, PRE>(p, acc, pbias, smem, n0, m0, tr, prope);
             return;
         }
     }
@@ -951,6 +977,11 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         }
     }
     if constexpr (EPI == EPI_F16 || EPI == EPI_QKV) sat_report(amax, p.err_flag);
+}
+
+template <int EPI, int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr) {
+    epilogue<EPI, FI, FJ, WM, WN, WOFF, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc);   // (the last argument is not read without PRE)
 }
 
 template <int EPI, int NS, int WM, int FJ>
@@ -1402,16 +1433,30 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
         for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool tr = false;
     f32x4 pbias[FI];
-    auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
-    if constexpr (EPI == EPI_QKV) {
+    if constexpr (EPI == EPI_QKV && FI * FJ <= 6) {   // small wave tiles: the RoPE values of the epilogue are fetched before the main loop (24 registers)
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+        f32x4 prope[FI][FJ];
+        auto pfq = [&]() {
+            prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias);
+            prefetch_rope<FI, FJ, WM, WN, NL>(p, n0, m0, prope);
+        };
+        if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pfq);
+        else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pfq);
+        GTAV_STAMP(bs.t[2]);
+        epilogue<EPI, FI, FJ, WM, WN, NL, true>(p, acc, pbias, smem, n0, m0, ks, tr, prope);
+    } else if constexpr (EPI == EPI_QKV) {
+        tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
         if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        GTAV_STAMP(bs.t[2]);
+        epilogue<EPI, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
     } else {
+        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
         mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        GTAV_STAMP(bs.t[2]);
+        epilogue<EPI, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
     }
-    GTAV_STAMP(bs.t[2]);
-    epilogue<EPI, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
 
