@@ -142,6 +142,7 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         b = p1;
     }
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, av = v, bv = v;
+    const float kshift = xr[0];   // the shift of the one-pass statistics below (same cache line as thread 0's own load)
     if (act) {
         v = *(const f32x4*)(xr + c);
         av = *(const f32x4*)(a + c);
@@ -185,23 +186,23 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         if (pd.flags & 1) store16_sc1(xw, v);
         else *(f32x4*)xw = v;
     }
-    float s = wave_sum_dpp((v[0] + v[1]) + (v[2] + v[3]));
-    if (lane == 0) red[wid] = s;
+    // Row statistics in ONE block-wide reduction: sums of (v - K) and (v - K)^2 with the shift K = the row's first residual element (a sample
+    // of the row, so |mean - K| is of the order of the standard deviation and E[(v-K)^2] - E[v-K]^2 does not cancel), reduced side by side.
+    // The two-pass form (mean, then centred squares) cost a second wave reduction + LDS exchange + barrier on the critical path of a
+    // latency-bound launch (65 per forward).
+    const float a0 = act ? v[0] - kshift : 0.f, a1 = act ? v[1] - kshift : 0.f, a2 = act ? v[2] - kshift : 0.f, a3 = act ? v[3] - kshift : 0.f;
+    const float s1 = wave_sum_dpp((a0 + a1) + (a2 + a3));
+    const float s2 = wave_sum_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
+    if (lane == 0) { red[wid] = s1; red[8 + wid] = s2; }
     __syncthreads();
-    float tot = 0.f;
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tot += i < nw ? red[i] : 0.f;     // red[] is read with two ds_read_b128, not a counted loop
-    const float mean = tot / (float)D;
-    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-    float q = wave_sum_dpp(act ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f);
-    if (lane == 0) red[8 + wid] = q;
-    __syncthreads();
-    float tq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tq += i < nw ? red[8 + i] : 0.f;
-    const float rstd = 1.0f / sqrtf(tq / (float)D + 1e-6f);
+    for (int i = 0; i < 8; ++i) { t1 += i < nw ? red[i] : 0.f; t2 += i < nw ? red[8 + i] : 0.f; }   // red[] is read with ds_read_b128s, not a counted loop
+    const float m1 = t1 / (float)D, mean = kshift + m1;
+    const float var = fmaxf(t2 / (float)D - m1 * m1, 0.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
     if (!act) return;
-    const float dd[4] = {d0, d1, d2, d3};
+    const float dd[4] = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
     float yv[4], amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
