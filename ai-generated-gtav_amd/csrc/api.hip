@@ -1,6 +1,7 @@
 // C-ABI of gtav_amd (see include/gtav_amd.h): handles own repacked weights + workspace in HBM and
 // enqueue the kernel sequence of each reference entry point on the caller's stream.
 #include "../../include/gtav_amd.h"
+#include "../../include/gtav_amd_testing.h"
 #include "ops.h"
 
 #include <cmath>
@@ -262,7 +263,7 @@ struct gtav_dit {
     float* mod_cur = nullptr;
     int *mod_last = nullptr, *mod_changed = nullptr;
     int* t_steps_dev = nullptr;    // [1024]
-    struct { bool valid = false; int B = 0, F = 0, start = 0, cur = 0, n_steps = 0; const float* actions = nullptr; } prepared;
+    struct { bool valid = false, fold_tables = false; int B = 0, F = 0, start = 0, cur = 0, n_steps = 0; const float* actions = nullptr; } prepared;
     // which window the per-layer temporal K/V caches currently describe: written by a full-window (mode 0) sampler step,
     // required by a context-cached (mode 1) step, invalidated by anything else that writes the caches (gtav_dit_forward)
     struct { bool valid = false; int B = 0, F = 0, start = 0, cur = 0; const void* x = nullptr; } kvrec;
@@ -282,6 +283,21 @@ struct gtav_dit {
     // handles with training enabled keep the split path (the copies are not refreshed by the optimizer).
     bool fuse_tattn = false;
     int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
+    // ---- LayerNorm fold (gemm.h EPI_*_FOLD): the LayerNorm + modulate between a residual GEMM and its consumer runs inside the
+    // two GEMM epilogues.  Seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection.  Per-frame c1 / c2 tables for every
+    // consumer: ctab [max_rows][CTW] (built next to the modulation table, one grouped GEMM), ctab_cur [maxB * maxT][CTW] = the rows of the
+    // current sampler step (gathered with mod_cur).  Groups are ordered fc1 seams, to_qkv seams, final: a launch over the first n covers a prefix.
+    struct Fold {
+        bool ok = false;              // geometry allows it (tokens per frame % 16 == 0 and >= 64, D % 256 == 0) and the buffers exist
+        int mode = 1;                 // 0 = never, 1 = heuristic (min_m_a / min_m_b), 2 = every seam at every M (tests)
+        int min_m_a = 1 << 30, min_m_b = 1 << 30;
+        int CTW = 0, n_groups = 0, n_groups_a = 0, Rp = 0;
+        std::vector<int> col_c;       // column of seam s's c1 in a ctab row (c2 follows at + N_s): s = 2 hb (to_qkv), 2 hb + 1 (fc1), 4 L (final)
+        float *ctab = nullptr, *ctab_cur = nullptr, *stats = nullptr;
+        f16* sx = nullptr;
+        GemmGroup* groups_dev = nullptr;
+        int *gcol_dev = nullptr, *gscale_dev = nullptr;
+    } fold;
     hipStream_t cap_stream = nullptr;            // private stream the step is captured on (the caller's may be the null stream)
     ~gtav_dit() {
         for (auto& kv : graphs)
@@ -296,7 +312,7 @@ struct gtav_dit {
         bool on = false, have_fwd = false, have_actions = false;
         int B = 0, T = 0, M = 0, Mp = 0, rows = 0;
         float loss_scale = 65536.0f;
-        long step = 0;
+        float grad_div = 1.0f;              // the arena holds the sum over this many ranks (gtav_dit_set_grad_divisor)
         std::vector<Slot*> params;          // trainable slots in a fixed (sorted-by-name) order
         float* grad_arena = nullptr;        // all gradients, contiguous (one all-reduce); caller-owned when passed to train_enable
         size_t grad_count = 0;
@@ -314,6 +330,23 @@ struct gtav_dit {
     } tr;
 };
 
+// LayerNorm fold: which seams run folded at M tokens (seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection)
+static void fold_policy(const gtav_dit* h, int M, bool& fa, bool& fb) {
+    const gtav_dit::Fold& f = h->fold;
+    fa = fb = false;
+    if (!f.ok || f.mode == 0 || h->tr.on || h->fuse_tattn) return;
+    fa = f.mode == 2 || M >= f.min_m_a;
+    fb = f.mode == 2 || M >= f.min_m_b;
+}
+// c1 / c2 tables of `rows` rows of the modulation table h->mod (same row numbering): fp16 operands, ONE grouped GEMM over every needed seam
+static int dit_fold_tables(gtav_dit* h, int rows, bool fa, bool fb, hipStream_t s) {
+    if (!fa && !fb) return 0;
+    gtav_dit::Fold& f = h->fold;
+    const int ng = fb ? f.n_groups : f.n_groups_a;   // (seam B alone still builds the fc1 groups in front of it: never selected by the policy)
+    RET_IF(launch_ctab_inputs(h->mod, h->MODW, rows, round_up(rows, 128), h->D, f.gcol_dev, f.gscale_dev, ng, f.sx, (size_t)f.Rp * h->D, s));
+    return launch_gemm_grouped(f.groups_dev, ng, h->Hm > 3 * h->D ? h->Hm : 3 * h->D, rows, h->D, s);
+}
+
 static int dit_cond(gtav_dit* h, const int64_t* t64, int rows, int Tq, const StepParams* sp, int use_cur, const float* actions,
                     int64_t act_outer, int64_t act_inner, hipStream_t s) {
     GTAV_REQUIRE(rows <= h->max_rows, "conditioning rows %d exceed max_cond_rows %d", rows, h->max_rows);
@@ -323,14 +356,36 @@ static int dit_cond(gtav_dit* h, const int64_t* t64, int rows, int Tq, const Ste
     RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, h->HC, ldhc, rows, h->D, 256, 1, s));
     RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, h->Sc, h->D, rows, h->D, ldhc, 1, s));
     RET_IF(launch_skinny_f32(h->Sc, h->D, h->w_ada, h->b_ada, h->mod, h->MODW, rows, h->MODW, h->D, 0, s));
-    return 0;
+    bool fa, fb;
+    fold_policy(h, rows * h->P, fa, fb);     // one forward over these rows' frames: the LayerNorm-fold tables of the seams it will fold
+    return dit_fold_tables(h, rows, fa, fb, s);
 }
 
 // x_src: frames of C*H*W floats; frame_index (device, optional) selects the NB = B*Tq frames to process.
+// ctab: the c1 / c2 tables of the LayerNorm fold with the row numbering of `mod` (h->fold.ctab beside h->mod, h->fold.ctab_cur beside h->mod_cur).
 static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_index, int B, int Tq, int t0,
-                            const float* mod, const int* mod_rows, float* v_out, hipStream_t s) {
+                            const float* mod, const int* mod_rows, const float* ctab, float* v_out, hipStream_t s) {
     const int D = h->D, P = h->P, NB = B * Tq, M = NB * P;
     GTAV_REQUIRE(M <= h->Mmax, "forward: %d tokens exceed workspace (%d)", M, h->Mmax);
+    bool fold_a, fold_b;
+    fold_policy(h, M, fold_a, fold_b);
+    const gtav_dit::Fold& fo = h->fold;
+    // consumer side of a folded seam: X = xn holds x (1 + scale), statistics in fo.stats, tables of seam `seam`
+    auto fold_consumer = [&](GemmParams& q, int seam, int N) {
+        q.bias = nullptr;
+        q.f_P = P; q.f_rows = mod_rows; q.f_stats = fo.stats; q.f_nslot = D / 32;
+        q.f_c1 = ctab + fo.col_c[seam]; q.f_c2 = q.f_c1 + N; q.f_ldc = fo.CTW;
+    };
+    // producer side: in-place gated residual update + operand and statistics of the LayerNorm that follows (scale vectors at `next_scale`)
+    auto fold_producer = [&](int cls, const f16* X, const f16* Wt, int K, const float* bias, const float* gate, const float* next_scale) -> int {
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.X = X; q.ldx = K; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->resid; q.ldo = D; q.bias = bias; q.err_flag = h->err_flag;
+        q.gate = gate; q.gate_stride = h->MODW; q.gate_rows = mod_rows; q.rows_per_gate = P;
+        q.f_P = P; q.f_rows = mod_rows; q.f_scale = next_scale; q.f_stats_out = fo.stats; q.f_a = h->xn;
+        PROF(h, cls, s, launch_gemm(q, EPI_RESID_FOLD, s));
+        return 0;
+    };
     PROF(h, PC_OTHER, s, launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, h->err_flag, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
@@ -365,18 +420,22 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         have_pend = true;
         return 0;
     };
+    bool folded_in = false;   // the LayerNorm in front of the next to_qkv / final projection was folded into the fc2 before it (seam B)
     for (int l = 0; l < h->L; ++l) {
         for (int hf = 0; hf < 2; ++hf) {
-            const gtav_dit::Half& w = h->halves[l * 2 + hf];
-            const float* mb = mod + (size_t)(l * 2 + hf) * 6 * D;
+            const int hb = l * 2 + hf;
+            const gtav_dit::Half& w = h->halves[hb];
+            const float* mb = mod + (size_t)hb * 6 * D;
             // temporal half of a batch-1 window step: QKV projection and attention in one launch, on LayerNorm rows written in
             // (b, 16 positions, frame) tile order
             const bool fused_t = hf == 1 && h->fuse_tattn && !h->tr.on && w.w_qkv_hm && have_pend && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
             if (fused_t) { pend.tperm_T = Tq; pend.tperm_P = P; }
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
+            if (!folded_in)
+                PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
+            if (folded_in) fold_consumer(g, 2 * hb, 3 * D);
             if (fused_t) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
@@ -390,24 +449,41 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                     g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
                     g.rope_cs = h->rope_t.cs_dev;
                 }
-                PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
+                PROF(h, PC_QKV, s, launch_gemm(g, folded_in ? EPI_QKV_FOLD : EPI_QKV, s));
                 if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
                 else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             }
-            RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
-            PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
-            have_pend = false;
+            folded_in = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
-            PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
-            RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D));
+            if (fold_a) {
+                // seam A: out-proj updates the residual in place and emits fc1's operand + row statistics; fc1 normalises in its epilogue
+                RET_IF(fold_producer(PC_OUT, h->ao, w.w_out, D, w.b_out, mb + 2 * D, mb + 4 * D));
+                fold_consumer(g, 2 * hb + 1, h->Hm);
+                PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH_FOLD, s));
+            } else {
+                RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
+                PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
+                have_pend = false;
+                PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
+            }
+            if (fold_b) {
+                // seam B: the LayerNorm that follows fc2 is the next half-block's first one (scale_msa) or the final layer's
+                const float* next_scale = hb + 1 < 2 * h->L ? mod + (size_t)(hb + 1) * 6 * D + D : mod + (size_t)h->L * 12 * D + D;
+                RET_IF(fold_producer(PC_FC2, h->hbuf, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, next_scale));
+                folded_in = true;
+            } else {
+                RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D));
+            }
         }
     }
     const float* mf = mod + (size_t)h->L * 12 * D;
-    PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
+    if (!folded_in)
+        PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
-    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    if (folded_in) fold_consumer(g, 4 * h->L, h->Nfin);
+    PROF(h, PC_OTHER, s, launch_gemm(g, folded_in ? EPI_F32_FOLD : EPI_F32, s));
     PROF(h, PC_OTHER, s, launch_unpatchify(h->fo, h->Nfin, v_out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
     PROF(h, PC_EMPTY, s, 0);   // an event pair around nothing: the per-pair overhead to subtract from every class
     return h->prof.collect(s);
@@ -416,7 +492,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
 extern "C" {
 
 const char* gtav_last_error(void) { return gtav::last_error(); }
-int gtav_abi_version(void) { return 3; }   // 3: training step (gtav_dit_train_*), collectives (gtav_comm_*)
+int gtav_abi_version(void) { return 4; }   // 3: training step (gtav_dit_train_*), collectives (gtav_comm_*); 4: LayerNorm fold switch, optimizer state (gtav_dit_{get,set}_opt_state)
 
 int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     GTAV_REQUIRE(c && out, "dit_create: null argument");
@@ -517,6 +593,50 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT));
     A_(a.alloc_t(&h->mod_cur, (size_t)h->maxB * h->maxT * h->MODW)); A_(a.alloc_t(&h->mod_last, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->mod_changed, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
     h->use_graph = GTAV_ENV_INT("GTAV_GRAPH", 1) != 0;   // the shipped library reads no environment: gtav_dit_set_graph() is the switch
+    if (!rc && h->P % 16 == 0 && h->P >= 64 && D % 256 == 0 && h->Hm % 128 == 0 && h->Nfin % 4 == 0) {
+        gtav_dit::Fold& f = h->fold;
+        const int nhb = h->L * 2, nseam = 2 * nhb + 1;
+        // ctab row: [fc1 seams | to_qkv seams | final], each seam c1 [N] then c2 [N]
+        f.col_c.assign(nseam, 0);
+        int col = 0;
+        for (int hb = 0; hb < nhb; ++hb) { f.col_c[2 * hb + 1] = col; col += 2 * h->Hm; }
+        for (int hb = 0; hb < nhb; ++hb) { f.col_c[2 * hb] = col; col += 2 * 3 * D; }
+        f.col_c[2 * nhb] = col; col += 2 * h->Nfin;
+        f.CTW = col;
+        f.n_groups = 2 * nseam; f.n_groups_a = 2 * nhb;
+        f.Rp = round_up(h->max_rows, 128);
+        A_(a.alloc_t(&f.ctab, (size_t)h->max_rows * f.CTW));
+        A_(a.alloc_t(&f.ctab_cur, (size_t)h->maxB * h->maxT * f.CTW));
+        A_(a.alloc_t(&f.stats, Mx * (size_t)(D / 32) * 2));
+        A_(a.alloc_t(&f.sx, (size_t)f.n_groups * f.Rp * D));
+        A_(a.alloc_t(&f.groups_dev, f.n_groups)); A_(a.alloc_t(&f.gcol_dev, f.n_groups)); A_(a.alloc_t(&f.gscale_dev, f.n_groups));
+        if (!rc) {
+            // group 2 q + kind (kind 0: scale -> c1, kind 1: shift -> c2), q = position of the seam in the ctab row order
+            std::vector<GemmGroup> groups(f.n_groups);
+            std::vector<int> gcol(f.n_groups), gsc(f.n_groups);
+            auto add = [&](int q, int seam, const f16* W, int N, const float* bias, int shift_col, int scale_col) {
+                for (int kind = 0; kind < 2; ++kind) {
+                    GemmGroup& g = groups[2 * q + kind];
+                    g.X = f.sx + (size_t)(2 * q + kind) * f.Rp * D; g.W = W; g.N = N; g.ldo = f.CTW;
+                    g.out = f.ctab + f.col_c[seam] + (kind ? N : 0); g.bias = kind ? bias : nullptr;
+                    gcol[2 * q + kind] = kind ? shift_col : scale_col; gsc[2 * q + kind] = kind ? 0 : 1;
+                }
+            };
+            for (int hb = 0; hb < nhb; ++hb) {   // chunk order of a half-block's modulation: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+                add(hb, 2 * hb + 1, h->halves[hb].w_fc1, h->Hm, h->halves[hb].b_fc1, (hb * 6 + 3) * D, (hb * 6 + 4) * D);
+                add(nhb + hb, 2 * hb, h->halves[hb].w_qkv, 3 * D, nullptr, (hb * 6 + 0) * D, (hb * 6 + 1) * D);
+            }
+            add(2 * nhb, 2 * nhb, h->w_final, h->Nfin, h->b_final, h->L * 12 * D, h->L * 12 * D + D);
+            if (hipMemcpy(f.groups_dev, groups.data(), groups.size() * sizeof(GemmGroup), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(f.gcol_dev, gcol.data(), gcol.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(f.gscale_dev, gsc.data(), gsc.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("dit_create: upload of the LayerNorm-fold group tables failed");
+                rc = 1;
+            }
+            f.ok = !rc;
+            f.min_m_a = 1024; f.min_m_b = 1024;   // measured thresholds: DESIGN.md 4.7
+        }
+    }
 #undef A_
     if (rc) {
         delete h;
@@ -606,7 +726,7 @@ int gtav_dit_forward(gtav_dit* h, const float* x, const int64_t* t, const float*
     h->prepared.valid = false;
     h->kvrec.valid = false;
     RET_IF(dit_cond(h, t, B * T, 1, nullptr, 0, actions, h->A, 0, s));
-    return dit_forward_core(h, x, nullptr, B, T, 0, h->mod, nullptr, out, s);
+    return dit_forward_core(h, x, nullptr, B, T, 0, h->mod, nullptr, h->fold.ctab, out, s);
 }
 
 int gtav_dit_set_schedule(gtav_dit* h, const float* ac, int32_t n) {
@@ -622,7 +742,7 @@ static int denoise_step_body(gtav_dit* h, float* x, int B, int F, int T, const f
     const size_t fsz = (size_t)h->C * h->H * h->W;
     const int Tq = mode == 1 ? 1 : T, t0 = mode == 1 ? T - 1 : 0;
     if (!prepared) RET_IF(dit_cond(h, nullptr, B * Tq, Tq, h->step_dev, mode == 1, actions, (int64_t)F * h->A, h->A, s));
-    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, prepared ? h->mod_cur : h->mod, nullptr, h->vout, s));
+    RET_IF(dit_forward_core(h, x, h->frame_idx, B, Tq, t0, prepared ? h->mod_cur : h->mod, nullptr, prepared ? h->fold.ctab_cur : h->fold.ctab, h->vout, s));
     // DDIM update of frame `cur` (train_dit.py:110-125, generate.py:220)
     const float* vlast = h->vout + (size_t)(Tq - 1) * fsz;
     RET_IF(launch_ddim_update_step(x, F, vlast, (size_t)Tq * fsz, B, (int)fsz, h->step_dev, s));
@@ -650,6 +770,13 @@ int gtav_dit_prepare_frame(gtav_dit* h, int32_t B, int32_t F, int32_t start, int
     RET_IF(launch_skinny_f32(h->E, 256, h->w_t0, h->b_t0, h->HC, ldhc, rows, h->D, 256, 1, s));
     RET_IF(launch_skinny_f32(h->HC, ldhc, h->w_t2cat, actions ? h->b_t2a : h->b_t2, h->Sc, h->D, rows, h->D, ldhc, 1, s));
     RET_IF(launch_skinny_f32(h->Sc, h->D, h->w_ada, h->b_ada, h->mod, h->MODW, rows, h->MODW, h->D, 0, s));
+    {   // LayerNorm-fold tables of every row, for the seams a full-window step (B T P tokens) or a context-cached step (B P tokens) folds
+        bool fa, fb, fa1, fb1;
+        fold_policy(h, B * T * h->P, fa, fb);
+        fold_policy(h, B * h->P, fa1, fb1);
+        RET_IF(dit_fold_tables(h, rows, fa || fa1, fb || fb1, s));
+        h->prepared.fold_tables = fa || fa1 || fb || fb1;
+    }
     GTAV_CHECK_HIP(hipMemsetAsync(h->mod_last, 0xFF, (size_t)h->maxB * h->maxT * sizeof(int), s));   // the table changed: every slot of mod_cur is stale
     h->prepared.valid = true; h->prepared.B = B; h->prepared.F = F; h->prepared.start = start; h->prepared.cur = cur;
     h->prepared.n_steps = n_steps; h->prepared.actions = actions;
@@ -687,7 +814,8 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
     sp.alpha_t = h->ac_host[t_cur]; sp.alpha_next = h->ac_host[t_next]; sp.cond_step = cond_step;
     RET_IF(launch_step_setup(h->step_dev, sp, h->frame_idx, h->mod_rows_dev, prepared ? h->mod_last : nullptr, h->mod_changed, B, mode == 1 ? 1 : T, T, F,
                              mode == 1, s));
-    if (prepared) RET_IF(launch_gather_rows(h->mod, h->mod_rows_dev, h->mod_changed, h->mod_cur, B * (mode == 1 ? 1 : T), h->MODW, s));
+    if (prepared) RET_IF(launch_gather_rows(h->mod, h->mod_rows_dev, h->mod_changed, h->mod_cur, B * (mode == 1 ? 1 : T), h->MODW,
+                                            h->prepared.fold_tables ? h->fold.ctab : nullptr, h->fold.ctab_cur, h->fold.CTW, s));
     if (!h->use_graph || h->prof.on) return denoise_step_body(h, x, B, F, T, actions, mode, v_out, prepared, s);
 
     // hipGraph path: the first step of a new (shape, buffers) key runs eagerly (warm-up: lazy module load, function
@@ -740,6 +868,19 @@ int gtav_dit_denoise_step(gtav_dit* h, float* x, int32_t B, int32_t F, int32_t s
 int gtav_dit_set_graph(gtav_dit* h, int32_t enable) {
     GTAV_REQUIRE(h, "dit_set_graph: null handle");
     h->use_graph = enable != 0;
+    return 0;
+}
+
+int gtav_dit_set_fold(gtav_dit* h, int32_t mode, int32_t min_tokens_a, int32_t min_tokens_b) {
+    GTAV_REQUIRE(h && mode >= 0 && mode <= 2, "dit_set_fold: mode %d", mode);
+    GTAV_REQUIRE(mode == 0 || h->fold.ok, "dit_set_fold: this geometry has no LayerNorm fold (tokens per frame %d must be a multiple of 16 and >= 64)", h->P);
+    for (auto& kv : h->graphs)       // captured sampler steps contain the other kernel sequence
+        if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+    h->prepared.valid = false;       // the per-frame tables were built for the old policy
+    h->fold.mode = mode;
+    if (min_tokens_a >= 0) h->fold.min_m_a = min_tokens_a;
+    if (min_tokens_b >= 0) h->fold.min_m_b = min_tokens_b;
     return 0;
 }
 
@@ -898,6 +1039,11 @@ int gtav_dit_set_loss_scale(gtav_dit* h, float scale) {
     return 0;
 }
 
+int gtav_dit_set_grad_divisor(gtav_dit* h, float divisor) {
+    GTAV_REQUIRE(h && h->tr.on && divisor >= 1.0f, "set_grad_divisor: bad argument");
+    h->tr.grad_div = divisor;
+    return 0;
+}
 int gtav_dit_zero_grad(gtav_dit* h, void* stream) {
     GTAV_REQUIRE(h && h->tr.on, "zero_grad: training is not enabled");
     // (hipMemsetAsync splits 2.4 GB into ~600 fill launches of 4 MB: 3.8 ms per step in the rocprofv3 trace; one grid-stride kernel: 0.5 ms)
@@ -1169,11 +1315,11 @@ int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float e
     gtav_dit::Train& tr = h->tr;
     GTAV_CHECK_HIP(hipMemsetAsync(tr.ctl, 0, 2 * sizeof(float), s));
     RET_IF(launch_sumsq(tr.grad_arena, tr.grad_count, tr.ctl, s));
-    RET_IF(launch_clip_coef(tr.ctl, 1.0f / tr.loss_scale, max_grad_norm, s));
-    tr.step += 1;
-    const float bc1 = 1.0f - powf(beta1, (float)tr.step), bc2 = 1.0f - powf(beta2, (float)tr.step);
+    // overflow (non-finite norm, or a saturated fp16 gradient / activation recorded in the error word) skips the step on the device; the
+    // Adam step count and its bias corrections live in ctl[4..6] and advance only with applied steps
+    RET_IF(launch_clip_coef(tr.ctl, 1.0f / (tr.loss_scale * tr.grad_div), max_grad_norm, beta1, beta2, h->err_flag, s));
     // one launch: AdamW on every parameter + the fp16 W / W^T operands of the GEMM weights rewritten from the updated masters
-    RET_IF(launch_adamw_multi(tr.adam_params, tr.adam_items, tr.adam_n_items, tr.ctl, lr, beta1, beta2, eps, weight_decay, bc1, bc2, s));
+    RET_IF(launch_adamw_multi(tr.adam_params, tr.adam_items, tr.adam_n_items, tr.ctl, lr, beta1, beta2, eps, weight_decay, s));
     RET_IF(launch_add_f32(h->b_t2, h->b_ext, h->b_t2a, h->D, s));   // fused bias of c when actions are given (gtav_dit_finalize)
     h->prepared.valid = false;
     h->kvrec.valid = false;
@@ -1182,6 +1328,51 @@ int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float e
 
 // ctl: [0] sum of squares of the scaled gradients, [1] step coefficient (0 = the step was skipped), [2] skipped steps so far,
 // [3] unscaled global gradient norm of the last step (torch.nn.utils.clip_grad_norm_'s return value)
+// Optimizer state of one parameter (AdamW first / second moments, contiguous in the parameter's state-dict shape) and the step counters:
+// with gtav_dit_get_weight / set_weight (the fp32 masters) this is everything `accelerator.save_state` / `load_state` keep for the
+// optimizer (train_dit.py:765-849).
+static int opt_slot(gtav_dit* h, const char* name, int64_t numel, Slot** out) {
+    GTAV_REQUIRE(h && name && h->tr.on, "opt_state: training is not enabled");
+    auto it = h->wt.slots.find(name);
+    GTAV_REQUIRE(it != h->wt.slots.end() && it->second.trainable && it->second.am && it->second.av, "opt_state: '%s' is not a trainable parameter", name);
+    GTAV_REQUIRE(numel == (int64_t)it->second.R * it->second.C, "opt_state: '%s' has %d x %d elements, got %lld", name, it->second.R, it->second.C, (long long)numel);
+    *out = &it->second;
+    return 0;
+}
+int gtav_dit_get_opt_state(gtav_dit* h, const char* name, float* m_dst, float* v_dst, int64_t numel, void* stream) {
+    Slot* sl = nullptr;
+    RET_IF(opt_slot(h, name, numel, &sl));
+    GTAV_REQUIRE(m_dst && v_dst, "get_opt_state: null destination");
+    GTAV_CHECK_HIP(hipMemcpyAsync(m_dst, sl->am, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipMemcpyAsync(v_dst, sl->av, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+int gtav_dit_set_opt_state(gtav_dit* h, const char* name, const float* m_src, const float* v_src, int64_t numel, void* stream) {
+    Slot* sl = nullptr;
+    RET_IF(opt_slot(h, name, numel, &sl));
+    GTAV_REQUIRE(m_src && v_src, "set_opt_state: null source");
+    GTAV_CHECK_HIP(hipMemcpyAsync(sl->am, m_src, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipMemcpyAsync(sl->av, v_src, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+int gtav_dit_get_opt_step(gtav_dit* h, int64_t* applied_steps, int64_t* skipped_steps, void* stream) {
+    GTAV_REQUIRE(h && h->tr.on && applied_steps && skipped_steps, "get_opt_step: bad argument");
+    float c[8];
+    GTAV_CHECK_HIP(hipMemcpyAsync(c, h->tr.ctl, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *applied_steps = (int64_t)c[4];
+    *skipped_steps = (int64_t)c[2];
+    return 0;
+}
+int gtav_dit_set_opt_step(gtav_dit* h, int64_t applied_steps, int64_t skipped_steps, void* stream) {
+    GTAV_REQUIRE(h && h->tr.on && applied_steps >= 0 && applied_steps < (1 << 24) && skipped_steps >= 0, "set_opt_step: bad argument (the step count is kept as an exact fp32 integer: < 2^24)");
+    float c[8];
+    GTAV_CHECK_HIP(hipMemcpyAsync(c, h->tr.ctl, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    c[4] = (float)applied_steps; c[2] = (float)skipped_steps;
+    GTAV_CHECK_HIP(hipMemcpy(h->tr.ctl, c, sizeof(c), hipMemcpyHostToDevice));
+    return 0;
+}
 int gtav_dit_train_stats(gtav_dit* h, float* out4_host, void* stream) {
     GTAV_REQUIRE(h && out4_host && h->tr.on, "train_stats: bad argument");
     GTAV_CHECK_HIP(hipMemcpyAsync(out4_host, h->tr.ctl, 4 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -1451,6 +1642,10 @@ int gtav_add_noise(const float* x, const float* noise, const float* alpha, float
 int gtav_vtarget(const float* x, const float* noise, const float* alpha, float* vt, int32_t rows, int32_t n, float clamp_abs,
                  void* stream) {
     return launch_vtarget(x, noise, alpha, vt, rows, n, clamp_abs, (hipStream_t)stream);
+}
+int gtav_axpy_f32(float* y, const float* x, float alpha, int64_t n, void* stream) {
+    GTAV_REQUIRE(y && x && n > 0, "axpy_f32: bad argument");
+    return launch_axpy_f32(y, x, alpha, (size_t)n, (hipStream_t)stream);
 }
 int gtav_mse(const float* a, int64_t a_stride, const float* b, int64_t b_stride, int32_t rows, int32_t n, float* out, void* stream) {
     return launch_mse(a, (size_t)a_stride, b, (size_t)b_stride, rows, n, out, (hipStream_t)stream);

@@ -182,9 +182,8 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         }
         if (pd.gate) y = y * g4;
         v = v + y;
-        float* xw = pd.x_out ? pd.x_out + (size_t)m * ldx + c : xr + c;   // training forward keeps every residual state
-        if (pd.flags & 1) store16_sc1(xw, v);
-        else *(f32x4*)xw = v;
+        // (the updated row is stored BEHIND the block barrier of the statistics below: in place it overwrites xr[0], which every wave of the
+        // block reads as the shift K of the one-pass statistics — a wave that started late must not see the updated value there)
     }
     // Row statistics in ONE block-wide reduction: sums of (v - K) and (v - K)^2 with the shift K = the row's first residual element (a sample
     // of the row, so |mean - K| is of the order of the standard deviation and E[(v-K)^2] - E[v-K]^2 does not cancel), reduced side by side.
@@ -194,7 +193,12 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
     const float s1 = wave_sum_dpp((a0 + a1) + (a2 + a3));
     const float s2 = wave_sum_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
     if (lane == 0) { red[wid] = s1; red[8 + wid] = s2; }
-    __syncthreads();
+    __syncthreads();   // every wave has consumed its copy of kshift = xr[0] by now
+    if (PEND && act) {
+        float* xw = pd.x_out ? pd.x_out + (size_t)m * ldx + c : xr + c;   // training forward keeps every residual state
+        if (pd.flags & 1) store16_sc1(xw, v);
+        else *(f32x4*)xw = v;
+    }
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { t1 += i < nw ? red[i] : 0.f; t2 += i < nw ? red[8 + i] : 0.f; }   // red[] is read with ds_read_b128s, not a counted loop
@@ -296,6 +300,10 @@ __global__ void fill_f32_kernel(float* dst, size_t n, float v) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) dst[idx] = v;
 }
 
+__global__ void axpy_f32_kernel(float* y, const float* x, float alpha, size_t n) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) y[idx] += alpha * x[idx];
+}
+
 __global__ void add_f32_kernel(const float* a, const float* b, float* out, size_t n) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
         out[idx] = a[idx] + b[idx];
@@ -324,13 +332,50 @@ __global__ void step_setup_kernel(StepParams* dst, StepParams v, int* frame_idx,
 // the step then index the modulation by frame slot directly; through the row indirection every one of the 65 LayerNorm launches of a forward
 // paid a dependent load (index, then the row's shift / scale) at the head of its critical path: 5.53 us per launch in the sampler against
 // 4.87 us in the plain forward.  Per step only the denoised frame's row changes: one 0.8 MB copy.
+// (W2 > 0: a second table — the c1 / c2 tables of the LayerNorm fold — is gathered by the same launch: blocks beyond W cover it)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const int* __restrict__ rows, const int* __restrict__ changed,
-                                                          float* __restrict__ cur, int W) {
+                                                          float* __restrict__ cur, int W, const float* __restrict__ table2, float* __restrict__ cur2, int W2) {
     const int slot = blockIdx.y;
     if (!changed[slot]) return;
-    const size_t c = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= (size_t)W) return;
-    *(f32x4*)(cur + (size_t)slot * W + c) = *(const f32x4*)(table + (size_t)rows[slot] * W + c);
+    const int nb1 = (W + 1023) >> 10;
+    if ((int)blockIdx.x < nb1) {
+        const size_t c = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+        if (c >= (size_t)W) return;
+        *(f32x4*)(cur + (size_t)slot * W + c) = *(const f32x4*)(table + (size_t)rows[slot] * W + c);
+    } else {
+        const size_t c = ((size_t)(blockIdx.x - nb1) * 256 + threadIdx.x) * 4;
+        if (c >= (size_t)W2) return;
+        *(f32x4*)(cur2 + (size_t)slot * W2 + c) = *(const f32x4*)(table2 + (size_t)rows[slot] * W2 + c);
+    }
+}
+
+// X operands of the grouped table GEMM of the LayerNorm fold (gemm.h launch_gemm_grouped): group g <- columns [col[g], col[g] + D) of the fp32
+// modulation table `mod` [R][MODW] as fp16 TILE-MAJOR [Rp][D] (rows >= R zero); scale groups (is_scale[g]) hold 1 + (scale + 1e-6), the factor
+// the producer epilogue applies to the residual (model/dit.py:19-27 modulate).
+__global__ __launch_bounds__(256) void ctab_inputs_kernel(const float* __restrict__ mod, int MODW, int R, int Rp, int D, const int* __restrict__ col,
+                                                          const int* __restrict__ is_scale, f16* __restrict__ sx, size_t group_stride) {
+    const int g = blockIdx.y;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;      // one thread per 8 consecutive k of one row
+    const int per_row = D >> 3;
+    const int r = (int)(idx / per_row), k = (int)(idx - (size_t)r * per_row) * 8;
+    if (r >= Rp) return;
+    union { f16x8 h; u32x4 u; } o;
+    if (r < R) {
+        const float* src = mod + (size_t)r * MODW + col[g] + k;
+        const f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 4);
+        const bool sc = is_scale[g] != 0;
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = sc ? 1.0f + (v[e] + 1e-6f) : v[e];
+            x = __builtin_amdgcn_fmed3f(x, -F16_MAX, F16_MAX);
+            o.h[e] = (f16)x;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = (f16)0.f;
+    }
+    *(u32x4*)(sx + (size_t)g * group_stride + tiled_off(r, k, D)) = o.u;
 }
 
 __global__ void cond_inputs_frame_kernel(int rows, int B, int T, int F, int start, int cur, int t_ctx, const int* __restrict__ t_steps,
@@ -707,6 +752,12 @@ int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream) {
     return 0;
 }
 
+int launch_axpy_f32(float* y, const float* x, float alpha, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(axpy_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, y, x, alpha, n);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, a, b, out, n);
     GTAV_CHECK_HIP(hipGetLastError());
@@ -720,9 +771,21 @@ int launch_step_setup(StepParams* dst, const StepParams& v, int* frame_idx, int*
     return 0;
 }
 
-int launch_gather_rows(const float* table, const int* rows, const int* changed, float* cur, int slots, int W, hipStream_t stream) {
-    GTAV_REQUIRE(W % 4 == 0 && slots > 0, "gather_rows: W=%d slots=%d", W, slots);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(W, 1024), slots), dim3(256), 0, stream, table, rows, changed, cur, W);
+int launch_gather_rows(const float* table, const int* rows, const int* changed, float* cur, int slots, int W, const float* table2, float* cur2, int W2,
+                       hipStream_t stream) {
+    GTAV_REQUIRE(W % 4 == 0 && W2 % 4 == 0 && slots > 0, "gather_rows: W=%d W2=%d slots=%d", W, W2, slots);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(W, 1024) + (table2 ? cdiv(W2, 1024) : 0), slots), dim3(256), 0, stream, table, rows, changed, cur, W,
+                       table2, cur2, table2 ? W2 : 0);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ctab_inputs(const float* mod, int MODW, int R, int Rp, int D, const int* col, const int* is_scale, int n_groups, f16* sx, size_t group_stride,
+                       hipStream_t stream) {
+    GTAV_REQUIRE(D % 64 == 0 && Rp % 128 == 0 && R <= Rp && n_groups > 0, "ctab_inputs: bad geometry");
+    const size_t threads = (size_t)Rp * (D >> 3);
+    hipLaunchKernelGGL(ctab_inputs_kernel, dim3((unsigned)((threads + 255) / 256), n_groups), dim3(256), 0, stream, mod, MODW, R, Rp, D, col, is_scale, sx,
+                       group_stride);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -17,7 +17,16 @@ enum GemmEpi : int {
                         // reduces the slabs and applies bias + gate + residual (ops.h: LnPending)
     EPI_F16_TILED = 7,  // out_f16 = acc + bias, TILE-MAJOR like the GELU epilogues (no activation): training keeps the MLP's
                         // pre-activation, and the backward pass's activation gradients are GEMM operands themselves
+    // ---- LayerNorm fold: the LayerNorm + adaLN modulate between a residual GEMM and the GEMM that consumes its
+    // output is split over the two epilogues instead of being a launch of its own (model/dit.py:19-27,200-225) ----
+    EPI_RESID_FOLD = 8,      // producer (out-proj, fc2; full K): x = resid[m][n] += gate (acc + bias) in place, AND the next GEMM's operand
+                             // A[m][n] = fp16(x (1 + scale_next + 1e-6)) tile-major, AND per-row partial sums (sum x, sum x^2) per 32-feature slot
+    EPI_QKV_FOLD = 9,        // consumers: X = A; y = (acc - mean c1[frame][n]) rstd + c2[frame][n], then as EPI_QKV / EPI_GELU_TANH / EPI_F32
+    EPI_GELU_TANH_FOLD = 10, //   with mean / rstd from the producer's partial sums and c1 = sum_k (1 + scale_k) W[n][k],
+    EPI_F32_FOLD = 11,       //   c2 = sum_k shift_k W[n][k] + bias[n] from the per-frame tables (gemm_grouped: one launch per forward)
 };
+constexpr bool epi_is_fold_consumer(int e) { return e == EPI_QKV_FOLD || e == EPI_GELU_TANH_FOLD || e == EPI_F32_FOLD; }
+constexpr int epi_base(int e) { return e == EPI_QKV_FOLD ? EPI_QKV : e == EPI_GELU_TANH_FOLD ? EPI_GELU_TANH : e == EPI_F32_FOLD ? EPI_F32 : e; }
 
 enum QkvMode : int {
     QKV_SPATIAL = 0,   // Q,K -> [nb][head][S][64], V -> Vt [nb][head][64][S]   (nb = m / S)
@@ -59,7 +68,27 @@ struct GemmParams {
     // by run-time values cost ~110 scalar instructions (two float-reciprocal sequences) = 0.3-0.4 us in front of the first fill;
     // with the divisors' 32-bit reciprocals (a / d == mulhi(a, ceil(2^32 / d)) for a * d < 2^32) they are three s_mul_hi_u32
     struct TileMap { int tiles_m, tiles_n, gn, group, tiles; unsigned rcp_tiles, rcp_group, rcp_gn, rcp_gnlast; } tm;
+    // ---- LayerNorm fold ----
+    // Tokens are grouped in frames of f_P (a multiple of 16; a wave's token span must not exceed it); the per-frame vectors (gate and
+    // f_scale of the producer, f_c1 / f_c2 of the consumer) of frame fr = m / f_P are row (f_rows ? f_rows[fr] : fr) of their table.
+    int f_P;
+    const int* f_rows;
+    // consumer (EPI_*_FOLD)
+    const float* f_stats;   // [M][f_nslot][2]: (sum x, sum x^2) over features 32 s .. 32 s + 31 of row m, written by the producer
+    int f_nslot;            // K / 32 (a multiple of 8)
+    const float* f_c1;      // row r at f_c1 + r * f_ldc: [N]
+    const float* f_c2;
+    int f_ldc;
+    // producer (EPI_RESID_FOLD): out = resid, gate / gate_stride as EPI_RESID (rows by f_P / f_rows)
+    float* f_stats_out;     // [M][N / 32][2]
+    const float* f_scale;   // scale vectors of the NEXT LayerNorm: row r at f_scale + r * gate_stride
+    f16* f_a;               // tile-major [round_up(M, 128)][N]
 };
+
+// One group of a grouped launch (launch_gemm_grouped): out[m][n] = sum_k X[m][k] W[n][k] + bias[n], m < M (common), n < N.
+struct GemmGroup { const f16* X; const f16* W; float* out; const float* bias; int N; int ldo; };
+// blockIdx.y = group; every group has the same M and K; out is f32 row-major with leading dimension ldo.  `groups` is a DEVICE array.
+int launch_gemm_grouped(const GemmGroup* groups_dev, int n_groups, int max_N, int M, int K, hipStream_t stream);
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);

@@ -19,6 +19,7 @@
 #include "gemm.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <hip/hip_ext.h>
 
@@ -642,6 +643,88 @@ __device__ __forceinline__ void tile_map_fast(const GemmParams& p, int& n0, int&
     m0 = tile_m * TMB;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm fold, consumer side (EPI_*_FOLD).  The X operand is A[m][k] = x[m][k] (1 + scale[f][k]) of the residual row x
+// the LayerNorm would have normalised (f = frame of token m), so with mean / rstd of the row and the per-frame tables
+//   c1[f][n] = sum_k (1 + scale[f][k]) W[n][k],   c2[f][n] = sum_k shift[f][k] W[n][k] + bias[n]
+// the GEMM of the modulated LayerNorm output is   y[m][n] = (acc[m][n] - mean_m c1[f][n]) rstd_m + c2[f][n]   (model/dit.py:19-27).
+// mean / rstd come from the producer's partial sums (sum x, sum x^2) per 32-feature slot: lane (li, g) adds quarter g of its token's
+// slots in slot order, two xor-shuffles combine the quarters — ONE fixed order for every consumer block of that row.
+// A wave's 16-token groups never straddle a frame (f_P % 16 == 0, tiles start on multiples of 16).  The c1 / c2 slices of the block tile
+// — TNB features of the (at most FOLD_NFR) frames its tokens belong to — are staged in LDS once per block (fold_stage_tables, behind the
+// main loop: the ring is dead) and read from there per MFMA tile: no table registers are carried and no wave waits on its own global loads.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FOLD_NFR = 4;                          // frames a block tile can touch: TM <= 192 tokens, f_P >= 64 (host-checked)
+constexpr int fold_lds_bytes(int tnb) { return FOLD_NFR * 2 * tnb * 4; }
+template <int FJ>
+struct FoldTok {
+    float mu[FJ], rs[FJ];
+    int b1, b2, b3;             // first tokens of the block tile's 2nd / 3rd / 4th frame
+    int kmax;                   // last staged frame (token groups past M — ragged last tile — use it: their results are dropped, but must stay finite)
+    const char* cb;             // LDS: [frame k][c1 | c2][TNB] floats
+};
+// frame (inside the block tile) of the 16-token group that starts at token m
+template <int FJ>
+__device__ __forceinline__ int fold_frame_of(const FoldTok<FJ>& ft, int m) {
+    const int k = (m >= ft.b1 ? 1 : 0) + (m >= ft.b2 ? 1 : 0) + (m >= ft.b3 ? 1 : 0);
+    return k < ft.kmax ? k : ft.kmax;
+}
+template <int TNB, int TM, int FJ>
+__device__ __forceinline__ void fold_stage_tables(const GemmParams& p, char* cb, int n0, int m0, FoldTok<FJ>& ft) {
+    const int mlast = m0 + TM - 1 < p.M ? m0 + TM - 1 : p.M - 1;
+    const int f_first = m0 / p.f_P, nfr = mlast / p.f_P - f_first + 1;
+    ft.b1 = (f_first + 1) * p.f_P; ft.b2 = ft.b1 + p.f_P; ft.b3 = ft.b2 + p.f_P;
+    ft.kmax = nfr - 1;
+    ft.cb = cb;
+    constexpr int Q = TNB / 4;                        // 16-byte chunks per table row slice
+    for (int idx = threadIdx.x; idx < nfr * 2 * Q; idx += (int)blockDim.x) {
+        const int k = idx / (2 * Q), r = idx - k * 2 * Q, t = r / Q, n4 = r - t * Q;
+        int n = n0 + 4 * n4;
+        n = n < p.N ? n : p.N - 4;
+        const int row = p.f_rows ? p.f_rows[f_first + k] : f_first + k;
+        *(f32x4*)(cb + (size_t)((k * 2 + t) * TNB + 4 * n4) * 4) = *(const f32x4*)((t ? p.f_c2 : p.f_c1) + (size_t)row * p.f_ldc + n);
+    }
+}
+template <int FJ>
+__device__ __forceinline__ void fold_prepare(const GemmParams& p, int mw /* first token of the wave (wave-uniform) */, FoldTok<FJ>& ft) {
+    const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int q = p.f_nslot >> 2;                       // slots per lane quarter (even: f_nslot % 8 == 0)
+    const float inv_d = 1.0f / (float)(p.f_nslot * 32);
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+        int m = mw + 16 * j + li;
+        m = m < p.M ? m : p.M - 1;
+        const float* sp = p.f_stats + ((size_t)m * p.f_nslot + g * q) * 2;
+        float a1 = 0.f, a2 = 0.f;
+        for (int s = 0; s < q; s += 2) {
+            const f32x4 v = *(const f32x4*)(sp + 2 * s);
+            a1 += v[0]; a2 += v[1];
+            a1 += v[2]; a2 += v[3];
+        }
+        a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+        a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+        const float mu = a1 * inv_d;
+        ft.mu[j] = mu;
+        ft.rs[j] = 1.0f / sqrtf(fmaxf(a2 * inv_d - mu * mu, 0.f) + 1e-6f);
+    }
+}
+// producer side: a wave's token span (<= 64) is at most one frame long, so it meets at most two frames — the one of its first token (A)
+// and the next (B)
+__device__ __forceinline__ void fold_frames(const GemmParams& p, int mw, int& rowA, int& rowB, int& boundary) {
+    const int mf = mw < p.M ? mw : p.M - 1;
+    const int f0 = mf / p.f_P, flast = (p.M - 1) / p.f_P;
+    const int f1 = f0 < flast ? f0 + 1 : flast;
+    boundary = (f0 + 1) * p.f_P;
+    rowA = p.f_rows ? p.f_rows[f0] : f0;
+    rowB = p.f_rows ? p.f_rows[f1] : f1;
+}
+__device__ __forceinline__ f32x4 fold_apply(const f32x4 acc, float mu, float rs, const f32x4 c1, const f32x4 c2) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(__builtin_fmaf(-mu, c1[e], acc[e]), rs, c2[e]);
+    return r;
+}
+
 // QKV epilogue staged through LDS: bias + RoPE happen in registers (pairs are lane-local), the block's fp16 result is laid
 // out in LDS in the shape of its DESTINATION rows (q/k: [token][feature], V^T: [feature][token]) and leaves as 16-byte
 // stores — a whole 128-byte head row of one token (or 8 consecutive tokens of one V^T row) per 8 lanes — instead of 8-byte
@@ -669,9 +752,9 @@ __device__ __forceinline__ void prefetch_rope(const GemmParams& p, int n0, int m
     }
 }
 
-template <int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false>   // PRE: prope holds the prefetched (cos, sin) values (registers, static indexing)
+template <int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false, bool FOLD = false>   // PRE: prope holds the prefetched (cos, sin) values (registers, static indexing)
 __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, bool tr,
-                                           const f32x4 (&prope)[FI][FJ]) {
+                                           const f32x4 (&prope)[FI][FJ], FoldTok<FJ>& ft) {
     constexpr int TM = WM * 16 * FJ, TNB = 16 * FI * WN;
     const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6) - WOFF;   // WOFF leading waves are loader waves (mainloop_l)
     const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
@@ -682,6 +765,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
     int2* tab = (int2*)(smem + (TM * PN > TNB * PT ? TM * PN : TNB * PT));
     float amax = 0.f;
     __syncthreads();   // every wave is done reading the last K-step's stage
+    if constexpr (FOLD) fold_stage_tables<TNB, TM, FJ>(p, (char*)(tab + TM), n0, m0, ft);
     for (int r = threadIdx.x; r < TM; r += (int)blockDim.x) {
         const int m = m0 + r;
         int a = -1, b = 0;
@@ -699,6 +783,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
         }
         tab[r] = int2{a, b};
     }
+    if constexpr (FOLD) __syncthreads();   // the staged c1 / c2 slices are visible
     if (compute_wave) {
         if (tr) {
             // D[row = token][col = feature]: the lane owns tokens ml..ml+3 of feature nl -> V^T image [feature][token]
@@ -711,7 +796,20 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
                     const int ml = 16 * FJ * wm + 16 * j + 4 * g;
                     char* dst = smem + nl * PT + (((ml >> 3) ^ (nl & 7)) << 4) + ((ml >> 2) & 1) * 8;
                     const f32x4 a = acc[i][j];
-                    *(uint2*)dst = pack4(amax, a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+                    if constexpr (FOLD) {
+                        // the lane owns tokens 4 g .. 4 g + 3 of the group: their statistics live in lanes li = 4 g + e
+                        const float* cf = (const float*)ft.cb + fold_frame_of(ft, m0 + 16 * FJ * wm + 16 * j) * 2 * TNB + nl;
+                        const float c1 = cf[0], c2 = cf[TNB];
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float mu = __shfl(ft.mu[j], 4 * g + e, 64), rs = __shfl(ft.rs[j], 4 * g + e, 64);
+                            o[e] = __builtin_fmaf(__builtin_fmaf(-mu, c1, a[e]), rs, c2);
+                        }
+                        *(uint2*)dst = pack4(amax, o[0], o[1], o[2], o[3]);
+                    } else {
+                        *(uint2*)dst = pack4(amax, a[0] + bv, a[1] + bv, a[2] + bv, a[3] + bv);
+                    }
                 }
             }
         } else {
@@ -733,7 +831,13 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
                     const int ml = 16 * FJ * wm + 16 * j + li;
-                    f32x4 v = acc[i][j] + bv;
+                    f32x4 v;
+                    if constexpr (FOLD) {
+                        const float* cf = (const float*)ft.cb + fold_frame_of(ft, m0 + 16 * FJ * wm + 16 * j) * 2 * TNB + nl;
+                        v = fold_apply(acc[i][j], ft.mu[j], ft.rs[j], *(const f32x4*)cf, *(const f32x4*)(cf + TNB));
+                    } else {
+                        v = acc[i][j] + bv;
+                    }
                     if (rope) {
                         f32x4 cs;
                         if constexpr (PRE) cs = prope[i][j];
@@ -786,8 +890,9 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
 // features 16 FI wn .. and tokens 16 FJ wm ..; acc[i][j] is the 16 x 16 MFMA tile (feature group i, token group j).
 // The bias of the non-transposed epilogues is fetched BEFORE the main loop (prefetch_bias): its L2 / HBM round trip used to
 // sit at the head of every epilogue.
-template <int EPI, int FI, int WM, int WN = 2, int WOFF = 0>
+template <int EPIX, int FI, int WM, int WN = 2, int WOFF = 0>
 __device__ __forceinline__ void prefetch_bias(const GemmParams& p, int n0, f32x4 (&pbias)[FI]) {
+    constexpr int EPI = epi_base(EPIX);
     const int w = (int)(threadIdx.x >> 6) - WOFF;
     const int lane = threadIdx.x & 63, wn = w % WN, g = lane >> 4;
 #pragma unroll
@@ -798,15 +903,100 @@ __device__ __forceinline__ void prefetch_bias(const GemmParams& p, int n0, f32x4
     }
 }
 
-template <int EPI, int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false>
+template <int EPIX, int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr,
                                          const f32x4 (&prope)[FI][FJ]) {
-    constexpr int TM = WM * 16 * FJ;
+    constexpr int EPI = epi_base(EPIX);
+    constexpr bool FOLD = epi_is_fold_consumer(EPIX);   // LayerNorm fold, consumer side: v = (acc - mean c1) rstd + c2 instead of acc + bias
+    constexpr int TM = WM * 16 * FJ, TNB = 16 * FI * WN;
     constexpr int CT = 16 * FI * WN / 64;           // 64-feature sub-tiles per block tile row
     const int lane = threadIdx.x & 63, wraw = threadIdx.x >> 6, w = wraw - WOFF;   // WOFF leading waves are loader waves (mainloop_l)
     const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
     const bool compute_wave = w >= 0 && w < WN * WM;
     float amax = 0.f;
+    FoldTok<FJ> ft;
+    if constexpr (FOLD) {
+        if (compute_wave) fold_prepare<FJ>(p, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * wm), ft);
+    }
+
+    if constexpr (EPI == EPI_RESID_FOLD) {
+        // LayerNorm fold, producer side: the gated residual update in place, the next GEMM's operand A = x (1 + scale_next + 1e-6)
+        // (fp16, assembled in LDS in the tile-major image and copied out as 1-KiB pieces like the GELU output) and the row's partial
+        // sums per 32-feature slot for the consumer's mean / rstd.
+        static_assert(EPI != EPI_RESID_FOLD || FI % 2 == 0, "a 32-feature statistics slot is two MFMA feature tiles of one wave");
+        __syncthreads();   // every wave is done reading the last K-step's stage
+        if (compute_wave) {
+            int rowA, rowB, boundary;
+            fold_frames(p, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * wm), rowA, rowB, boundary);
+            const float *gA = p.gate + (size_t)rowA * p.gate_stride, *gB = p.gate + (size_t)rowB * p.gate_stride;
+            const float *sA = p.f_scale + (size_t)rowA * p.gate_stride, *sB = p.f_scale + (size_t)rowB * p.gate_stride;
+            float s1[FI / 2][FJ], s2[FI / 2][FJ];
+#pragma unroll
+            for (int h = 0; h < FI / 2; ++h)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) s1[h][j] = 0.f, s2[h][j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int nl = 16 * FI * wn + 16 * i + 4 * g;
+                const int n = n0 + nl;
+                const bool nok = n < p.N;
+                const int nc = nok ? n : 0;
+                const f32x4 bv = pbias[i];
+                const f32x4 gA4 = *(const f32x4*)(gA + nc), gB4 = *(const f32x4*)(gB + nc);
+                const f32x4 sA4 = *(const f32x4*)(sA + nc), sB4 = *(const f32x4*)(sB + nc);
+                const int c = nl & 63;
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    const int ml = 16 * FJ * wm + 16 * j + li;
+                    const int m = m0 + ml;
+                    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (nok && m < p.M) {
+                        float* dst = (float*)p.out + (size_t)m * p.ldo + n;
+                        const bool inA = m0 + 16 * FJ * wm + 16 * j < boundary;
+                        const f32x4 gt = inA ? gA4 : gB4, sc = inA ? sA4 : sB4;
+                        f32x4 x = *(const f32x4*)dst;
+                        x = x + gt * (acc[i][j] + bv);
+                        if (p.out_sc1) store16_sc1(dst, x);
+                        else *(f32x4*)dst = x;
+                        s1[i / 2][j] += (x[0] + x[1]) + (x[2] + x[3]);
+                        s2[i / 2][j] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = x[e] * (1.0f + (sc[e] + 1e-6f));
+                    }
+                    char* ld = smem + ((nl >> 6) * TM + ml) * 128 + (((c >> 3) ^ (ml & 7)) << 4) + (c & 7) * 2;
+                    *(uint2*)ld = pack4(amax, a[0], a[1], a[2], a[3]);
+                }
+            }
+            const int nslot = p.N >> 5;
+#pragma unroll
+            for (int h = 0; h < FI / 2; ++h) {
+                const int slot = (n0 + 16 * FI * wn + 32 * h) >> 5;
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    float t1 = s1[h][j], t2 = s2[h][j];
+                    t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+                    t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+                    const int m = m0 + 16 * FJ * wm + 16 * j + li;
+                    if (g == 0 && m < p.M && slot < nslot) *(float2*)(p.f_stats_out + ((size_t)m * nslot + slot) * 2) = float2{t1, t2};
+                }
+            }
+        }
+        sat_report(amax, p.err_flag);
+        __syncthreads();
+        const int nkt_out = p.N >> 6, last_rt = (p.M - 1) >> 7;
+        constexpr int PR = TM / 8;
+        for (int q = wraw; q < CT * PR; q += (int)(blockDim.x >> 6)) {
+            const int cs = q / PR, pq = q - cs * PR;
+            const int gr = m0 + 8 * pq;
+            const int rt = gr >> 7;
+            if (rt > last_rt || (n0 >> 6) + cs >= nkt_out) continue;
+            const uint4 val = *(const uint4*)(smem + (cs * TM + 8 * pq) * 128 + lane * 16);
+            char* dst = (char*)p.f_a + ((size_t)rt * nkt_out + (n0 >> 6) + cs) * TILE_BYTES + ((gr & 127) >> 3) * 1024 + lane * 16;
+            if (p.out_sc1) store16q_sc1(dst, val);
+            else *(uint4*)dst = val;
+        }
+        return;
+    }
 
     if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
         // The fp16 output is the next GEMM's A operand (tile-major).  The block's TM x 128 result is assembled in LDS in
@@ -814,6 +1004,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         // and then copied out as fully contiguous 1 KiB pieces (8 token rows, 16 B per lane) instead of 16 scattered 8-byte
         // stores per lane.  Works for any block tile whose first token row is a multiple of 8 (96-token tiles included).
         __syncthreads();   // every wave is done reading the last K-step's stage
+        if constexpr (FOLD) {
+            fold_stage_tables<TNB, TM, FJ>(p, smem + CT * TM * 128, n0, m0, ft);
+            __syncthreads();
+        }
         if (compute_wave) {
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
@@ -824,7 +1018,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 for (int j = 0; j < FJ; ++j) {
                     const int ml = 16 * FJ * wm + 16 * j + li;      // token inside the block tile
                     char* dst = smem + ((nl >> 6) * TM + ml) * 128 + (((c >> 3) ^ (ml & 7)) << 4) + (c & 7) * 2;
-                    const f32x4 v = acc[i][j] + bv;
+                    f32x4 v;
+                    if constexpr (FOLD) {
+                        const float* cf = (const float*)ft.cb + fold_frame_of(ft, m0 + 16 * FJ * wm + 16 * j) * 2 * TNB + nl;
+                        v = fold_apply(acc[i][j], ft.mu[j], ft.rs[j], *(const f32x4*)cf, *(const f32x4*)(cf + TNB));
+                    } else {
+                        v = acc[i][j] + bv;
+                    }
                     if constexpr (EPI == EPI_GELU_TANH)
                         {
                             if (GTAV_DBG(p, 16384)) {   // experiments build: the scalar form, for A/B runs
@@ -862,9 +1062,14 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     if constexpr (EPI == EPI_QKV) {
         // block-uniform: 8-token groups of a V^T row must not straddle attention items
         if (!GTAV_DBG(p, 16) && (p.qkv_mode == QKV_TEMPORAL || p.S % 8 == 0)) {
-            qkv_staged<FI, FJ, WM, WN, WOFF, PRE>(p, acc, pbias, smem, n0, m0, tr, prope);
+            qkv_staged<FI, FJ, WM, WN, WOFF, PRE, FOLD>(p, acc, pbias, smem, n0, m0, tr, prope, ft);
             return;
         }
+    }
+    if constexpr (FOLD) {   // (EPI_F32: the final projection)
+        __syncthreads();   // every wave is done reading the last K-step's stage
+        fold_stage_tables<TNB, TM, FJ>(p, smem, n0, m0, ft);
+        __syncthreads();
     }
     if (!compute_wave) return;
 
@@ -931,7 +1136,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         for (int j = 0; j < FJ; ++j) {
             const int m = m0 + 16 * FJ * wm + 16 * j + li;
             if (m >= p.M) continue;
-            f32x4 v = acc[i][j] + bv;
+            f32x4 v;
+            if constexpr (FOLD) {
+                const float* cf = (const float*)ft.cb + fold_frame_of(ft, m0 + 16 * FJ * wm + 16 * j) * 2 * TNB + (n - n0);
+                v = fold_apply(acc[i][j], ft.mu[j], ft.rs[j], *(const f32x4*)cf, *(const f32x4*)(cf + TNB));
+            } else {
+                v = acc[i][j] + bv;
+            }
             if constexpr (EPI == EPI_PARTIAL) {
                 float* dst = (float*)p.out + ((size_t)ks * p.M + m) * p.ldo + n;
                 if (p.out_sc1) store16_sc1(dst, v);
@@ -979,15 +1190,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     if constexpr (EPI == EPI_F16 || EPI == EPI_QKV) sat_report(amax, p.err_flag);
 }
 
-template <int EPI, int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
+template <int EPIX, int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr) {
-    epilogue<EPI, FI, FJ, WM, WN, WOFF, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc);   // (the last argument is not read without PRE)
+    epilogue<EPIX, FI, FJ, WM, WN, WOFF, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc);   // (the last argument is not read without PRE)
 }
 
-template <int EPI, int NS, int WM, int FJ>
+template <int EPIX, int NS, int WM, int FJ>
 __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 : 1)) void gemm_kernel(GemmParams p) {
+    constexpr int EPI = epi_base(EPIX);
     constexpr int TM = WM * 16 * FJ;
     __shared__ __attribute__((aligned(16))) char smem[NS * (1 + TM / 128) * TILE_BYTES];
+    static_assert(NS * (1 + TM / 128) * TILE_BYTES >= TM * 256 + TM * 8 + fold_lds_bytes(TN), "the ring must cover the epilogue's LDS image");
     BlockStamps bs;
     bs.begin(p);
     int n0, m0, ks, kt0, nkt;
@@ -1010,7 +1223,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 :
         mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPI, 4, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
+    epilogue<EPIX, 4, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
 
@@ -1180,13 +1393,15 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 // M = 5760 59.4 us without, 60.5-65.4 us with; M = 11 520 115.7 vs 113.1-115.7 (profiles/round2/dephase_sweep.txt).  A block does not
 // run faster while its partner idles — its K-step is bound by its own barrier-synchronised fill / read / MFMA chain, not by a fill
 // rate shared with the partner — so an offset only moves the idle time.  The same measurement explains the ping-pong kernel below.
-template <int EPI, int NS, int FI, int FJ, int WM>
-__global__ __launch_bounds__(128 * WM, ((WM == 2 || (WM == 4 && NS == 2)) && FI <= 4) ? 2 : 1) void gemm_g_kernel(GemmParams p) {
+template <int EPIX, int NS, int FI, int FJ, int WM>
+// (second launch-bound = waves per SIMD: the 8-wave large-M tile runs two blocks per CU = 4 waves per SIMD = 128 registers)
+__global__ __launch_bounds__(128 * WM, (WM == 4 && NS == 2 && FI <= 4) ? 4 : (WM == 2 && FI <= 4) ? 2 : 1) void gemm_g_kernel(GemmParams p) {
+    constexpr int EPI = epi_base(EPIX);
     constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
     constexpr int STAGE = (4 * FI + 2 * FJ * WM) * 1024;
     // ring, or the QKV epilogue's pitched LDS image + token table (qkv_staged), whichever is larger
     constexpr int PNB = (TNB / 8 + 7) / 8 * 8 * 16, PTB = (TM / 8 + 7) / 8 * 8 * 16;
-    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8;
+    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8 + (epi_is_fold_consumer(EPIX) ? fold_lds_bytes(TNB) : 0);
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPIB ? NS * STAGE : EPIB];
     BlockStamps bs;
     bs.begin(p);
@@ -1208,8 +1423,43 @@ __global__ __launch_bounds__(128 * WM, ((WM == 2 || (WM == 4 && NS == 2)) && FI 
         mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPI, FI, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
+    epilogue<EPIX, FI, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
+}
+
+// Grouped launch (launch_gemm_grouped): blockIdx.y selects one of several independent GEMMs that share M and K — the c1 / c2 tables of
+// the LayerNorm fold, 2 x 65 products of the per-frame (1 + scale) and shift vectors with every to_qkv / fc1 / final weight, in ONE launch
+// per forward (or per generated frame in the sampler).  128 x 96 tiles on the piece-granular main loop, plain f32 epilogue; a group with
+// fewer tiles than gridDim.x lets the surplus blocks exit.
+template <int NS, int FI, int FJ, int WM>
+__global__ __launch_bounds__(128 * WM, 1) void gemm_grouped_kernel(GemmParams p0, const GemmGroup* __restrict__ groups) {
+    constexpr int TNB = 32 * FI, TM = 16 * FJ * WM;
+    constexpr int STAGE = (4 * FI + 2 * FJ * WM) * 1024;
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+    GemmParams p = p0;
+    {
+        const GemmGroup* gr = groups + blockIdx.y;
+        p.X = gr->X; p.W = gr->W; p.out = gr->out; p.bias = gr->bias; p.N = gr->N; p.ldo = gr->ldo;
+    }
+    const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TNB - 1) / TNB, tiles = tiles_m * tiles_n;
+    // XCD-aware order over this group's own tile count, n fastest (co-resident blocks share the X row tile)
+    const int bid = blockIdx.x;
+    if (bid >= tiles) return;
+    const int xcd = bid & 7, qq = tiles >> 3, rr = tiles & 7;
+    const bool inrange = (bid >> 3) < qq + (xcd < rr ? 1 : 0);   // (always true for bid < tiles; keeps the map a bijection on [0, tiles))
+    const int tile_id = inrange ? (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3) : bid;
+    const int tile_m = tile_id / tiles_n, tile_n = tile_id - tile_m * tiles_n;
+    const int n0 = tile_n * TNB, m0 = tile_m * TM;
+    BlockStamps bs;
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pbias[FI];
+    auto pf = [&]() { prefetch_bias<EPI_F32, FI, WM>(p, n0, pbias); };
+    mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, 0, p.K / TK, acc, bs, pf);
+    epilogue<EPI_F32, FI, FJ, WM>(p, acc, pbias, smem, n0, m0, 0, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1402,13 +1652,14 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
     }
 }
 
-template <int EPI, int NS, int FI, int FJ, int WN, int WM, int NL>
+template <int EPIX, int NS, int FI, int FJ, int WN, int WM, int NL>
 __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmParams p) {
+    constexpr int EPI = epi_base(EPIX);
     constexpr int TNB = 16 * FI * WN, TM = 16 * FJ * WM;
     constexpr int STAGE = (2 * FI * WN + 2 * FJ * WM) * 1024;
     // ring, or the QKV epilogue's pitched LDS image + token table (qkv_staged), whichever is larger
     constexpr int PNB = (TNB / 8 + 7) / 8 * 8 * 16, PTB = (TM / 8 + 7) / 8 * 8 * 16;
-    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8;
+    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8 + (epi_is_fold_consumer(EPIX) ? fold_lds_bytes(TNB) : 0);
     extern __shared__ __attribute__((aligned(16))) char smem_l[];
     static_assert(NS * STAGE >= EPIB, "the ring must cover the epilogue's LDS image");
     char* smem = smem_l;
@@ -1443,19 +1694,19 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
         if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pfq);
         else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pfq);
         GTAV_STAMP(bs.t[2]);
-        epilogue<EPI, FI, FJ, WM, WN, NL, true>(p, acc, pbias, smem, n0, m0, ks, tr, prope);
+        epilogue<EPIX, FI, FJ, WM, WN, NL, true>(p, acc, pbias, smem, n0, m0, ks, tr, prope);
     } else if constexpr (EPI == EPI_QKV) {
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
         auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
         if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         GTAV_STAMP(bs.t[2]);
-        epilogue<EPI, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
+        epilogue<EPIX, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
     } else {
         auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
         mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         GTAV_STAMP(bs.t[2]);
-        epilogue<EPI, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
+        epilogue<EPIX, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
     }
     bs.end(p);
 }
@@ -1593,6 +1844,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
     bs.end(p);
 }
 
+#ifdef GTAV_EXPERIMENTS   // measured slower than shape 12 (profiles/round2/pp_stamps_v1.txt): not in the product library
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent ping-pong GEMM for large M (shape 16): one 1024-thread block per CU, two groups of 8 waves.
 //
@@ -1912,12 +2164,16 @@ __global__ __launch_bounds__(1024, 1) void gemm_pp_kernel(GemmParams p) {
 }
 
 
+#endif   // GTAV_EXPERIMENTS (ping-pong kernel)
+
 }  // namespace
 
 // Shape / ring-depth overrides: they select among kernels that all compute the same result (the parity tests force every
 // shape through them).  The debug bits (skip fills / skip MFMA: WRONG results, timing only) exist only in the
 // -DGTAV_EXPERIMENTS build, which also reads GTAV_GEMM_DEBUG / GTAV_GEMM_SHAPE for whole-bench A/B runs.
-static int g_force_stages = 0, g_debug = GTAV_ENV_INT("GTAV_GEMM_DEBUG", 0), g_force_wm = GTAV_ENV_INT("GTAV_GEMM_SHAPE", 0);
+// (per THREAD, like the handles: a test that forces a shape does not change what another thread's handle launches)
+static thread_local int g_force_stages = 0, g_force_wm = GTAV_ENV_INT("GTAV_GEMM_SHAPE", 0);
+static int g_debug = GTAV_ENV_INT("GTAV_GEMM_DEBUG", 0);
 void gemm_set_stages(int ns) { g_force_stages = ns; }
 void gemm_set_wm(int wm) { g_force_wm = wm; }
 #ifdef GTAV_EXPERIMENTS
@@ -1968,8 +2224,11 @@ static int device_cus(int* dev_out) {
 // barrier-synchronised waves serialise into fill / read / MFMA phases, where two independent co-resident blocks interleave them.
 // fc1 at M = 5760: 71-76 us against 57 us for shape 12.  Not selected by the heuristic (GTAV_PP=1 in the experiments build or a
 // forced shape 16 run it); the de-phased shape 12 above gets the same overlap with 16 computing waves.
-static int g_pp_enable = GTAV_ENV_INT("GTAV_PP", 0);
 static int g_l_for_8 = GTAV_ENV_INT("GTAV_L_FOR_8", 1);   // experiments build: 0 keeps the 96 x 96 tile (shape 8) where the cost model picks it
+#ifndef GTAV_EXPERIMENTS
+bool gemm_pp_ok(int, int, int, int) { return false; }   // the ping-pong kernel (shape 16) is compiled into the experiments build only
+#else
+static int g_pp_enable = GTAV_ENV_INT("GTAV_PP", 0);
 bool gemm_pp_ok(int M, int N, int K, int epi) {
     if (!(epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_QKV || epi == EPI_RESID)) return false;
     if (K % TK != 0 || K / TK < 14 || M % 8 != 0 || N % 8 != 0) return false;
@@ -1997,6 +2256,7 @@ static int launch_pp(const GemmParams& p, hipStream_t stream) {
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
+#endif   // GTAV_EXPERIMENTS (ping-pong launcher)
 
 // loader-wave kernels: dynamic LDS above 64 KiB needs the per-device opt-in once per instantiation
 // block -> tile map constants of the loader-wave kernels (tile_map_fast)
@@ -2081,17 +2341,30 @@ template <int EPI>
 static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hipStream_t stream) {
     GemmParams p = p_in;
     auto set_gn = [&](int tmb, int tnb) { p.tm.gn = choose_gn(p.M, p.N, p.K, tmb, tnb, splitk); };
+    // the LayerNorm-fold epilogues are instantiated for the shapes the heuristic can pick for them (2, 3, 11, 12, 14, 20)
+    constexpr bool FOLDISH = EPI == EPI_RESID_FOLD || epi_is_fold_consumer(EPI);
+    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 14 || shape == 20,
+                                        "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
+    if constexpr (!FOLDISH) {
+#ifdef GTAV_EXPERIMENTS
+    // measured slower than the shapes the heuristic picks: kept for A/B runs in the experiments build only
     if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
     if (shape == 23) return launch_l<EPI, 4, 4, 3, 2, 2, 4>(p, splitk, stream);   // 128 x 96, 4 compute waves of 64 x 48 + 4 loader waves
     if (shape == 25) return launch_l<EPI, 5, 2, 3, 4, 2, 4>(p, splitk, stream);   // shape 20 with a 5-stage ring (140 KiB)
+#else
+    GTAV_REQUIRE(shape != 8 && shape != 9 && shape != 16 && shape != 21 && shape != 23 && shape != 25,
+                 "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
+#endif
+    }
     // (a 128 x 128 loader-wave tile — 8 compute waves of 32 x 64 — was 12 % faster than shape 3 back to back and equal in the training step's
     // weight-gradient GEMMs, which are bound by the fabric traffic of their 118 MB of operands: not kept)
     // (Round 2 also measured one-block-per-CU large tiles on mainloop_g's half-K-step pipeline — 256 x 192, 192 x 192 and
     // 256 x 144 with 8 / 6 waves of 128 x 48 / 96 x 48 — and the 256 x 128 loader-wave tile, shape 21: all correct, all 5-30 %
     // SLOWER than the two-blocks-per-CU 128 x 192 tile at M = 5760 / 11 520, profiles/round2/gemm_large_tile_*.txt: without a
     // co-resident block the prologue and epilogue of every tile are exposed.  The 1-block shapes 30-32 were removed again.)
-    if (shape == 16) {
+#ifdef GTAV_EXPERIMENTS
+    if (shape == 16 && !FOLDISH) {
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_QKV || EPI == EPI_RESID) {
             GTAV_REQUIRE(gemm_pp_ok(p.M, p.N, p.K, EPI) || (p.K / TK >= 12 && p.M % 8 == 0 && p.N % 8 == 0),
                          "gemm: the ping-pong kernel needs K >= 768, M %% 8 == 0, N %% 8 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
@@ -2100,6 +2373,7 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
             GTAV_REQUIRE(false, "gemm: the ping-pong kernel (shape 16) has no epilogue %d", (int)EPI);
         }
     }
+#endif
     if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
         set_gn(96, 64);
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
@@ -2112,22 +2386,33 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
         set_gn(48, 64);
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384));   // 6 stages measured 6-8 % slower
+#ifdef GTAV_EXPERIMENTS
     } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
-        set_gn(96, 128);
-        const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
-        GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384));   // 3 stages 1-3 % and 5 stages 4-5 % slower
+        if constexpr (!FOLDISH) {
+            set_gn(96, 128);
+            const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
+            GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384));   // 3 stages 1-3 % and 5 stages 4-5 % slower
+        }
     } else if (shape == 8) {   // 96 x 96, 6 waves
-        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
+        if constexpr (FOLDISH || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
         } else {
             set_gn(96, 96);
             const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 96) * splitk);
             GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 3, 2, 3>), grid, dim3(384));
         }
+#endif
     } else if (shape == 7) {
-        set_gn(256, 256);
-        const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
-        GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
+#ifndef GTAV_EXPERIMENTS
+        if constexpr (EPI == EPI_QKV) {   // 15 spilled registers and never selected by the heuristic
+            GTAV_REQUIRE(false, "gemm: the 256 x 256 tile has no QKV epilogue in the product build");
+        } else
+#endif
+        if constexpr (!FOLDISH) {
+            set_gn(256, 256);
+            const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
+            GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
+        }
     } else if (shape == 3) {
         set_gn(128, TN);
         const dim3 grid(cdiv(p.M, 128) * cdiv(p.N, TN) * splitk);
@@ -2199,8 +2484,33 @@ int launch_gemm_tn(const GemmParams& p_in, hipStream_t stream) {
     return 0;
 }
 
-int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
+int launch_gemm_grouped(const GemmGroup* groups_dev, int n_groups, int max_N, int M, int K, hipStream_t stream) {
+    GTAV_REQUIRE(groups_dev && n_groups > 0 && n_groups < 65536 && M > 0 && max_N > 0 && K > 0 && K % TK == 0, "gemm_grouped: bad arguments");
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = M; p.N = max_N; p.K = K; p.splitk = 1;
+    const dim3 grid(cdiv(M, 96) * cdiv(max_N, 128), n_groups);
+    hipLaunchKernelGGL((gemm_grouped_kernel<4, 4, 2, 3>), grid, dim3(384), 0, stream, p, groups_dev);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     GemmParams p = p_in;
+    const int epi = epi_base(epi_x);
+    const bool fold_c = epi_is_fold_consumer(epi_x), fold_p = epi_x == EPI_RESID_FOLD;
+    if (fold_c || fold_p) {
+        GTAV_REQUIRE(p.f_P > 0 && p.f_P % 16 == 0 && p.M % p.f_P == 0, "gemm/fold: %d tokens per frame must be a multiple of 16 and divide M=%d", p.f_P, p.M);
+        if (fold_c) {
+            GTAV_REQUIRE(p.f_stats && p.f_c1 && p.f_c2 && p.f_ldc >= p.N && p.f_nslot == p.K / 32 && p.f_nslot % 8 == 0,
+                         "gemm/fold: consumer needs the row statistics (K/32 = %d slots, a multiple of 8) and the c1 / c2 tables", p.K / 32);
+            GTAV_REQUIRE(!p.bias, "gemm/fold: the bias of a fold consumer lives in its c2 table");
+            if (epi == EPI_QKV) GTAV_REQUIRE(p.qkv_mode == QKV_TEMPORAL || p.S % 16 == 0, "gemm/fold: spatial QKV needs S %% 16 == 0");
+        } else {
+            GTAV_REQUIRE(p.gate && p.f_scale && p.f_stats_out && p.f_a && p.N % 64 == 0 && p.ldo >= p.N,
+                         "gemm/fold: producer needs gate, next scale, statistics and operand buffers, N %% 64 == 0");
+        }
+    }
     p.debug = g_debug & (3 | 16 | 32 | 2048 | 8192 | 16384);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
     p.stamps = nullptr;
 #ifdef GTAV_EXPERIMENTS
@@ -2228,6 +2538,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         GTAV_REQUIRE(p.out && p.ldo >= p.N && p.ldo % 4 == 0, "gemm: bad output ldo=%d", p.ldo);
         if (epi == EPI_RESID && p.gate) GTAV_REQUIRE(p.rows_per_gate > 0, "gemm/resid: rows_per_gate");
         if (epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_F16_TILED) GTAV_REQUIRE(p.ldo % 64 == 0, "gemm/gelu: tile-major output needs ldo %% 64 == 0");
+        if (fold_p) GTAV_REQUIRE(p.splitk <= 1, "gemm/fold: the producer epilogue needs the complete sum (no split-K)");
         if (epi == EPI_PARTIAL) {
             splitk = p.splitk;
             GTAV_REQUIRE(splitk >= 1 && (p.K / TK) % splitk == 0, "gemm/partial: splitk=%d must divide K/64=%d", splitk, p.K / TK);
@@ -2238,6 +2549,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     //     4-stage ring — 17-25 % faster than 4 waves at M = 720;
     //   larger grids: 4 waves, 2-stage ring, two co-resident blocks per CU; the 128 x 256 / 8-wave tile (shape 4) ties it.
     const int blocks128 = cdiv(p.M, 128) * cdiv(p.N, TN) * splitk;
+    const bool foldish = fold_c || fold_p;
     int wm = g_force_wm ? g_force_wm : (blocks128 <= 256 ? 3 : 2);
     if (!g_force_wm && blocks128 <= 256) {
         // small M: every block is bound by its own L2->LDS fill (~65 GB/s per CU), i.e. by (TN + TM) x K bytes, and the grid
@@ -2268,12 +2580,21 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
     // store burst per round of 256 tiles) is not hidden by a co-resident block: they win only where the K loop is long
     // relative to the output and the grid is one well-filled round — the N = 1024 residual GEMMs at M >= 11 520
     // (profiles/round1/v12_gemm_256tile_microbench.txt: fc2 129 -> 98 us, out-proj 40 -> 35 us).
-    if (!g_force_wm && splitk == 1 && epi != EPI_QKV && p.N % 256 == 0 && p.N <= 1024 && p.K >= 1024) {
+    if (!g_force_wm && splitk == 1 && epi != EPI_QKV && !foldish && p.N % 256 == 0 && p.N <= 1024 && p.K >= 1024) {
         const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
         if (t256 * 10 >= rounds * 256 * 7) wm = 7;
     }
     int ns = g_force_stages ? g_force_stages : (wm == 12 ? 2 : wm >= 8 ? 4 : wm == 3 ? 4 : 2);   // (shapes 20+ carry their ring depth in the template)
-    switch (epi) {
+    // a wave's token span (16 FJ) must not exceed a frame: the skinny 64 x 48 / 64 x 96 tiles span 16 / 32 tokens, the others 48-64
+    if (foldish) {
+        const int span = wm == 2 ? 64 : (wm == 3 || wm == 14) ? 32 : wm == 11 ? 16 : 48;
+        GTAV_REQUIRE(p.f_P >= span, "gemm/fold: frames of %d tokens are shorter than the token span (%d) of a wave of block shape %d", p.f_P, span, wm);
+    }
+    switch (epi_x) {
+        case EPI_RESID_FOLD: return launch_epi<EPI_RESID_FOLD>(p, ns, wm, splitk, stream);
+        case EPI_QKV_FOLD: return launch_epi<EPI_QKV_FOLD>(p, ns, wm, splitk, stream);
+        case EPI_GELU_TANH_FOLD: return launch_epi<EPI_GELU_TANH_FOLD>(p, ns, wm, splitk, stream);
+        case EPI_F32_FOLD: return launch_epi<EPI_F32_FOLD>(p, ns, wm, splitk, stream);
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);
         case EPI_GELU_TANH: return launch_epi<EPI_GELU_TANH>(p, ns, wm, splitk, stream);
@@ -2282,7 +2603,7 @@ int launch_gemm(const GemmParams& p_in, int epi, hipStream_t stream) {
         case EPI_QKV: return launch_epi<EPI_QKV>(p, ns, wm, splitk, stream);
         case EPI_PARTIAL: return launch_epi<EPI_PARTIAL>(p, ns, wm, splitk, stream);
         case EPI_F16_TILED: return launch_epi<EPI_F16_TILED>(p, ns, wm, splitk, stream);
-        default: GTAV_REQUIRE(false, "gemm: unknown epilogue %d", epi);
+        default: GTAV_REQUIRE(false, "gemm: unknown epilogue %d", epi_x);
     }
     return 0;
 }

@@ -28,7 +28,13 @@ struct StepParams {
 int launch_step_setup(StepParams* dst, const StepParams& v, int* frame_idx, int* mod_rows, int* last_rows, int* changed, int B, int Tq, int T, int F,
                       int use_cur, hipStream_t stream);
 // current-step conditioning table: cur[slot] <- table[rows[slot]] (W floats) for the slots step_setup flagged in `changed`
-int launch_gather_rows(const float* table, const int* rows, const int* changed, float* cur, int slots, int W, hipStream_t stream);
+// (table2 / cur2 / W2: optional second table gathered by the same launch — the c1 / c2 tables of the LayerNorm fold)
+int launch_gather_rows(const float* table, const int* rows, const int* changed, float* cur, int slots, int W, const float* table2, float* cur2, int W2,
+                       hipStream_t stream);
+// LayerNorm fold (gemm.h EPI_*_FOLD): fp16 tile-major X operands [n_groups][Rp][D] of the grouped table GEMM from the fp32 modulation table:
+// group g = columns [col[g], col[g] + D) of mod [R][MODW]; is_scale[g] != 0 stores 1 + (scale + 1e-6).  col / is_scale are device arrays.
+int launch_ctab_inputs(const float* mod, int MODW, int R, int Rp, int D, const int* col, const int* is_scale, int n_groups, f16* sx, size_t group_stride,
+                       hipStream_t stream);
 // Conditioning inputs for a whole generated frame (rows laid out as above, n_steps row sets for frame `cur`).
 int launch_cond_inputs_frame(int rows, int B, int T, int F, int start, int cur, int t_ctx, const int* t_steps, const float* sincos,
                              float* E, const float* actions, int A, float* HC, int ldhc, int D, int Apad, int* err_flag,
@@ -105,6 +111,7 @@ int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
 // cs[pos][k] = (cos[pos][2k], sin[pos][2k]) for k < 32: the GEMM epilogue's interleaved RoPE table
 int launch_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int npos, hipStream_t stream);
 int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
+int launch_axpy_f32(float* y, const float* x, float alpha, size_t n, hipStream_t stream);   // y += alpha x (x may alias y)
 
 // Conditioning inputs (model/dit.py:96-118,359-364) for `rows` (b, frame) pairs, row r = (r / Tq, r % Tq):
 //   E[r][0:256] = sincos_table[t_r],  t_r = t64 ? t64[r] : (r % Tq == Tq - 1 ? t_cur : t_ctx)   (train_dit.py:64-91)
@@ -171,12 +178,15 @@ struct AdamParam {
     f16* wT; int RpT;                      // tile-major fp16 W^T (logical row length RpT = round_up(R, 64)), or null
 };
 struct AdamItem { int param; unsigned start; };   // GEMM weight: tile index (row-major over 64 x 64 tiles); fp32 parameter: first element
+// ctl [8] floats: [0] sum of squares of the scaled gradients, [1] step coefficient (0 = step skipped), [2] skipped steps, [3] unscaled gradient
+// norm, [4] applied steps (the Adam step count), [5] / [6] bias corrections of the step being applied (written by clip_coef on the device)
 int launch_adamw_multi(const AdamParam* params, const AdamItem* items, int n_items, const float* ctl, float lr, float beta1, float beta2, float eps, float wd,
-                       float bc1, float bc2, hipStream_t stream);
+                       hipStream_t stream);
 int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream);
-int launch_clip_coef(float* ctl, float inv_scale, float max_norm, hipStream_t stream);
+// err_flag (optional): ERR_F16_SAT / ERR_NONFINITE in the handle's error word count as overflow (step skipped) and are cleared
+int launch_clip_coef(float* ctl, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream);
 int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,
-                 float wd, float bc1, float bc2, hipStream_t stream);
+                 float wd, hipStream_t stream);
 
 // ---- attention.hip -----------------------------------------------------------------------
 // Full (non-causal) attention over S tokens per (nb, head), head_dim 64 (model/attention.py:127-129, model/vae.py:101).

@@ -927,7 +927,11 @@ __global__ void ada_reduce_kernel(const float* __restrict__ part, int nchunk, si
 // Optimizer (torch.optim.AdamW semantics, train_dit.py:232-238) with the loss scale and the clipping coefficient folded in.
 //   ctl[0] = sum of squares of the SCALED gradients (sumsq_kernel, all parameters), ctl[1] = coefficient written by clip_coef_kernel:
 //   inv_scale * min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_), or 0 when the norm is not finite (overflow:
-//   the step is skipped and ctl[2] counts it).
+//   the step is skipped and ctl[2] counts it).  Overflow = a non-finite norm OR the handle's error word carrying ERR_F16_SAT /
+//   ERR_NONFINITE: every fp16 gradient / activation store saturates to +-65504 and raises that bit, so at a too-large loss scale the
+//   norm itself stays finite — the bit is what says the gradients are clipped garbage.  The bits are cleared here (consumed).
+//   ctl[4] = number of APPLIED steps (the Adam step count t: a skipped step does not advance it), ctl[5] / ctl[6] = the bias
+//   corrections 1 - beta1^t / 1 - beta2^t of the step being applied, computed here on the device so that m / v and t stay in step.
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ ctl) {
     __shared__ float red[16];
@@ -936,20 +940,33 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     const float t = block_sum(a, red);
     if (threadIdx.x == 0) atomicAdd(ctl, t);
 }
-__global__ void clip_coef_kernel(float* ctl, float inv_scale, float max_norm) {
+__global__ void clip_coef_kernel(float* ctl, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag) {
     const float norm = sqrtf(ctl[0]) * inv_scale;
-    if (!(norm == norm) || isinf(norm)) {
+    bool overflow = !(norm == norm) || isinf(norm);
+    if (err_flag) {
+        const int bits = *err_flag & (ERR_F16_SAT | ERR_NONFINITE);
+        if (bits) {
+            overflow = true;
+            atomicAnd(err_flag, ~bits);
+        }
+    }
+    if (overflow) {
         ctl[1] = 0.f;
         ctl[2] += 1.f;
     } else {
         ctl[1] = inv_scale * (max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f);
+        const float t = ctl[4] + 1.0f;
+        ctl[4] = t;
+        ctl[5] = 1.0f - powf(beta1, t);
+        ctl[6] = 1.0f - powf(beta2, t);
     }
     ctl[3] = norm;
 }
 __global__ void adamw_kernel(float* __restrict__ p, int ldp, int R, int C, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             const float* __restrict__ ctl, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+                             const float* __restrict__ ctl, float lr, float beta1, float beta2, float eps, float wd) {
     const float coef = ctl[1];
     if (coef == 0.f) return;               // overflow: skip the step
+    const float bc1 = ctl[5], bc2 = ctl[6];
     const size_t total = (size_t)R * C;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C);
@@ -971,9 +988,10 @@ __global__ void adamw_kernel(float* __restrict__ p, int ldp, int R, int C, const
 // along c) and, through an LDS transpose, into the tile-major fp16 W^T (16 bytes along r): the separate convert passes (two more reads
 // of the 0.8 GB of masters, 370 launches) and 300 per-parameter AdamW launches are gone.
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamParam* __restrict__ params, const AdamItem* __restrict__ items, const float* __restrict__ ctl,
-                                                          float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2) {
+                                                          float lr, float beta1, float beta2, float eps, float wd) {
     const float coef = ctl[1];
     if (coef == 0.f) return;               // overflow: skip the step
+    const float bc1 = ctl[5], bc2 = ctl[6];
     const AdamItem it = items[blockIdx.x];
     const AdamParam P = params[it.param];
     const float decay = 1.0f - lr * wd, step = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
@@ -1204,20 +1222,20 @@ int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream) {
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_clip_coef(float* ctl, float inv_scale, float max_norm, hipStream_t stream) {
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, ctl, inv_scale, max_norm);
+int launch_clip_coef(float* ctl, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, ctl, inv_scale, max_norm, beta1, beta2, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
 int launch_adamw_multi(const AdamParam* params, const AdamItem* items, int n_items, const float* ctl, float lr, float beta1, float beta2, float eps, float wd,
-                       float bc1, float bc2, hipStream_t stream) {
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_items), dim3(256), 0, stream, params, items, ctl, lr, beta1, beta2, eps, wd, bc1, bc2);
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(n_items), dim3(256), 0, stream, params, items, ctl, lr, beta1, beta2, eps, wd);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
 int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,
-                 float wd, float bc1, float bc2, hipStream_t stream) {
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, p, ldp, R, C, g, m, v, ctl, lr, beta1, beta2, eps, wd, bc1, bc2);
+                 float wd, hipStream_t stream) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, stream, p, ldp, R, C, g, m, v, ctl, lr, beta1, beta2, eps, wd);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

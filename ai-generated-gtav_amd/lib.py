@@ -60,6 +60,7 @@ SIGNATURES = {
     "gtav_dit_train_param_count": [_p, C.POINTER(C.c_int64)],
     "gtav_dit_train_enable": [_p, _p, _l],
     "gtav_dit_set_loss_scale": [_p, _f],
+    "gtav_dit_set_grad_divisor": [_p, _f],
     "gtav_dit_zero_grad": [_p, _p],
     "gtav_dit_train_forward": [_p, _p, _p, _p, _p, _i, _i, _p],
     "gtav_dit_train_backward": [_p, _p, _p, _p],
@@ -69,8 +70,13 @@ SIGNATURES = {
     "gtav_dit_train_get_residual": [_p, _i, _p, _l, _p],
     "gtav_dit_adamw_step": [_p, _f, _f, _f, _f, _f, _f, _p],
     "gtav_dit_train_stats": [_p, C.POINTER(C.c_float), _p],
+    "gtav_dit_get_opt_state": [_p, C.c_char_p, _p, _p, _l, _p],
+    "gtav_dit_set_opt_state": [_p, C.c_char_p, _p, _p, _l, _p],
+    "gtav_dit_get_opt_step": [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _p],
+    "gtav_dit_set_opt_step": [_p, _l, _l, _p],
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_set_fused_temporal": [_p, _i],
+    "gtav_dit_set_fold": [_p, _i, _i, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_comm_unique_id": [_p],
@@ -91,6 +97,7 @@ SIGNATURES = {
     "gtav_add_noise": [_p, _p, _p, _p, _i, _i, _f, _p],
     "gtav_vtarget": [_p, _p, _p, _p, _i, _i, _f, _p],
     "gtav_mse": [_p, _l, _p, _l, _i, _i, _p, _p],
+    "gtav_axpy_f32": [_p, _p, _f, _l, _p],
     "gtav_frames_to_u8": [_p, _p, _i, _i, _i, _p],
     "gtav_moments_to_latents": [_p, _p, _i, _i, _i, _i, _f, _p],
     "gtav_latents_to_tokens": [_p, _p, _i, _i, _i, _p],

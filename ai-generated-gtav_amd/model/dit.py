@@ -177,6 +177,8 @@ class DiT(_HipModule):
     def max_frames(self, v):
         self._max_frames = int(v)
         if v > self._capacity_t:
+            if self._handle and self._trainable and self._grads is not None:
+                raise RuntimeError("a trainable DiT cannot grow its window after training was enabled: construct it with the largest max_frames")
             self._capacity_t = int(v)
             self._free()
 
@@ -212,14 +214,16 @@ class DiT(_HipModule):
 
     # ------------------------------------------------------------------------------------------
     def _ensure(self, B: int, T: int, cond_rows: int = 0):
-        if cond_rows > max(self._capacity_rows, self._capacity_b * self._capacity_t):
-            self._capacity_rows = cond_rows
-            self._free()
-        if T > self._capacity_t:
-            self._capacity_t = T
-            self._free()
-        if B > self._capacity_b:
-            self._capacity_b = B
+        grow = (cond_rows > max(self._capacity_rows, self._capacity_b * self._capacity_t)) or T > self._capacity_t or B > self._capacity_b
+        if grow and self._handle and self._trainable and self._grads is not None:
+            # the fp32 masters and the AdamW state live only in the handle: refuse BEFORE anything is destroyed (the handle stays usable)
+            raise RuntimeError(f"a trainable DiT cannot grow its workspace after training was enabled (batch {B} > {self._capacity_b}, window {T} > "
+                               f"{self._capacity_t} or {cond_rows} conditioning rows > {max(self._capacity_rows, self._capacity_b * self._capacity_t)}): "
+                               "size it with max_batch / max_frames / reserve() before the first step")
+        if grow:
+            self._capacity_rows = max(self._capacity_rows, cond_rows)
+            self._capacity_t = max(self._capacity_t, T)
+            self._capacity_b = max(self._capacity_b, B)
             self._free()
         if not self._handle:
             L = _lib.load()
@@ -229,16 +233,17 @@ class DiT(_HipModule):
                 _lib.check(L.gtav_dit_create(C.byref(cfg), C.byref(self._handle)))
                 if getattr(self, "_fused_temporal", False):
                     _lib.check(L.gtav_dit_set_fused_temporal(self._handle, 1))
+                if getattr(self, "_fold", None) is not None:
+                    _lib.check(L.gtav_dit_set_fold(self._handle, *self._fold))
                 if self._trainable:
-                    if self._grads is not None:
-                        raise RuntimeError("a trainable DiT cannot grow its workspace after the first step (the optimizer state lives in the "
-                                           "handle): size it with max_batch / max_frames or reserve() first")
                     n = C.c_int64(0)
                     _lib.check(L.gtav_dit_train_param_count(self._handle, C.byref(n)))
                     # one contiguous fp32 gradient arena owned by torch: a single all-reduce covers the whole model (train.py)
                     self._grads = torch.zeros(n.value, device=self.device, dtype=torch.float32)
                     _lib.check(L.gtav_dit_train_enable(self._handle, self._grads.data_ptr(), n.value))
                     _lib.check(L.gtav_dit_set_loss_scale(self._handle, self._loss_scale))
+                    if self.grad_divisor != 1.0:
+                        _lib.check(L.gtav_dit_set_grad_divisor(self._handle, self.grad_divisor))
             self._dirty = True
         if self._dirty:
             gh, gw = self.input_h // self.patch_size, self.input_w // self.patch_size
@@ -340,7 +345,7 @@ class DiT(_HipModule):
         out = torch.empty(shp, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().gtav_dit_get_grad(self._handle, name.encode(), out.data_ptr(), out.numel(), _lib.current_stream()))
-        return out / self._loss_scale
+        return out / (self._loss_scale * self.grad_divisor)
 
     def residual_after(self, k: int, B: int, T: int) -> torch.Tensor:
         """Residual stream of the last forward_train after k branch additions (4 per block; k = 4 (i + 1) is the output of block i),
@@ -363,6 +368,50 @@ class DiT(_HipModule):
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().gtav_dit_train_stats(self._handle, buf, _lib.current_stream()))
         return buf[1] != 0.0, int(buf[2]), float(buf[3])
+
+    def opt_state_dict(self) -> Dict[str, torch.Tensor]:
+        """AdamW state of every trainable parameter as CPU tensors: "m.<name>" / "v.<name>" (first / second moments, state-dict shapes)
+        plus "step" = [applied steps, skipped steps] — what accelerator.save_state keeps for the optimizer (train_dit.py:765-800)."""
+        assert self._trainable and self._handle, "no optimizer state: construct with trainable=True and run a step (or reserve()) first"
+        L = _lib.load()
+        out = {}
+        with torch.cuda.device(self.device):
+            for k, shp in self._shapes().items():
+                m = torch.empty(shp, device=self.device, dtype=torch.float32)
+                v = torch.empty_like(m)
+                _lib.check(L.gtav_dit_get_opt_state(self._handle, k.encode(), m.data_ptr(), v.data_ptr(), m.numel(), _lib.current_stream()))
+                out["m." + k], out["v." + k] = m.cpu(), v.cpu()
+            a, sk = C.c_int64(0), C.c_int64(0)
+            _lib.check(L.gtav_dit_get_opt_step(self._handle, C.byref(a), C.byref(sk), _lib.current_stream()))
+        out["step"] = torch.tensor([a.value, sk.value], dtype=torch.int64)
+        return out
+
+    def load_opt_state_dict(self, state: Dict[str, torch.Tensor]):
+        """Inverse of opt_state_dict (the weights themselves: load_state_dict).  The handle is built first if it does not exist yet."""
+        assert self._trainable, "construct the model with trainable=True"
+        self._ensure(self._capacity_b, self._capacity_t)
+        L = _lib.load()
+        with torch.cuda.device(self.device):
+            for k, shp in self._shapes().items():
+                m = state["m." + k].to(self.device, torch.float32).contiguous()
+                v = state["v." + k].to(self.device, torch.float32).contiguous()
+                if tuple(m.shape) != tuple(shp) or tuple(v.shape) != tuple(shp):
+                    raise RuntimeError(f"load_opt_state_dict: {k} has shape {tuple(m.shape)}, expected {tuple(shp)}")
+                _lib.check(L.gtav_dit_set_opt_state(self._handle, k.encode(), m.data_ptr(), v.data_ptr(), m.numel(), _lib.current_stream()))
+            st = state["step"]
+            _lib.check(L.gtav_dit_set_opt_step(self._handle, int(st[0]), int(st[1]), _lib.current_stream()))
+            torch.cuda.synchronize()
+
+    @property
+    def grad_divisor(self) -> float:
+        return getattr(self, "_grad_divisor", 1.0)
+
+    @grad_divisor.setter
+    def grad_divisor(self, v: float):
+        """The gradient arena holds the SUM over this many ranks (all-reduce SUM): the optimizer step divides, the arena is not rescaled."""
+        self._grad_divisor = float(v)
+        if self._handle:
+            _lib.check(_lib.load().gtav_dit_set_grad_divisor(self._handle, self._grad_divisor))
 
     def pull_weights(self):
         """Copies the trained fp32 masters from the GPU back into the host state dict (checkpoints, state_dict())."""
@@ -430,6 +479,13 @@ class DiT(_HipModule):
         self._fused_temporal = bool(enable)
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fused_temporal(self._handle, int(self._fused_temporal)))
+
+    def set_fold(self, mode: int, min_tokens_a: int = -1, min_tokens_b: int = -1):
+        """LayerNorm fold (gtav_dit_set_fold): 0 = separate LayerNorm launches everywhere, 1 = folded into the GEMM epilogues where that is
+        measured faster (default), 2 = every seam at every size.  min_tokens_* < 0 keep the thresholds of mode 1."""
+        self._fold = (int(mode), int(min_tokens_a), int(min_tokens_b))
+        if self._handle:
+            _lib.check(_lib.load().gtav_dit_set_fold(self._handle, *self._fold))
 
     def check(self):
         with torch.cuda.device(self.device):

@@ -18,31 +18,26 @@ def encode_frames(vae, frames: torch.Tensor) -> torch.Tensor:
     return vae_encode(frames, vae, frames.shape[1])
 
 
-@torch.inference_mode()
-def forward_loss(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx: torch.Tensor,
-                 ctx_noise_idx: torch.Tensor, ctx_noise: torch.Tensor, noise: torch.Tensor, noise_steps: int = 50,
-                 n_prompt_frames: int = 4, noise_abs_max: float = 20.0, clamp_min: float = 1e-6, keep_activations: bool = False):
-    """train_dit.py:590-650 for clips of n_prompt_frames + 1 frames. Returns (loss (1,) tensor, v_pred, v_target).
-    keep_activations: run the DiT through forward_train so that dit.backward_(v_pred, v_target) can follow."""
+def _frame_step(dit, latents, actions, i, target_noise_idx, ctx_noise_idx, ctx_noise, noise, nr, ac, noise_abs_max, keep_activations):
+    """One iteration of the frame loop of `_shared_step` (train_dit.py:590-650) for target frame i: returns (loss (1,), v_pred, v_target)."""
     dev = dit.device
     L = _lib.load()
-    B, total = latents.shape[:2]
-    assert total == n_prompt_frames + 1
-    nr = torch.linspace(0, 999, noise_steps + 1).long()                                 # train_dit.py:309-315
-    ac = _alphas_cumprod(clamp_min)
-    i = n_prompt_frames
-    ctx_noise_idx = torch.minimum(ctx_noise_idx.cpu(), target_noise_idx.cpu())       # train_dit.py:587
+    B = latents.shape[0]
+    tgt = [int(v) for v in target_noise_idx]
+    ctx = [min(int(c), t_) for c, t_ in zip(ctx_noise_idx, tgt)]                       # train_dit.py:587 torch.minimum
     start = max(0, i + 1 - dit.max_frames)
     t = torch.zeros((B, i + 1), dtype=torch.long)
-    t[:, :-1] = nr[ctx_noise_idx].unsqueeze(1)
-    t[:, -1] = nr[target_noise_idx.cpu()]
+    t[:, :-1] = nr[torch.tensor(ctx)].unsqueeze(1)
+    t[:, -1] = nr[torch.tensor(tgt)]
     t = t[:, start:]
     W = t.shape[1]
     x_curr = latents[:, start: i + 1].to(dev, torch.float32).contiguous()
     a = actions[:, start: i + 1].to(dev, torch.float32).contiguous() if actions is not None else None
     n = x_curr[0, 0].numel()
     alpha = ac[t].to(dev).contiguous()                                                  # (B, W)
-    all_noise = torch.cat([ctx_noise.to(dev, torch.float32), noise.to(dev, torch.float32)], dim=1).contiguous()
+    all_noise = torch.empty_like(x_curr)                                                # copies only: torch is storage here
+    all_noise[:, :-1] = ctx_noise.to(dev, torch.float32)
+    all_noise[:, -1:] = noise.to(dev, torch.float32)
     x_noisy = torch.empty_like(x_curr)
     stream = _lib.current_stream()
     with torch.cuda.device(dev):
@@ -60,6 +55,53 @@ def forward_loss(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], ta
         vp_last = v_pred[:, -1]
         _lib.check(L.gtav_mse(vp_last.data_ptr(), v_pred.stride(0), v_target.data_ptr(), n, B, n, out.data_ptr(), stream))
     return out[:1], v_pred, v_target.reshape(B, 1, *x_curr.shape[2:])
+
+
+def _per_frame(arg, n_iter, what):
+    """A per-iteration argument of the frame loop: a list / tuple of n_iter entries, or (one target frame) the entry itself."""
+    if isinstance(arg, (list, tuple)):
+        assert len(arg) == n_iter, f"{what}: {len(arg)} entries for {n_iter} target frames"
+        return list(arg)
+    if torch.is_tensor(arg) and what.endswith("idx") and arg.dim() == 2:
+        assert arg.shape[0] == n_iter, f"{what}: {arg.shape[0]} rows for {n_iter} target frames"
+        return [arg[k] for k in range(n_iter)]
+    assert n_iter == 1, f"{what}: clips with {n_iter} target frames need one entry per target frame"
+    return [arg]
+
+
+@torch.inference_mode()
+def forward_loss(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx, ctx_noise_idx, ctx_noise, noise,
+                 noise_steps: int = 50, n_prompt_frames: int = 4, noise_abs_max: float = 20.0, clamp_min: float = 1e-6,
+                 keep_activations: bool = False, on_frame=None):
+    """train_dit.py:590-682 `_shared_step`: for every target frame i in [n_prompt_frames, total_frames) noise the window that ends at i,
+    run the DiT over it, MSE against the v-target of frame i; returns (mean loss over the target frames (1,), v_pred, v_target) of the LAST
+    target frame.  The shipped dataset has ONE target frame (5-frame clips): then the draws are plain tensors — target_noise_idx /
+    ctx_noise_idx (B,), ctx_noise (B, W - 1, C, h, w), noise (B, 1, C, h, w).  Longer clips pass one entry per target frame (lists, or
+    (n, B) index tensors); the window of target frame i holds min(i + 1, max_frames) frames.
+    keep_activations: run the DiT through forward_train so that dit.backward_(v_pred, v_target) can follow; on_frame(k, v_pred, v_target)
+    is called after target frame k's forward (the trainer differentiates each frame's loss right there, train_dit.py:679-680)."""
+    B, total = latents.shape[:2]
+    n_iter = total - n_prompt_frames
+    assert n_iter >= 1, "forward_loss: no target frame behind the prompt frames"
+    tgts, ctxs = _per_frame(target_noise_idx, n_iter, "target_noise_idx"), _per_frame(ctx_noise_idx, n_iter, "ctx_noise_idx")
+    cns, nzs = _per_frame(ctx_noise, n_iter, "ctx_noise"), _per_frame(noise, n_iter, "noise")
+    nr = torch.linspace(0, 999, noise_steps + 1).long()                                 # train_dit.py:309-315
+    ac = _alphas_cumprod(clamp_min)
+    total_loss = None
+    for k, i in enumerate(range(n_prompt_frames, total)):
+        loss, v_pred, v_target = _frame_step(dit, latents, actions, i, tgts[k].cpu().tolist(), ctxs[k].cpu().tolist(), cns[k], nzs[k], nr, ac,
+                                             noise_abs_max, keep_activations)
+        if on_frame is not None:
+            on_frame(k, v_pred, v_target)
+        if total_loss is None:
+            total_loss = loss
+        else:
+            with torch.cuda.device(dit.device):                                         # total_loss += loss (train_dit.py:676), as a HIP kernel
+                _lib.check(_lib.load().gtav_axpy_f32(total_loss.data_ptr(), loss.data_ptr(), 1.0, 1, _lib.current_stream()))
+    if n_iter > 1:
+        with torch.cuda.device(dit.device):                                             # / (total_frames - n_prompt_frames) (train_dit.py:682)
+            _lib.check(_lib.load().gtav_axpy_f32(total_loss.data_ptr(), total_loss.data_ptr(), 1.0 / n_iter - 1.0, 1, _lib.current_stream()))
+    return total_loss, v_pred, v_target
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -153,37 +195,56 @@ def cosine_with_min_lr(step: int, base_lr: float, num_warmup_steps: int, num_tra
 
 
 def all_reduce_gradients(dit, world_size: int):
-    """Data-parallel gradient averaging (what DDP does under accelerate): one all-reduce over the contiguous arena, in place."""
+    """Data-parallel gradient averaging (what DDP does under accelerate): ONE all-reduce (SUM) over the contiguous arena; the division by
+    the world size is not a pass over the 2.4 GB arena but a factor of the optimizer's step coefficient (dit.grad_divisor ->
+    gtav_dit_set_grad_divisor): arena / (loss scale x world) is the rank average."""
     if world_size > 1:
         import torch.distributed as dist
         dist.all_reduce(dit.grad_arena, op=dist.ReduceOp.SUM)
-        dit.grad_arena.div_(world_size)
+    dit.grad_divisor = float(max(1, world_size))
+
+
+_BUCKET_PREFIXES = ("external_cond.", "t_embedder.", "x_embedder.")
 
 
 def gradient_buckets(dit):
     """The all-reduce buckets of the overlapped backward, in the order their gradients become final: (phase after which the bucket is
     complete, arena offset, count).  One bucket per block (38 M floats = 151 MB for DiT-S/2: large enough for RCCL's ring over xGMI to run
     at link rate, small enough that 15 of the 16 hide behind the blocks still being differentiated), the final layer after phase 0, the
-    embedders last.  The arena is laid out in lexicographic name order, so "blocks.<l>." is one contiguous slice."""
+    embedders last.  The arena is laid out in lexicographic name order, so "blocks.<l>." is one contiguous slice.  Built and VALIDATED once per
+    model (cached on it): the buckets must be disjoint and cover the arena — a model with parameters outside these prefixes fails here, before
+    any collective is issued; prefixes the model does not have (external_cond_dim = 0) are skipped."""
+    cached = getattr(dit, "_gradient_buckets", None)
+    if cached is not None and cached[0] == dit.grad_arena.numel():
+        return cached[1]
     L = dit.depth
     buckets = [(0,) + dit.param_range("final_layer.")]
     buckets += [(L - l,) + dit.param_range(f"blocks.{l}.") for l in reversed(range(L))]
-    rest = [dit.param_range(p) for p in ("external_cond.", "t_embedder.", "x_embedder.")]
-    buckets += [(L + 1,) + r for r in rest]
+    buckets += [(L + 1,) + dit.param_range(p) for p in _BUCKET_PREFIXES]
+    buckets = [b for b in buckets if b[2] > 0]
+    spans = sorted((off, off + cnt) for _, off, cnt in buckets)
+    ok = spans and spans[0][0] == 0 and spans[-1][1] == dit.grad_arena.numel() and all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+    if not ok:
+        raise RuntimeError("gradient_buckets: the per-block / embedder slices do not tile the gradient arena (a parameter outside the known name "
+                           f"prefixes?): spans {spans[:3]} ... {spans[-2:]}, arena {dit.grad_arena.numel()}")
+    dit._gradient_buckets = (dit.grad_arena.numel(), buckets)
     return buckets
 
 
 def backward_overlapped(dit, v_pred, v_target, world_size: int, comm_stream=None, all_reduce=None):
-    """backward_ in phases with the all-reduce of each finished bucket enqueued on `comm_stream` while the compute stream differentiates
+    """backward_ in phases with the all-reduce (SUM) of each finished bucket enqueued on `comm_stream` while the compute stream differentiates
     the next block (what DDP's bucketed reducer does under accelerate).  `all_reduce(tensor)` defaults to
-    torch.distributed.all_reduce (SUM) and may be gtav_amd.comm.Comm.all_reduce_.  Gradients are averaged (divided by world_size)."""
-    import torch.distributed as dist
+    torch.distributed.all_reduce (SUM) and may be gtav_amd.comm.Comm.all_reduce_.  The arena then holds the SUM over the ranks and
+    dit.grad_divisor = world_size tells the optimizer (no pass over the arena)."""
     if all_reduce is None:
+        import torch.distributed as dist
         all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    comm_stream = comm_stream or torch.cuda.Stream(device=dit.device)
+    if comm_stream is None:
+        comm_stream = getattr(dit, "_comm_stream", None)
+        if comm_stream is None:
+            comm_stream = dit._comm_stream = torch.cuda.Stream(device=dit.device)       # one per model, not one per step
     arena = dit.grad_arena
-    buckets = gradient_buckets(dit)
-    done = 0
+    buckets = gradient_buckets(dit)                                                     # validated: covers the arena
     L = dit.depth
     for phase in range(L + 2):
         dit.backward_phases_(v_pred, v_target, phase, phase + 1)
@@ -196,27 +257,111 @@ def backward_overlapped(dit, v_pred, v_target, world_size: int, comm_stream=None
             comm_stream.wait_event(ev)
             for _, off, cnt in ready:
                 all_reduce(arena[off: off + cnt])
-                done += cnt
     if world_size > 1:
         torch.cuda.current_stream(dit.device).wait_stream(comm_stream)
-        assert done == arena.numel(), "gradient buckets must cover the arena"
-        arena.div_(world_size)
+    dit.grad_divisor = float(max(1, world_size))
 
 
 @torch.inference_mode()
-def training_step(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx: torch.Tensor, ctx_noise_idx: torch.Tensor,
-                  ctx_noise: torch.Tensor, noise: torch.Tensor, lr: float, weight_decay: float = 0.0, max_grad_norm: float = 1.0,
-                  world_size: int = 1, noise_steps: int = 50, n_prompt_frames: int = 4, noise_abs_max: float = 20.0, clamp_min: float = 1e-6,
-                  overlap_all_reduce: bool = True, comm_stream=None, all_reduce=None):
-    """One optimisation step on a batch of (n_prompt_frames + 1)-frame latent clips: forward + loss (train_dit.py:590-650), backward,
-    gradient all-reduce (bucketed and overlapped with the backward pass when world_size > 1), clip, AdamW.  Returns the loss tensor (1,)."""
+def training_step(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx, ctx_noise_idx, ctx_noise, noise, lr: float,
+                  weight_decay: float = 0.0, max_grad_norm: float = 1.0, world_size: int = 1, noise_steps: int = 50, n_prompt_frames: int = 4,
+                  noise_abs_max: float = 20.0, clamp_min: float = 1e-6, overlap_all_reduce: bool = True, comm_stream=None, all_reduce=None):
+    """One optimisation step on a batch of latent clips: for every target frame forward + loss and its backward (train_dit.py:590-680: each
+    frame's loss is differentiated inside the frame loop, the gradients add up), gradient all-reduce (bucketed and overlapped with the LAST
+    frame's backward pass when world_size > 1), clip, AdamW.  Returns the mean loss over the target frames, a (1,) tensor."""
     dit.zero_grad()
-    loss, v_pred, v_target = forward_loss(dit, latents, actions, target_noise_idx, ctx_noise_idx, ctx_noise, noise, noise_steps, n_prompt_frames,
-                                          noise_abs_max, clamp_min, keep_activations=True)
-    if world_size > 1 and overlap_all_reduce:
-        backward_overlapped(dit, v_pred, v_target, world_size, comm_stream, all_reduce)
-    else:
-        dit.backward_(v_pred, v_target)
+    n_iter = latents.shape[1] - n_prompt_frames
+    overlap = world_size > 1 and overlap_all_reduce
+
+    def on_frame(k, v_pred, v_target):
+        if overlap and k == n_iter - 1:
+            backward_overlapped(dit, v_pred, v_target, world_size, comm_stream, all_reduce)
+        else:
+            dit.backward_(v_pred, v_target)
+
+    loss, _, _ = forward_loss(dit, latents, actions, target_noise_idx, ctx_noise_idx, ctx_noise, noise, noise_steps, n_prompt_frames,
+                              noise_abs_max, clamp_min, keep_activations=True, on_frame=on_frame)
+    if not overlap:
         all_reduce_gradients(dit, world_size)
     dit.adamw_step(lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
     return loss
+
+
+class LossScaler:
+    """Dynamic loss scale for the fp16 backward pass (the reference trains under bf16 autocast and needs none).  The optimizer step skips
+    itself on the device when a gradient overflowed (non-finite norm or a saturated fp16 store: gtav_dit_adamw_step); every `check_every`
+    steps this reads the skip counter (one synchronisation) and halves the scale if steps were skipped since the last check, or doubles it
+    after `growth_interval` clean steps — torch.cuda.amp.GradScaler's policy at a coarser cadence."""
+
+    def __init__(self, dit, check_every: int = 50, growth_interval: int = 2000, min_scale: float = 1.0, max_scale: float = 2.0 ** 24):
+        self.dit, self.check_every, self.growth_interval = dit, int(check_every), int(growth_interval)
+        self.min_scale, self.max_scale = float(min_scale), float(max_scale)
+        self._calls = 0
+        self._clean = 0
+        self._skipped_seen = None
+
+    def update(self) -> float:
+        """Call once per optimisation step (after adamw_step).  Returns the loss scale the NEXT step will use."""
+        self._calls += 1
+        if self._calls % self.check_every:
+            return self.dit.loss_scale
+        _, skipped, _ = self.dit.train_stats()
+        if self._skipped_seen is None:
+            self._skipped_seen = 0
+        if skipped > self._skipped_seen:
+            self.dit.loss_scale = max(self.min_scale, self.dit.loss_scale * 0.5)
+            self._clean = 0
+        else:
+            self._clean += self.check_every
+            if self._clean >= self.growth_interval:
+                self.dit.loss_scale = min(self.max_scale, self.dit.loss_scale * 2.0)
+                self._clean = 0
+        self._skipped_seen = skipped
+        return self.dit.loss_scale
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Checkpoint / resume (reference train_dit.py:746-849): `save_model` = the weights alone as one .safetensors with the reference's key
+# names (train_dit.py:758-762); `save_checkpoint` = accelerator.save_state (model + optimizer) + step.json {step, epoch}; `load_checkpoint`
+# = load_state + step.json, then the caller skips `steps_in_epoch * gradient_accumulation_steps` batches (train_dit.py:841-843).
+# ------------------------------------------------------------------------------------------------------------------------
+def save_model(dit, path: str):
+    """train_dit.py:746-763: weights only, safetensors, reference key names (incl. the de-duplicated rotary `freqs`)."""
+    from . import weights as _w
+    if getattr(dit, "_trainable", False) and dit._handle:
+        dit.pull_weights()
+    _w.save_state_dict_file(dit.state_dict(), path)
+
+
+def save_state(dit, ckpt_dir: str, global_step: int, epoch: int, extra: Optional[dict] = None):
+    """train_dit.py:765-800 `save_checkpoint`: <dir>/model.safetensors (fp32 masters), <dir>/optimizer.safetensors (AdamW moments + step
+    counters), <dir>/step.json {"step", "epoch", "loss_scale", ...}.  Rank 0 writes; the caller barriers around it like the reference."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    os.makedirs(ckpt_dir, exist_ok=True)
+    save_model(dit, os.path.join(ckpt_dir, "model.safetensors"))
+    save_file({k: v.contiguous() for k, v in dit.opt_state_dict().items()}, os.path.join(ckpt_dir, "optimizer.safetensors"))
+    state = {"step": int(global_step), "epoch": int(epoch), "loss_scale": float(dit.loss_scale)}
+    state.update(extra or {})
+    with open(os.path.join(ckpt_dir, "step.json"), "w") as f:
+        json.dump(state, f)
+
+
+def load_state(dit, ckpt_dir: str, steps_per_epoch: Optional[int] = None, gradient_accumulation_steps: int = 1) -> dict:
+    """train_dit.py:802-849 `load_checkpoint`: restores weights, AdamW state and the loss scale into `dit` (trainable=True) and returns
+    step.json's dict plus "skip_iter" = (step % steps_per_epoch) * gradient_accumulation_steps, the number of batches of the current
+    epoch the resumed loop has to skip (train_dit.py:841-843), when steps_per_epoch is given."""
+    import json
+    import os
+    from safetensors.torch import load_file
+    from . import weights as _w
+    dit.load_state_dict(_w.load_state_dict_file(os.path.join(ckpt_dir, "model.safetensors")))
+    dit.load_opt_state_dict(load_file(os.path.join(ckpt_dir, "optimizer.safetensors")))
+    with open(os.path.join(ckpt_dir, "step.json")) as f:
+        state = json.load(f)
+    if "loss_scale" in state:
+        dit.loss_scale = float(state["loss_scale"])
+    if steps_per_epoch:
+        state["skip_iter"] = (state["step"] % int(steps_per_epoch)) * int(gradient_accumulation_steps)
+    return state

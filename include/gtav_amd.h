@@ -28,6 +28,8 @@
  *   gtav_dit_train_enable    hipMalloc + hipMemset of masters, optimizer state, saved-activation and backward workspace, two small
  *                            synchronous hipMemcpy (the multi-tensor AdamW tables)
  *   gtav_dit_train_stats     copies four floats back and synchronises `stream`
+ *   gtav_dit_get_opt_step / gtav_dit_set_opt_step   copy the optimizer's control words and synchronise `stream`
+ *   gtav_dit_set_fold        destroys the captured graphs of the handle
  *   gtav_comm_unique_id / gtav_comm_init / gtav_comm_destroy   dlopen of librccl.so on first use; RCCL's own bootstrap (blocking)
  * The library reads no environment variables (RCCL, once loaded, reads its own NCCL_* / RCCL_* variables).
  */
@@ -116,6 +118,16 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
  * synchronises the device; every call drops the captured graphs of the handle.  Ignored on handles with training enabled. */
 int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
 
+/* LayerNorm fold.  The LayerNorm + adaLN modulate between a residual GEMM and the GEMM that consumes its output
+ * (model/dit.py:19-27, 200-225: out-proj -> fc1 = seam A, fc2 -> next to_qkv / final projection = seam B) can run inside the two GEMM
+ * epilogues instead of as a launch of its own: the producer updates the residual in place and emits x (1 + scale) plus per-row partial
+ * sums, the consumer applies (acc - mean c1) rstd + c2 with per-frame tables c1 / c2 built next to the adaLN table.  Same arithmetic up to
+ * fp32 summation order and one fp16 rounding of a differently scaled operand.  mode 0 = never, 1 = where it is measured faster (default:
+ * a seam folds at >= min_tokens tokens per forward), 2 = every seam at every size.  min_tokens_a / _b < 0 keep the current thresholds.
+ * Drops the captured graphs and the prepared frame of the handle; ignored (never folded) on handles with training enabled or
+ * gtav_dit_set_fused_temporal on, and on geometries whose frames are not a multiple of 16 (>= 64) tokens. */
+int gtav_dit_set_fold(gtav_dit* h, int32_t mode, int32_t min_tokens_a, int32_t min_tokens_b);
+
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
  * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).
  * Classes: 0 LN+modulate, 1 QKV GEMM, 2 spatial attention, 3 temporal attention, 4 out-proj GEMM, 5 fc1 GEMM,
@@ -142,6 +154,9 @@ int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by
 int gtav_dit_train_param_count(gtav_dit* h, int64_t* numel);
 int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena_numel);
 int gtav_dit_set_loss_scale(gtav_dit* h, float scale);
+/* Data-parallel training: the gradient arena holds the SUM over `divisor` ranks (all-reduce SUM) — gtav_dit_adamw_step and gtav_dit_train_stats
+ * then work on arena / (loss scale x divisor), i.e. the rank average DDP would have produced, without a pass over the 2.4 GB arena.  Default 1. */
+int gtav_dit_set_grad_divisor(gtav_dit* h, float divisor);
 int gtav_dit_zero_grad(gtav_dit* h, void* stream);
 /* DiT.forward in training mode: same result as gtav_dit_forward, keeps the activations the backward pass needs. */
 int gtav_dit_train_forward(gtav_dit* h, const float* x_dev, const int64_t* t_dev, const float* actions_dev, float* out_dev,
@@ -163,8 +178,19 @@ int gtav_dit_train_param_range(gtav_dit* h, const char* prefix, int64_t* offset,
 /* Raw (loss-scaled) gradient of one parameter in torch layout. */
 int gtav_dit_get_grad(gtav_dit* h, const char* name, float* dst_dev, int64_t numel, void* stream);
 int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm, void* stream);
+/* (gtav_dit_adamw_step: the step is SKIPPED on the device — weights, moments and the Adam step count untouched, "skipped steps" + 1 —
+ * when the global gradient norm is not finite or when an fp16 gradient / activation store saturated since the last step: every such
+ * store clamps to +-65504 and raises a bit in the handle's error word, which the step consumes.  The Adam step count t and its bias
+ * corrections 1 - beta^t are kept on the device and advance with APPLIED steps only.) */
 /* out4_host: sum of squares of the scaled gradients, step coefficient (0 = skipped), skipped steps so far, unscaled gradient norm. */
 int gtav_dit_train_stats(gtav_dit* h, float* out4_host, void* stream);
+/* Optimizer state for checkpoint / resume (train_dit.py:765-849 accelerator.save_state / load_state): the AdamW first / second moments of
+ * one parameter (fp32, the parameter's state-dict shape; the fp32 master itself goes through gtav_dit_get_weight / set_weight) and the
+ * counters (applied steps = the Adam step count; skipped steps).  get_opt_step / set_opt_step synchronise `stream`. */
+int gtav_dit_get_opt_state(gtav_dit* h, const char* name, float* m_dst_dev, float* v_dst_dev, int64_t numel, void* stream);
+int gtav_dit_set_opt_state(gtav_dit* h, const char* name, const float* m_src_dev, const float* v_src_dev, int64_t numel, void* stream);
+int gtav_dit_get_opt_step(gtav_dit* h, int64_t* applied_steps, int64_t* skipped_steps, void* stream);
+int gtav_dit_set_opt_step(gtav_dit* h, int64_t applied_steps, int64_t skipped_steps, void* stream);
 
 /* Reads and clears the handle's device error word (synchronises): fails if, since the last call, a timestep was outside
  * [0, 999], an input held a NaN/inf, or an fp16 activation store saturated (|x| > 65504 is clamped to +-65504, never
@@ -218,6 +244,8 @@ int gtav_add_noise(const float* x_dev, const float* noise_dev, const float* alph
 /* train_dit.py:643-645: v_target = sqrt(a)*clamp(noise) - sqrt(1-a)*x. */
 int gtav_vtarget(const float* x_dev, const float* noise_dev, const float* alpha_dev, float* vt_dev, int32_t rows,
                  int32_t n, float clamp_abs, void* stream);
+/* y[i] += alpha * x[i] (x may alias y): the trainer's `total_loss += loss` / `total_loss / n` on device scalars (train_dit.py:676,682). */
+int gtav_axpy_f32(float* y_dev, const float* x_dev, float alpha, int64_t n, void* stream);
 /* train_dit.py:650 mse_loss: out[0] = mean((a-b)^2) over rows x n; a,b rows are a_stride / b_stride floats apart.
  * out_dev must hold 1 + rows floats. */
 int gtav_mse(const float* a_dev, int64_t a_stride, const float* b_dev, int64_t b_stride, int32_t rows, int32_t n,
@@ -287,11 +315,8 @@ int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16
                            int32_t gate_stride, int32_t rows_per_gate, void* out_f16_dev, const float* shift_dev,
                            const float* scale_dev, int32_t mod_stride, void* stream);
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K);
-/* Force the GEMM pipeline depth (0 = heuristic, 2 or 4 LDS stages) / block shape (0 = heuristic; 2, 3, 7, 8, 9, 11, 12, 14:
- * csrc/gemm.hip launch_epi).  Every choice computes the same result; the parity tests use these to cover each kernel.
- * (Timing experiments that change results exist only in the separate -DGTAV_EXPERIMENTS build, csrc/experiments.h.) */
-void gtav_op_gemm_set_stages(int32_t ns);
-void gtav_op_gemm_set_wm(int32_t wm);
+/* (The per-thread hooks the parity tests use to force a GEMM block shape / pipeline depth are declared in gtav_amd_testing.h: they are
+ * not part of the product interface.) */
 /* fp32 [R][C] -> fp16 [Rp][Cp] zero padded; tiled != 0 writes the GEMM's tile-major operand layout (128 x 64 tiles,
  * csrc/common.h tiled_off; Rp % 128 == 0, Cp % 64 == 0).  All fp16 GEMM operands (x_f16_dev, w_f16_dev) and the fp16
  * outputs of gtav_op_ln_*, gtav_op_attn_* and the GELU epilogues use that layout. */

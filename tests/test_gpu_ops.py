@@ -408,11 +408,12 @@ def test_gemm_8wave_tile_matches(M, N, K):
         lib.gtav_op_gemm_set_stages(0)
 
 
-@pytest.mark.parametrize("shape", [7, 8, 9, 11, 12, 14, 20, 21, 23])
+@pytest.mark.parametrize("shape", [7, 11, 12, 14, 20])
 def test_gemm_other_tiles_all_epilogues(shape):
-    """Block shapes 7 (256 x 256, phased K-tile, mainloop256), 8 (96 x 96) and 9 (128 features x 96 tokens; piece-granular
-    mainloop_g) through every epilogue they support, incl. ragged token and feature edges, K of one and two tiles
-    (prologue / tail paths of the pipelines) and split-K slabs."""
+    """Block shapes 7 (256 x 256, phased K-tile, mainloop256), 11 / 14 (64 x 48, 64 x 96), 12 (128 x 192; piece-granular mainloop_g) and
+    20 (128 x 96 loader-wave kernel) through every epilogue they support, incl. ragged token and feature edges, K of one and two tiles
+    (prologue / tail paths of the pipelines) and split-K slabs.  (Shapes 8, 9, 16, 21, 23, 25 measured slower than these and exist only
+    in the experiments build, csrc/build.sh exp.)"""
     lib = L.load()
     try:
         lib.gtav_op_gemm_set_wm(shape)
@@ -425,130 +426,12 @@ def test_gemm_other_tiles_all_epilogues(shape):
             out = torch.full((M, N), float("nan"), device=dev())
             gemm(xd, w16, bd, M, N, K, 0, out, N)
             assert rel_l2(out, x.float() @ w.half().float().t() + b) < 2e-5, (M, N, K)
-        if shape != 8:     # the 96-feature tile has no tile-major (GELU) epilogue and cannot split Q|K|V^T blocks
-            test_gemm_f16_and_gelu_epilogues()
-            test_gemm_qkv_spatial_layout_and_rope()
+        test_gemm_f16_and_gelu_epilogues()
         test_gemm_residual_gate_epilogue()
-        test_gemm_qkv_temporal_layout()
+        if shape != 7:     # the 256 x 256 tile has no QKV epilogue in the product build (never selected for it)
+            test_gemm_qkv_spatial_layout_and_rope()
+            test_gemm_qkv_temporal_layout()
         for args in ((720, 1024, 4096, 2), (720, 1024, 1024, 4), (300, 256, 512, 1), (5760, 1024, 1024, 2)):
             test_gemm_splitk_partials_reduced_by_layernorm(*args)
-    finally:
-        lib.gtav_op_gemm_set_wm(0)
-
-
-# ------------------------------------------------------------------------------------------------------------------------
-# round 2: the persistent ping-pong kernel (block shape 16) — every epilogue it has, forced onto it at sizes with one tile per
-# block (T < 256), several tiles per block (T = 720: both wave groups alternate MAIN / EPILOGUE, ring continues across tiles),
-# ragged token / feature edges, K of 14, 16 and 64 K-steps
-# ------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K", [(5760, 3072, 1024), (2312, 384, 896), (192, 128, 1024), (1160, 1024, 4096), (11520, 1024, 1024)])
-def test_pingpong_gelu_and_residual(M, N, K):
-    lib = L.load()
-    x = _rand(M, K, seed=1).half()
-    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
-    b = _rand(N, seed=3)
-    w16, xd, bd = pad_weight_f16(w), to_tiled_f16(x), b.to(dev())
-    pre = x.float() @ w.half().float().t() + b
-    try:
-        lib.gtav_op_gemm_set_wm(16)
-        for epi, fn in ((2, lambda z: torch.nn.functional.gelu(z, approximate="tanh")), (3, lambda z: torch.nn.functional.gelu(z))):
-            out = torch.zeros(((M + 127) // 128 * 128, N), device=dev(), dtype=torch.float16)
-            gemm(xd, w16, bd, M, N, K, epi, out, N)
-            assert rel_l2(untile(out, M, N).float(), fn(pre)) < 6e-4, epi
-        # gated residual in place (one gate row per P tokens) and the plain residual
-        P = 8
-        resid = _rand(M, N, seed=4)
-        mod = _rand(M // P, 2 * N, seed=5)
-        md = mod.to(dev())
-        r = resid.clone().to(dev())
-        L.check(lib.gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), r.data_ptr(), N, M, N, K, 4,
-                                     md[:, N:].data_ptr(), 2 * N, P, stream()))
-        assert rel_l2(r, resid + mod[:, N:].repeat_interleave(P, dim=0) * pre) < 2e-5
-        r2 = resid.clone().to(dev())
-        L.check(lib.gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), r2.data_ptr(), N, M, N, K, 4, 0, 0, 1, stream()))
-        assert rel_l2(r2, resid + pre) < 2e-5
-    finally:
-        lib.gtav_op_gemm_set_wm(0)
-
-
-@pytest.mark.parametrize("NB,S,D", [(40, 144, 1024), (5, 576, 1024), (3, 48, 1024)])
-def test_pingpong_qkv_spatial(NB, S, D):
-    lib = L.load()
-    heads, M = D // 64, NB * S
-    x = _rand(M, D, seed=1).half()
-    w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
-    bias = _rand(3 * D, seed=7)
-    ang = (_rand(S, 32, seed=3) * 3).repeat_interleave(2, dim=-1)
-    cos, sin = ang.cos(), ang.sin()
-    w16 = pad_weight_f16(w)
-    q = torch.zeros(NB, heads, S, 64, device=dev(), dtype=torch.float16)
-    k = torch.zeros_like(q)
-    vt = torch.zeros(NB, heads, 64, S, device=dev(), dtype=torch.float16)
-    xd, bd, cd, sd_ = to_tiled_f16(x), bias.to(dev()), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
-    cs = torch.empty_like(cd)
-    L.check(lib.gtav_op_rope_interleave(cd.data_ptr(), sd_.data_ptr(), cs.data_ptr(), S, stream()))
-    try:
-        lib.gtav_op_gemm_set_wm(16)
-        L.check(lib.gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), bd.data_ptr(), M, D, 0, q.data_ptr(), k.data_ptr(), vt.data_ptr(), S, 0, 0,
-                                     0, cs.data_ptr(), stream()))
-    finally:
-        lib.gtav_op_gemm_set_wm(0)
-    y = (x.float() @ w.half().float().t() + bias).reshape(NB, S, 3, heads, 64)
-    qr = _rope_ref(y[:, :, 0].permute(0, 2, 1, 3), cos[None, None], sin[None, None])
-    kr = _rope_ref(y[:, :, 1].permute(0, 2, 1, 3), cos[None, None], sin[None, None])
-    vr = y[:, :, 2].permute(0, 2, 3, 1)
-    assert rel_l2(q.float(), qr) < 6e-4 and rel_l2(k.float(), kr) < 6e-4 and rel_l2(vt.float(), vr) < 6e-4
-
-
-@pytest.mark.parametrize("B,Tq,t0,Tmax,P", [(8, 5, 0, 5, 144), (8, 1, 4, 5, 144), (3, 2, 1, 4, 16)])
-def test_pingpong_qkv_temporal(B, Tq, t0, Tmax, P):
-    lib = L.load()
-    D, M = 1024, B * Tq * P
-    x = _rand(M, D, seed=1).half()
-    w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
-    ang = (_rand(Tmax, 32, seed=3) * 3).repeat_interleave(2, dim=-1)
-    cos, sin = ang.cos(), ang.sin()
-    w16 = pad_weight_f16(w)
-    q = torch.zeros(M, D, device=dev(), dtype=torch.float16)
-    kv = torch.zeros(B, Tmax, P, 2, D, device=dev(), dtype=torch.float16)
-    xd, cd, sd_ = to_tiled_f16(x), cos.to(dev()).contiguous(), sin.to(dev()).contiguous()
-    cs = torch.empty_like(cd)
-    L.check(lib.gtav_op_rope_interleave(cd.data_ptr(), sd_.data_ptr(), cs.data_ptr(), Tmax, stream()))
-    try:
-        lib.gtav_op_gemm_set_wm(16)
-        L.check(lib.gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), 0, M, D, 1, q.data_ptr(), kv.data_ptr(), kv.data_ptr(), P, Tq, t0, Tmax,
-                                     cs.data_ptr(), stream()))
-    finally:
-        lib.gtav_op_gemm_set_wm(0)
-    y = (x.float() @ w.half().float().t()).reshape(B, Tq, P, 3, D // 64, 64)
-    pos = torch.arange(t0, t0 + Tq)
-    c, s = cos[pos][None, :, None, None, :], sin[pos][None, :, None, None, :]
-    qr = _rope_ref(y[:, :, :, 0], c, s).reshape(M, D)
-    kr = _rope_ref(y[:, :, :, 1], c, s).reshape(B, Tq, P, D)
-    vr = y[:, :, :, 2].reshape(B, Tq, P, D)
-    assert rel_l2(q.float(), qr) < 6e-4
-    assert rel_l2(kv[:, t0:t0 + Tq, :, 0].float(), kr) < 6e-4 and rel_l2(kv[:, t0:t0 + Tq, :, 1].float(), vr) < 6e-4
-    if t0 > 0:
-        assert kv[:, :t0].abs().max().item() == 0
-
-
-def test_pingpong_runs_are_bitwise_repeatable():
-    """Race screen: 30 launches of the multi-tile case must give bit-identical outputs (a fill that lands after its first read, or a
-    ring slot refilled too early, shows up as run-to-run differences)."""
-    lib = L.load()
-    M, N, K = 5760, 4096, 1024
-    x = _rand(M, K, seed=1).half()
-    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
-    w16, xd, bd = pad_weight_f16(w), to_tiled_f16(x), _rand(N, seed=3).to(dev())
-    try:
-        lib.gtav_op_gemm_set_wm(16)
-        first = None
-        for it in range(30):
-            out = torch.zeros(((M + 127) // 128 * 128, N), device=dev(), dtype=torch.float16)
-            gemm(xd, w16, bd, M, N, K, 2, out, N)
-            if first is None:
-                first = out.clone()
-            else:
-                assert torch.equal(out, first), it
     finally:
         lib.gtav_op_gemm_set_wm(0)

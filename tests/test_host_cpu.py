@@ -17,9 +17,13 @@ from gtav_amd import lib as L  # noqa: E402
 
 
 def test_cabi_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "gtav_amd.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(gtav_[a-z0-9_]+)\s*\(", hdr))
+    def decls(name):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        return set(re.findall(r"\b(gtav_[a-z0-9_]+)\s*\(", hdr))
+    product, hooks = decls("gtav_amd.h"), decls("gtav_amd_testing.h")
+    assert hooks == {"gtav_op_gemm_set_stages", "gtav_op_gemm_set_wm"} and not (product & hooks)   # test hooks stay out of the product header
+    declared = product | hooks
     assert len(declared) >= 35
     dll = ctypes.CDLL(L.LIB_PATH)
     missing = [n for n in sorted(declared) if not hasattr(dll, n)]
@@ -27,7 +31,7 @@ def test_cabi_exports_every_declared_symbol():
     # the ctypes binding covers the whole header
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.load()
-    assert lib.gtav_abi_version() == 3
+    assert lib.gtav_abi_version() == 4
     assert lib.gtav_last_error() is not None
 
 
@@ -239,16 +243,18 @@ def _grad_allreduce_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gtav_amd.train import all_reduce_gradients
 
-    class FakeDit:          # the trainer only touches .grad_arena: one contiguous fp32 tensor (the GPU model's gradient arena)
+    class FakeDit:          # the trainer touches .grad_arena (one contiguous fp32 tensor, the GPU model's gradient arena) and .grad_divisor
         grad_arena = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        grad_divisor = 1.0
     d = FakeDit()
     all_reduce_gradients(d, world)
-    q.put((rank, d.grad_arena.clone()))
+    q.put((rank, d.grad_arena.clone() / d.grad_divisor))     # what the optimizer works on: arena / divisor (gtav_dit_set_grad_divisor)
     dist.destroy_process_group()
 
 
 def test_gradient_allreduce_averages_over_ranks_gloo():
-    """train.all_reduce_gradients (DDP's gradient averaging, one all-reduce over the contiguous arena) on two gloo ranks."""
+    """train.all_reduce_gradients (DDP's gradient averaging: ONE all-reduce SUM over the contiguous arena, the division by the world size
+    handed to the optimizer as dit.grad_divisor instead of a pass over the arena) on two gloo ranks."""
     import socket
     import torch
     import torch.multiprocessing as mp

@@ -20,8 +20,11 @@ def main():
     ap.add_argument("--actions", action="store_true")
     ap.add_argument("--fused-ab", action="store_true", help="A/B the fused temporal QKV + attention kernel instead: variant 0 = two-kernel path, 1 = fused")
     ap.add_argument("--depth", type=int, default=16, help="fewer blocks: the weights then stay in the 256 MiB Infinity Cache between forwards")
+    ap.add_argument("--fold-ab", action="store_true", help="A/B the LayerNorm fold instead: variant = fold mode (0 off, 1 default policy, 2 every seam, "
+                    "3 = seam A only, 4 = seam B only); the PRODUCT library unless --exp")
+    ap.add_argument("--exp", action="store_true")
     a = ap.parse_args()
-    lib = L.load_experiments()
+    lib = L.load_experiments() if (a.exp or not a.fold_ab) else L.load()
     import gtav_amd.weights as W
     from gtav_amd.model.dit import DiT_models
     dev = torch.device("cuda", 0)
@@ -39,7 +42,11 @@ def main():
     ref = None
     for r in range(a.rounds):
         for v in a.variants:
-            if a.fused_ab:
+            if a.fold_ab:
+                if v == 3: dit.set_fold(1, 0, 1 << 30)
+                elif v == 4: dit.set_fold(1, 1 << 30, 0)
+                else: dit.set_fold(v, 1024, 1024)
+            elif a.fused_ab:
                 dit.set_fused_temporal(bool(v & 1))
                 lib.gtav_op_gemm_set_debug(v & ~1)    # e.g. 513 = fused + debug bit 9 (no K/V cache rows: timing only)
             else:
@@ -62,9 +69,11 @@ def main():
             torch.cuda.synchronize()
             prof = dit.profile_read()
             dit.profile(False)
-            cls = " ".join(f"{k.replace('gemm_', '')}={v[0] / max(v[1], 1) * 1e3:.2f}" for k, v in prof.items() if v[1] and k != "empty_event_pair")
-            print(f"round {r} variant {v:3d}: forward {ms:.3f} ms (rel diff vs first {err:.1e}) | us per launch: {cls}", flush=True)
-    lib.gtav_op_gemm_set_debug(0)
+            cls = " ".join(f"{k.replace('gemm_', '')}={v[0] / max(v[1], 1) * 1e3:.2f}x{v[1] // 4}" for k, v in prof.items() if v[1] and k != "empty_event_pair")
+            tot = sum(v[0] for k, v in prof.items() if k != "empty_event_pair") / 4
+            print(f"round {r} variant {v:3d}: forward {ms:.3f} ms (rel diff vs first {err:.1e}) kernels {tot:.3f} ms | us per launch x launches: {cls}", flush=True)
+    if hasattr(lib, "gtav_op_gemm_set_debug"):
+        lib.gtav_op_gemm_set_debug(0)
 
 
 if __name__ == "__main__":
