@@ -490,6 +490,41 @@ def train_forward_loss(dit_fn: Callable, latents: Tensor, actions: Optional[Tens
     return loss, v_pred, v_target, x_noisy, t
 
 
+def train_shared_step(dit_fn: Callable, latents: Tensor, actions: Optional[Tensor], target_noise_idx: Tensor, ctx_noise_idx: Tensor,
+                      ctx_noises, noises, noise_steps: int = 50, n_prompt_frames: int = 4, max_frames: int = 5,
+                      noise_abs_max: float = 20.0, clamp_min: float = 1e-6):
+    """train_dit.py:590-682 — the whole frame loop of `_shared_step` for clips with any number of target frames, random draws injected:
+    target_noise_idx / ctx_noise_idx (n, B) ints, ctx_noises[k] (B, W_k - 1, C, h, w), noises[k] (B, 1, C, h, w), n = total_frames -
+    n_prompt_frames, W_k = min(n_prompt_frames + k + 1, max_frames).  Returns (mean loss over the target frames, [per-frame loss],
+    [v_pred], [v_target])."""
+    B, total = latents.shape[:2]
+    n_iter = total - n_prompt_frames
+    nr = noise_range_train(noise_steps)
+    ac = alphas_cumprod_table(clamp_min)[:, None, None, None]
+    ctx_noise_idx = torch.minimum(ctx_noise_idx, target_noise_idx)                      # :587
+    losses, vps, vts = [], [], []
+    for idx, i in enumerate(range(n_prompt_frames, total)):                              # :590
+        start = max(0, i + 1 - max_frames)                                               # :598
+        t = torch.zeros((B, i + 1), dtype=torch.long)
+        t[:, :-1] = nr[ctx_noise_idx[idx]].unsqueeze(1)                                  # :610-611
+        t[:, -1] = nr[target_noise_idx[idx]]
+        x_curr, t = latents[:, start: i + 1], t[:, start:]                               # :614-615
+        a = actions[:, start: i + 1] if actions is not None else None
+        cn = ctx_noises[idx].clamp(-noise_abs_max, noise_abs_max)
+        nz = noises[idx].clamp(-noise_abs_max, noise_abs_max)
+        x_noisy = x_curr.clone()
+        al = ac[t[:, :-1]]
+        x_noisy[:, :-1] = x_noisy[:, :-1] * al.sqrt() + (1 - al).sqrt() * cn             # :631-634
+        al = ac[t[:, -1:]]
+        x_noisy[:, -1:] = x_noisy[:, -1:] * al.sqrt() + (1 - al).sqrt() * nz             # :639-643
+        v_target = al.sqrt() * nz - (1 - al).sqrt() * x_curr[:, -1:]                     # :644-646
+        v_pred = dit_fn(x_noisy, t, a)                                                   # :649
+        losses.append(F.mse_loss(v_pred[:, -1:], v_target))                              # :650
+        vps.append(v_pred)
+        vts.append(v_target)
+    return sum(losses) / n_iter, losses, vps, vts                                        # :676, :682
+
+
 def trainer_predict_latents(dit_fn: Callable, vae_sd, vcfg: VAEConfig, frames: Tensor, actions: Optional[Tensor],
                             new_frame_noise: Tensor, num_frames: int, n_prompt_frames: int = 4, ddim_noise_steps: int = 50,
                             ddim_noise_steps_inference: int = 50, max_frames: int = 5, noise_abs_max: float = 20.0) -> Tensor:

@@ -194,6 +194,46 @@ def test_g7_harness_encode_rollout_decode_bytes():
     assert (u8[:, :, 100].int() - g["frames_u8_row100"].int()).abs().max().item() <= 1
 
 
+def test_g10_frame_loop_three_target_frames():
+    """G10 (reference statements of train_dit.py:590-682 on the reference DiT module, 7-frame clips = three target frames with windows of
+    5 frames sliding): pins `oracle.train_shared_step` — per-frame losses, v_pred of every target frame, the returned mean loss."""
+    g = gold("g10_frame_loop.safetensors")
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=17)
+    cfg = O.DiTConfig(**SMALL_DIT)
+    fn = lambda x, t, a: O.dit_forward(sd, cfg, x, t, a)
+    with torch.no_grad():
+        mean, losses, vps, vts = O.train_shared_step(fn, g["latents"], g["actions"], g["target_idx"], g["ctx_idx"],
+                                                     [g[f"ctx_noise{k}"] for k in range(3)], [g[f"noise{k}"] for k in range(3)])
+    for k in range(3):
+        assert rel(vts[k], g[f"v_target{k}"]) < 1e-6 and rel(vps[k], g[f"v_pred{k}"]) < TOL
+        assert abs(losses[k].item() - g[f"loss{k}"].item()) / g[f"loss{k}"].item() < TOL
+    assert abs(mean.item() - g["mean_loss"].item()) / g["mean_loss"].item() < TOL
+
+
+@pytest.mark.slow
+def test_g9_config0_production_size():
+    """G9 = BASELINE configs[0] at PRODUCTION size (reference DiT-S/2, 16 blocks, 608 M parameters + the full ViT-L/20 VAE through the
+    reference's own vae_encode / denoise_step loop / decode tail): the oracle's 33 chained full-size forwards (windows of 2, 3, 4
+    frames), stride-sampled frames and bytes."""
+    g = gold("g9_config0_full.safetensors")
+    vsd = W.synth_state_dict(W.vae_param_shapes(), seed=1)
+    vcfg = O.vit_l_20_shallow_encoder()
+    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    cfg = O.dit_s_2()
+    clip = O.dummy_clip()
+    assert torch.equal(clip[None, :1, :, ::8, ::8], g["prompt_frames"])
+    fn = lambda x, t, a: O.dit_forward(sd, cfg, x, t, a)
+    with torch.no_grad():
+        x0 = O.vae_encode_frames(vsd, vcfg, clip[None, :1])
+        assert rel(x0, g["latents_prompt"]) < TOL
+        lat = O.generate_latents(fn, x0, 4, 10, g["noise"], g["actions"])
+        assert rel(lat, g["latents_final"]) < 1e-4
+        u8 = O.vae_decode_latents(vsd, vcfg, g["latents_final"])
+    d = (u8[:, :, ::4, ::4].int() - g["frames_u8_stride4"].int()).abs()
+    assert d.max().item() <= 1 and int((d > 0).sum()) <= 20, int((d > 0).sum())
+    assert (u8[:, :, 100].int() - g["frames_u8_row100"].int()).abs().max().item() <= 1
+
+
 def test_initialize_weights_statistics():
     """a13: DiT.initialize_weights (model/dit.py:295-326) — N(0, 0.02) Linear weights, zero biases, t-MLP std 0.01, the adaLN
     modulation of every block ZEROED (blocks are the identity at init), final adaLN std 0.01, final linear std 0.001;

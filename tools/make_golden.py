@@ -55,8 +55,10 @@ SMALL_DIT_NATIVE = dict(input_h=18, input_w=32, patch_size=2, in_channels=16, hi
 
 
 @torch.no_grad()
-def g7_harness(rd, rv, ref_denoise_step, ref_schedule):
-    """G7: BASELINE config 1 end to end through the reference's own harness functions — dummy-ramp first frame
+def g7_harness(rd, rv, ref_denoise_step, ref_schedule, full_dit=False):
+    """G9 (full_dit=True): the same harness with the PRODUCTION-SIZE DiT-S/2 (depth 16, hidden 1024, 608 M parameters, the repo's seed-0
+    synthetic weights) — BASELINE configs[0] exactly: 33 full-size forwards with windows of 2, 3 and 4 frames, full-size VAE on both ends.
+    G7: BASELINE config 1 end to end through the reference's own harness functions — dummy-ramp first frame
     (dummy_dataset.py:15-36) -> generate.vae_encode (generate.py:50-66, full-size ViT-L/20 VAE) -> 4-frame / 10-step rollout
     with train_dit.denoise_step (generate.py:186-220; small DiT on the native 18x32 latent grid, action "W") -> decode tail
     (generate.py:238-244: vae.decode(x / s), (x + 1) / 2, clamp(x * 255, 0, 255).byte()).  Stored: inputs, latents after the
@@ -67,8 +69,12 @@ def g7_harness(rd, rv, ref_denoise_step, ref_schedule):
     from einops import rearrange
     vsd = W.synth_state_dict(W.vae_param_shapes(), seed=1)
     vae = load_into(rv.VAE_models["vit-l-20-shallow-encoder"](), vsd)
-    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT_NATIVE), seed=31)
-    dit = load_into(rd.DiT(**SMALL_DIT_NATIVE), sd)
+    if full_dit:
+        sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+        dit = load_into(rd.DiT_models["DiT-S/2"](), sd)
+    else:
+        sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT_NATIVE), seed=31)
+        dit = load_into(rd.DiT(**SMALL_DIT_NATIVE), sd)
     clip = RefDummy(split="test")[0]["video"]            # (5, 3, 360, 640) blue -> red ramp
     n_prompt, total, steps = 1, 4, 10
     prompt = clip[None, :n_prompt].contiguous()          # --start_frame convention: the first frame is the prompt
@@ -93,8 +99,9 @@ def g7_harness(rd, rv, ref_denoise_step, ref_schedule):
     img = rearrange(img, "(b t) c h w -> b t h w c", t=total)
     u8 = torch.clamp(img * 255, 0, 255).byte()
     inside = ((img * 255 > 0) & (img * 255 < 255)).float().mean().item()
-    print(f"g7: {inside * 100:.1f} % of the float pixels are strictly inside (0, 255); u8 mean {u8.float().mean():.1f}")
-    save("g7_harness.safetensors", {"prompt_frames": prompt[:, :, :, ::8, ::8].clone(), "noise": noise, "actions": actions,
+    tag = "g9" if full_dit else "g7"
+    print(f"{tag}: {inside * 100:.1f} % of the float pixels are strictly inside (0, 255); u8 mean {u8.float().mean():.1f}")
+    save("g9_config0_full.safetensors" if full_dit else "g7_harness.safetensors", {"prompt_frames": prompt[:, :, :, ::8, ::8].clone(), "noise": noise, "actions": actions,
                                     "latents_prompt": lat_prompt, "latents_final": lat_final,
                                     "frames_f32_stride4": img[:, :, ::4, ::4].clone(), "frames_u8_stride4": u8[:, :, ::4, ::4].clone(),
                                     "frames_u8_row100": u8[:, :, 100].clone()})
@@ -192,9 +199,57 @@ def g8_training(rd):
     print("G8 parameters with gradients:", len(names), "; without:", [k for k in params if params[k].grad is None])
 
 
+@torch.no_grad()
+def g10_frame_loop(rd, ref_schedule):
+    """G10: the frame loop of `_shared_step` (train_dit.py:590-682) on clips with THREE target frames (7 frames, 4 prompt): per target
+    frame i the reference's statements — window slice, timesteps from the per-frame noise indices, noising of context and target frame,
+    v-target, `self.dit(x_noisy, t, actions_curr)`, `mse_loss(v_pred[:, -1:], v_target)` — with the draws injected, on the reference DiT
+    module (small width).  Stored: inputs, per-frame losses, the returned mean loss, v_pred of every target frame."""
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=17)
+    m = load_into(rd.DiT(**SMALL_DIT), sd)
+    g = torch.Generator().manual_seed(14)
+    B, total, n_prompt, max_frames = 2, 7, 4, 5
+    lat = torch.randn(B, total, 16, 8, 16, generator=g) * 0.5
+    actions = one_hot_actions(B, total, g)
+    n_iter = total - n_prompt
+    tgt = torch.randint(1, 51, (n_iter, B), generator=g)
+    ctx = torch.randint(1, 41, (n_iter, B), generator=g)
+    ctx_m = torch.minimum(ctx, tgt)
+    ac = torch.cumprod(1.0 - ref_schedule(1000, clamp_min=0.000001).float(), dim=0)[:, None, None, None]
+    nr = torch.linspace(0, 999, 51).long()
+    out = {"latents": lat, "actions": actions, "target_idx": tgt, "ctx_idx": ctx}
+    total_loss = 0.0
+    for idx, i in enumerate(range(n_prompt, total)):
+        x_input, a_input = lat[:, : i + 1], actions[:, : i + 1]
+        start = max(0, i + 1 - max_frames)
+        t = torch.zeros((B, i + 1), dtype=torch.long)
+        t[:, :-1] = nr[ctx_m[idx]].unsqueeze(1)
+        t[:, -1] = nr[tgt[idx]]
+        x_curr, t, a_curr = x_input[:, start:], t[:, start:], a_input[:, start:]
+        cn = torch.randn(x_curr[:, :-1].shape, generator=g) * 6
+        nz = torch.randn(x_curr[:, -1:].shape, generator=g) * 6
+        out[f"ctx_noise{idx}"], out[f"noise{idx}"] = cn.clone(), nz.clone()
+        cn, nz = cn.clamp(-20, 20), nz.clamp(-20, 20)
+        x_noisy = x_curr.clone()
+        al = ac[t[:, :-1]]
+        x_noisy[:, :-1].mul_(al.sqrt()).add_((1 - al).sqrt() * cn)
+        al = ac[t[:, -1:]]
+        x_noisy[:, -1:].mul_(al.sqrt()).add_((1 - al).sqrt() * nz)
+        v_target = al.sqrt() * nz - (1 - al).sqrt() * x_curr[:, -1:]
+        v_pred = m(x_noisy, t, a_curr)
+        loss = torch.nn.functional.mse_loss(v_pred[:, -1:], v_target)
+        total_loss = total_loss + loss
+        out[f"loss{idx}"], out[f"v_pred{idx}"], out[f"v_target{idx}"] = loss.reshape(1), v_pred, v_target
+    out["mean_loss"] = (total_loss / n_iter).reshape(1)
+    save("g10_frame_loop.safetensors", out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rd, rv, ref_denoise_step, ref_schedule = ref_shim.import_reference()
+    if "--only-g9-g10" in sys.argv:
+        g10_frame_loop(rd, ref_schedule)
+        return g7_harness(rd, rv, ref_denoise_step, ref_schedule, full_dit=True)
     if "--only-g7" in sys.argv:
         return g7_harness(rd, rv, ref_denoise_step, ref_schedule)
     if "--only-g1-g8" in sys.argv:
@@ -349,6 +404,8 @@ def main():
     dec = fv.decode(z)
     del fv, fvsd
     g7_harness(rd, rv, ref_denoise_step, ref_schedule)
+    g10_frame_loop(rd, ref_schedule)
+    g7_harness(rd, rv, ref_denoise_step, ref_schedule, full_dit=True)
     g1_per_op(rd, rv)
     g8_training(rd)
     save("g3_full_vae.safetensors", {"mean": post.mean, "logvar": post.logvar, "z": z, "decoded_stride4": dec[:, :, ::4, ::4].clone(),
