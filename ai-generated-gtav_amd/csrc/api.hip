@@ -373,7 +373,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // consumer side of a folded seam: X = xn holds x (1 + scale), statistics in fo.stats, tables of seam `seam`
     auto fold_consumer = [&](GemmParams& q, int seam, int N) {
         q.bias = nullptr;
-        q.f_P = P; q.f_rows = mod_rows; q.f_stats = fo.stats; q.f_nslot = D / 32;
+        q.f_P = P; q.f_rows = mod_rows; q.f_stats = fo.stats; q.f_nslot = D / 64;
         q.f_c1 = ctab + fo.col_c[seam]; q.f_c2 = q.f_c1 + N; q.f_ldc = fo.CTW;
     };
     // producer side: in-place gated residual update + operand and statistics of the LayerNorm that follows (scale vectors at `next_scale`)
@@ -607,7 +607,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
         f.Rp = round_up(h->max_rows, 128);
         A_(a.alloc_t(&f.ctab, (size_t)h->max_rows * f.CTW));
         A_(a.alloc_t(&f.ctab_cur, (size_t)h->maxB * h->maxT * f.CTW));
-        A_(a.alloc_t(&f.stats, Mx * (size_t)(D / 32) * 2));
+        A_(a.alloc_t(&f.stats, Mx * (size_t)(D / 64) * 2));
         A_(a.alloc_t(&f.sx, (size_t)f.n_groups * f.Rp * D));
         A_(a.alloc_t(&f.groups_dev, f.n_groups)); A_(a.alloc_t(&f.gcol_dev, f.n_groups)); A_(a.alloc_t(&f.gscale_dev, f.n_groups));
         if (!rc) {
@@ -1688,6 +1688,24 @@ int gtav_op_gemm_qkv(const void* x, int32_t ldx, const void* w, const float* bia
     g.qkv_mode = mode; g.q = (f16*)q; g.k = (f16*)k; g.v = (f16*)v; g.Tq = Tq; g.t0 = t0; g.Tmax = Tmax;
     g.rope_cs = rope_cs;
     return launch_gemm(g, EPI_QKV, (hipStream_t)stream);
+}
+int gtav_op_gemm_fold_producer(const void* x, const void* w, const float* bias, float* resid, int32_t M, int32_t N, int32_t K, const float* gate,
+                               const float* next_scale, int32_t mod_stride, int32_t tokens_per_frame, void* a_out, float* stats_out, void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)x; g.ldx = K; g.W = (const f16*)w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = resid; g.ldo = N;
+    g.gate = gate; g.gate_stride = mod_stride; g.rows_per_gate = tokens_per_frame;
+    g.f_P = tokens_per_frame; g.f_scale = next_scale; g.f_stats_out = stats_out; g.f_a = (f16*)a_out;
+    return launch_gemm(g, EPI_RESID_FOLD, (hipStream_t)stream);
+}
+int gtav_op_gemm_fold_consumer(const void* a, const void* w, int32_t M, int32_t N, int32_t K, int32_t epi, const float* stats, const float* c1, const float* c2,
+                               int32_t ldc, int32_t tokens_per_frame, void* out, int32_t ldo, void* stream) {
+    GTAV_REQUIRE(epi == EPI_F32 || epi == EPI_GELU_TANH, "gemm_fold_consumer: epilogue %d (0 = f32 row-major, 2 = GELU-tanh fp16 tile-major)", epi);
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)a; g.ldx = K; g.W = (const f16*)w; g.M = M; g.N = N; g.K = K; g.out = out; g.ldo = ldo;
+    g.f_P = tokens_per_frame; g.f_stats = stats; g.f_nslot = K / 64; g.f_c1 = c1; g.f_c2 = c2; g.f_ldc = ldc;
+    return launch_gemm(g, epi == EPI_F32 ? EPI_F32_FOLD : EPI_GELU_TANH_FOLD, (hipStream_t)stream);
 }
 int gtav_op_skinny_f32(const float* x, int32_t ldx, const float* w, const float* bias, float* y, int32_t ldy, int32_t M,
                        int32_t N, int32_t K, int32_t act_silu, void* stream) {

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         // `sp < nsplit` tests).  Unused slab slots re-read slab 0 (an L1 hit) and are not added; the order of the adds
         // (bias, slab 0, slab 1, ...) is unchanged.
         const float* pp = pd.parts + (size_t)m * pd.ld + c;
+        auto slab = [&](int sp) -> f32x4 { return *(const f32x4*)(pp + (size_t)sp * pd.slab_stride); };
         f32x4 g4 = f32x4{1.f, 1.f, 1.f, 1.f};
         if (pd.gate) {
             int gr = m / pd.rows_per_gate;
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         const int nchunk = pd.nsplit <= 2 ? 2 : pd.nsplit <= 4 ? 4 : 8;     // block-uniform
         if (nchunk == 2) {
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) sl[sp] = *(const f32x4*)(pp + (size_t)(sp < pd.nsplit ? sp : 0) * pd.slab_stride);
+            for (int sp = 0; sp < 2; ++sp) sl[sp] = slab(sp < pd.nsplit ? sp : 0);
         } else if (nchunk == 4) {
 #pragma unroll
-            for (int sp = 0; sp < 4; ++sp) sl[sp] = *(const f32x4*)(pp + (size_t)(sp < pd.nsplit ? sp : 0) * pd.slab_stride);
+            for (int sp = 0; sp < 4; ++sp) sl[sp] = slab(sp < pd.nsplit ? sp : 0);
         } else {
 #pragma unroll
-            for (int sp = 0; sp < 8; ++sp) sl[sp] = *(const f32x4*)(pp + (size_t)(sp < pd.nsplit ? sp : 0) * pd.slab_stride);
+            for (int sp = 0; sp < 8; ++sp) sl[sp] = slab(sp < pd.nsplit ? sp : 0);
         }
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp)

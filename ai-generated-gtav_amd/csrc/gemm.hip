@@ -166,9 +166,11 @@ __device__ __forceinline__ void interleave_mfma_dsread() {
 // next tile AFTER its MFMAs instead of before: a wave's direct-to-LDS loads back-pressure its in-order instruction
 // stream at the ~63 GB/s/CU fill rate (profiles/round1/v5_gemm_8wave_microbench.txt: fills-only and MFMA-only loops
 // cost the same and used to add up), so the partners' fill and MFMA phases now run beside each other.
-template <bool TR, int NS, int WM, int FJ, typename AfterPrologue>
+struct NoStepHook { __device__ __forceinline__ void operator()(int) const {} };
+// per_step(t): called once per K-step behind that step's refill (EPI_RESID_FOLD: one residual load per lane and step)
+template <bool TR, int NS, int WM, int FJ, typename AfterPrologue, typename PerStep = NoStepHook>
 __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
-                                         f32x4 (&acc)[4][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
+                                         f32x4 (&acc)[4][FJ], BlockStamps& bs, AfterPrologue after_prologue, PerStep per_step = PerStep()) {
     constexpr int NWAVE = 2 * WM;
     constexpr int TMB = WM * 16 * FJ;                  // tokens per block tile
     constexpr int XT = TMB / 128;                      // 128-row X tiles per stage
@@ -221,6 +223,7 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
         if (t == 0) GTAV_STAMP(bs.t[1]);
         const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
         if (refill && !late) stage(t + NS - 1);
+        per_step(t);
         const char* b = smem + (t % NS) * STAGE_BYTES;
         if (!GTAV_DBG(p, 2)) {
             // both 32-deep halves of the K-step are fetched up front: the second half's fragments arrive under the
@@ -385,9 +388,9 @@ __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int
 // 256 CUs and every block fills 512 KB through a ~65 GB/s per-CU LDS-DMA path; 128 x 96 / 96 x 96 tiles give 256 blocks of
 // 448 / 384 KB.  2 x WM waves; every wave issues G pieces per stage (the last waves repeat the final piece when the
 // piece count does not divide evenly: same bytes to the same place), NS-stage ring with counted vmcnt as in mainloop().
-template <bool TR, int NS, int FI, int FJ, int WM, typename AfterPrologue>
+template <bool TR, int NS, int FI, int FJ, int WM, typename AfterPrologue, typename PerStep = NoStepHook>
 __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
-                                           f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
+                                           f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue, PerStep per_step = PerStep()) {
     constexpr int NWAVE = 2 * WM;
     constexpr int WPC = 4 * FI, XPC = 2 * FJ * WM, NP = WPC + XPC;   // pieces per stage
     constexpr int G = (NP + NWAVE - 1) / NWAVE;
@@ -489,6 +492,7 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             sync(t);
             const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
             if (refill && !late) stage(t + NS - 1);
+            per_step(t);
             if (t > 0) {
                 rdh(t, 0, wa, xa);
                 if (domm) mmh(wb, xb);
@@ -519,6 +523,7 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             sync(t);
             const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
             if (refill && !late) stage(t + NS - 1);
+            per_step(t);
             if (t > 0 && !GTAV_DBG(p, 2)) {
                 rd(t, wr, xr);
                 mm(wm_, xm_);
@@ -555,6 +560,7 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             f16x8 wf[2][FI], xf[2][FJ];
             rd(t, wf, xf);
             if (!GTAV_DBG(p, 1)) stage(t + 1);
+            per_step(t);
             mm(wf, xf);
 #pragma unroll
             for (int i = 0; i < G; ++i) {
@@ -568,6 +574,7 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             sync(nkt - 1);
             f16x8 wf[2][FI], xf[2][FJ];
             rd(nkt - 1, wf, xf);
+            per_step(nkt - 1);
             mm(wf, xf);
         }
     } else {
@@ -575,6 +582,7 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             sync(t);
             const bool refill = t + NS - 1 < nkt && !GTAV_DBG(p, 1);
             if (refill && !late) stage(t + NS - 1);
+            per_step(t);
             f16x8 wf[2][FI], xf[2][FJ];
             rd(t, wf, xf);
             mm(wf, xf);
@@ -658,10 +666,12 @@ constexpr int FOLD_NFR = 4;                          // frames a block tile can 
 constexpr int fold_lds_bytes(int tnb) { return FOLD_NFR * 2 * tnb * 4; }
 template <int FJ>
 struct FoldTok {
-    float mu[FJ], rs[FJ];
+    float mu[FJ], rs[FJ];       // mean / 1 / sqrt(var + eps) of token column j (token li of the lane)
     int b1, b2, b3;             // first tokens of the block tile's 2nd / 3rd / 4th frame
     int kmax;                   // last staged frame (token groups past M — ragged last tile — use it: their results are dropped, but must stay finite)
-    const char* cb;             // LDS: [frame k][c1 | c2][TNB] floats
+    int nchunk;                 // 16-byte chunks of the block's table slice: [frame k][c1 | c2][TNB] floats
+    f32x4 tpre;                 // this thread's chunk of it, fetched before the main loop
+    const char* cb;             // LDS copy, written in the epilogue (fold_tables_to_lds)
 };
 // frame (inside the block tile) of the 16-token group that starts at token m
 template <int FJ>
@@ -669,37 +679,52 @@ __device__ __forceinline__ int fold_frame_of(const FoldTok<FJ>& ft, int m) {
     const int k = (m >= ft.b1 ? 1 : 0) + (m >= ft.b2 ? 1 : 0) + (m >= ft.b3 ? 1 : 0);
     return k < ft.kmax ? k : ft.kmax;
 }
+// Everything the folded epilogue needs from memory is fetched BEFORE the main loop, behind the first fills (like the bias): the block's
+// table slice, one 16-byte chunk per compute thread `ct` (kept in 4 registers through the K loop, written to LDS when the ring is dead),
+// and the row statistics, reduced to (mean, rstd) at once (2 FJ registers).  In the epilogue the same loads were two dependent memory round
+// trips in front of every tile's tail — 10 us per launch at M = 5760, where the 512 resident blocks reach their epilogues together
+// (profiles/round3/fold_v1_ab_B8.txt).
 template <int TNB, int TM, int FJ>
-__device__ __forceinline__ void fold_stage_tables(const GemmParams& p, char* cb, int n0, int m0, FoldTok<FJ>& ft) {
+__device__ __forceinline__ void fold_prefetch(const GemmParams& p, int n0, int m0, int ct /* compute-thread index */, int mw /* first token of the wave */,
+                                              bool compute_wave, FoldTok<FJ>& ft) {
     const int mlast = m0 + TM - 1 < p.M ? m0 + TM - 1 : p.M - 1;
     const int f_first = m0 / p.f_P, nfr = mlast / p.f_P - f_first + 1;
     ft.b1 = (f_first + 1) * p.f_P; ft.b2 = ft.b1 + p.f_P; ft.b3 = ft.b2 + p.f_P;
     ft.kmax = nfr - 1;
-    ft.cb = cb;
     constexpr int Q = TNB / 4;                        // 16-byte chunks per table row slice
-    for (int idx = threadIdx.x; idx < nfr * 2 * Q; idx += (int)blockDim.x) {
-        const int k = idx / (2 * Q), r = idx - k * 2 * Q, t = r / Q, n4 = r - t * Q;
+    ft.nchunk = nfr * 2 * Q;
+    ft.tpre = f32x4{0.f, 0.f, 0.f, 0.f};
+    ft.cb = nullptr;
+    if (ct >= 0 && ct < ft.nchunk) {
+        const int k = ct / (2 * Q), r = ct - k * 2 * Q, t = r / Q, n4 = r - t * Q;
         int n = n0 + 4 * n4;
         n = n < p.N ? n : p.N - 4;
         const int row = p.f_rows ? p.f_rows[f_first + k] : f_first + k;
-        *(f32x4*)(cb + (size_t)((k * 2 + t) * TNB + 4 * n4) * 4) = *(const f32x4*)((t ? p.f_c2 : p.f_c1) + (size_t)row * p.f_ldc + n);
+        ft.tpre = *(const f32x4*)((t ? p.f_c2 : p.f_c1) + (size_t)row * p.f_ldc + n);
     }
-}
-template <int FJ>
-__device__ __forceinline__ void fold_prepare(const GemmParams& p, int mw /* first token of the wave (wave-uniform) */, FoldTok<FJ>& ft) {
+    if (!compute_wave) return;
+    // statistics: 64-feature slots (sum x, sum x^2); lane (li, g) adds quarter g of its token's slots in slot order, two xor-shuffles
+    // combine the quarters: ONE fixed order for every consumer block of the row
     const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
-    const int q = p.f_nslot >> 2;                       // slots per lane quarter (even: f_nslot % 8 == 0)
-    const float inv_d = 1.0f / (float)(p.f_nslot * 32);
+    const int q = p.f_nslot >> 2;                       // slots per lane quarter
+    const float inv_d = 1.0f / (float)(p.f_nslot * 64);
 #pragma unroll
     for (int j = 0; j < FJ; ++j) {
         int m = mw + 16 * j + li;
         m = m < p.M ? m : p.M - 1;
         const float* sp = p.f_stats + ((size_t)m * p.f_nslot + g * q) * 2;
         float a1 = 0.f, a2 = 0.f;
-        for (int s = 0; s < q; s += 2) {
-            const f32x4 v = *(const f32x4*)(sp + 2 * s);
-            a1 += v[0]; a2 += v[1];
-            a1 += v[2]; a2 += v[3];
+        if (q & 1) {
+            for (int s = 0; s < q; ++s) {
+                const float2 v = *(const float2*)(sp + 2 * s);
+                a1 += v.x; a2 += v.y;
+            }
+        } else {
+            for (int s = 0; s < q; s += 2) {
+                const f32x4 v = *(const f32x4*)(sp + 2 * s);
+                a1 += v[0]; a2 += v[1];
+                a1 += v[2]; a2 += v[3];
+            }
         }
         a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
         a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
@@ -707,6 +732,12 @@ __device__ __forceinline__ void fold_prepare(const GemmParams& p, int mw /* firs
         ft.mu[j] = mu;
         ft.rs[j] = 1.0f / sqrtf(fmaxf(a2 * inv_d - mu * mu, 0.f) + 1e-6f);
     }
+}
+// epilogue, ring dead: the prefetched table chunks into LDS (the caller barriers afterwards)
+template <int FJ>
+__device__ __forceinline__ void fold_tables_to_lds(FoldTok<FJ>& ft, char* cb, int ct) {
+    ft.cb = cb;
+    if (ct >= 0 && ct < ft.nchunk) *(f32x4*)(cb + (size_t)ct * 16) = ft.tpre;
 }
 // producer side: a wave's token span (<= 64) is at most one frame long, so it meets at most two frames — the one of its first token (A)
 // and the next (B)
@@ -765,7 +796,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
     int2* tab = (int2*)(smem + (TM * PN > TNB * PT ? TM * PN : TNB * PT));
     float amax = 0.f;
     __syncthreads();   // every wave is done reading the last K-step's stage
-    if constexpr (FOLD) fold_stage_tables<TNB, TM, FJ>(p, (char*)(tab + TM), n0, m0, ft);
+    if constexpr (FOLD) fold_tables_to_lds<FJ>(ft, (char*)(tab + TM), (int)threadIdx.x - 64 * WOFF);
     for (int r = threadIdx.x; r < TM; r += (int)blockDim.x) {
         const int m = m0 + r;
         int a = -1, b = 0;
@@ -903,9 +934,34 @@ __device__ __forceinline__ void prefetch_bias(const GemmParams& p, int n0, f32x4
     }
 }
 
+// EPI_RESID_FOLD: the residual tile the epilogue will update is fetched INSIDE the main loop, one 16-byte load per lane and K-step (MFMA tile
+// q = i FJ + j at K-step q; tiles [qlo, qhi) here), into FI x FJ x 4 registers.  Not in front of the loop: the two-stage rings wait vmcnt(0) at
+// every K-step, so a burst of FI FJ loads issued behind the prologue fills is awaited in full — 64 KB per block from HBM — before the first
+// MFMA (fold v2: out-proj at M = 5760 33.5 us against 22.3 us for the slab GEMM, 6 us of it this read; profiles/round3).
+template <int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
+__device__ __forceinline__ void prefetch_resid(const GemmParams& p, int n0, int m0, f32x4 (&xpre)[FI][FJ], int qlo, int qhi) {
+    const int lane = threadIdx.x & 63, w = (int)(threadIdx.x >> 6) - WOFF;
+    const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
+    const bool cw = w >= 0 && w < WN * WM;
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int q = i * FJ + j;
+            if (q < qlo || q >= qhi) continue;
+            const int m = m0 + 16 * FJ * wm + 16 * j + li;
+            xpre[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cw && n < p.N && m < p.M) xpre[i][j] = *(const f32x4*)((const float*)p.out + (size_t)m * p.ldo + n);
+        }
+    }
+}
+
+// prope: registers fetched before the main loop when PRE — the RoPE (cos, sin) values of a QKV epilogue, or the residual tile of EPI_RESID_FOLD;
+// ft: the fold consumer's prefetched statistics / table chunk (fold_prefetch), unused otherwise
 template <int EPIX, int FI, int FJ, int WM, int WN = 2, int WOFF = 0, bool PRE = false>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr,
-                                         const f32x4 (&prope)[FI][FJ]) {
+                                         const f32x4 (&prope)[FI][FJ], FoldTok<FJ>& ft) {
     constexpr int EPI = epi_base(EPIX);
     constexpr bool FOLD = epi_is_fold_consumer(EPIX);   // LayerNorm fold, consumer side: v = (acc - mean c1) rstd + c2 instead of acc + bias
     constexpr int TM = WM * 16 * FJ, TNB = 16 * FI * WN;
@@ -914,27 +970,25 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     const int wn = w % WN, wm = w / WN, li = lane & 15, g = lane >> 4;
     const bool compute_wave = w >= 0 && w < WN * WM;
     float amax = 0.f;
-    FoldTok<FJ> ft;
-    if constexpr (FOLD) {
-        if (compute_wave) fold_prepare<FJ>(p, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * wm), ft);
-    }
 
     if constexpr (EPI == EPI_RESID_FOLD) {
         // LayerNorm fold, producer side: the gated residual update in place, the next GEMM's operand A = x (1 + scale_next + 1e-6)
         // (fp16, assembled in LDS in the tile-major image and copied out as 1-KiB pieces like the GELU output) and the row's partial
-        // sums per 32-feature slot for the consumer's mean / rstd.
-        static_assert(EPI != EPI_RESID_FOLD || FI % 2 == 0, "a 32-feature statistics slot is two MFMA feature tiles of one wave");
+        // sums per 64-feature slot for the consumer's mean / rstd.  PRE: the residual tile was fetched before the main loop (prope) — the
+        // read half of the read-modify-write is then off the tile's tail (it cost 14 us per launch at M = 5760, where every block reaches
+        // its epilogue at the same time: profiles/round3/fold_v1_ab_B8.txt).
+        static_assert(EPI != EPI_RESID_FOLD || (FI == 2 || FI == 4), "a 64-feature statistics slot is one wave (FI = 4) or two (FI = 2)");
+        constexpr int WPS = 4 / FI;                     // waves per statistics slot
+        float2* sc = (float2*)(smem + CT * TM * 128);   // [wn][token of the tile]: per-wave partial sums, combined after the barrier
         __syncthreads();   // every wave is done reading the last K-step's stage
         if (compute_wave) {
             int rowA, rowB, boundary;
             fold_frames(p, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * wm), rowA, rowB, boundary);
             const float *gA = p.gate + (size_t)rowA * p.gate_stride, *gB = p.gate + (size_t)rowB * p.gate_stride;
             const float *sA = p.f_scale + (size_t)rowA * p.gate_stride, *sB = p.f_scale + (size_t)rowB * p.gate_stride;
-            float s1[FI / 2][FJ], s2[FI / 2][FJ];
+            float s1[FJ], s2[FJ];
 #pragma unroll
-            for (int h = 0; h < FI / 2; ++h)
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) s1[h][j] = 0.f, s2[h][j] = 0.f;
+            for (int j = 0; j < FJ; ++j) s1[j] = 0.f, s2[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
                 const int nl = 16 * FI * wn + 16 * i + 4 * g;
@@ -942,8 +996,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 const bool nok = n < p.N;
                 const int nc = nok ? n : 0;
                 const f32x4 bv = pbias[i];
-                const f32x4 gA4 = *(const f32x4*)(gA + nc), gB4 = *(const f32x4*)(gB + nc);
-                const f32x4 sA4 = *(const f32x4*)(sA + nc), sB4 = *(const f32x4*)(sB + nc);
+                f32x4 gA4, gB4, sA4, sB4;
+                if (GTAV_DBG(p, 0x100000)) {   // (experiments build: timing without the gate / scale loads)
+                    gA4 = gB4 = f32x4{0.5f, 0.5f, 0.5f, 0.5f}; sA4 = sB4 = f32x4{0.1f, 0.1f, 0.1f, 0.1f};
+                } else {
+                    gA4 = *(const f32x4*)(gA + nc); gB4 = *(const f32x4*)(gB + nc);
+                    sA4 = *(const f32x4*)(sA + nc); sB4 = *(const f32x4*)(sB + nc);
+                }
                 const int c = nl & 63;
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
@@ -953,43 +1012,51 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                     if (nok && m < p.M) {
                         float* dst = (float*)p.out + (size_t)m * p.ldo + n;
                         const bool inA = m0 + 16 * FJ * wm + 16 * j < boundary;
-                        const f32x4 gt = inA ? gA4 : gB4, sc = inA ? sA4 : sB4;
-                        f32x4 x = *(const f32x4*)dst;
+                        const f32x4 gt = inA ? gA4 : gB4, sc4 = inA ? sA4 : sB4;
+                        f32x4 x;
+                        if constexpr (PRE) x = prope[i][j];
+                        else x = *(const f32x4*)dst;
                         x = x + gt * (acc[i][j] + bv);
-                        if (p.out_sc1) store16_sc1(dst, x);
-                        else *(f32x4*)dst = x;
-                        s1[i / 2][j] += (x[0] + x[1]) + (x[2] + x[3]);
-                        s2[i / 2][j] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+                        if (!GTAV_DBG(p, 0x10000)) {
+                            if (p.out_sc1 && !GTAV_DBG(p, 0x80000)) store16_sc1(dst, x);
+                            else *(f32x4*)dst = x;
+                        }
+                        s1[j] += (x[0] + x[1]) + (x[2] + x[3]);
+                        s2[j] += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = x[e] * (1.0f + (sc[e] + 1e-6f));
+                        for (int e = 0; e < 4; ++e) a[e] = x[e] * (1.0f + (sc4[e] + 1e-6f));
                     }
                     char* ld = smem + ((nl >> 6) * TM + ml) * 128 + (((c >> 3) ^ (ml & 7)) << 4) + (c & 7) * 2;
                     *(uint2*)ld = pack4(amax, a[0], a[1], a[2], a[3]);
                 }
             }
-            const int nslot = p.N >> 5;
 #pragma unroll
-            for (int h = 0; h < FI / 2; ++h) {
-                const int slot = (n0 + 16 * FI * wn + 32 * h) >> 5;
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) {
-                    float t1 = s1[h][j], t2 = s2[h][j];
-                    t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
-                    t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
-                    const int m = m0 + 16 * FJ * wm + 16 * j + li;
-                    if (g == 0 && m < p.M && slot < nslot) *(float2*)(p.f_stats_out + ((size_t)m * nslot + slot) * 2) = float2{t1, t2};
-                }
+            for (int j = 0; j < FJ; ++j) {      // the wave's 16 FI features of token li: the four lane groups g hold a quarter each
+                float t1 = s1[j], t2 = s2[j];
+                t1 += __shfl_xor(t1, 16, 64); t2 += __shfl_xor(t2, 16, 64);
+                t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+                if (g == 0) sc[wn * TM + 16 * FJ * wm + 16 * j + li] = float2{t1, t2};
             }
         }
         sat_report(amax, p.err_flag);
         __syncthreads();
+        {   // statistics slots of the tile: the waves that share a slot, added in wave order
+            const int nslot = p.N >> 6;
+            for (int q = threadIdx.x; q < TM * (TNB / 64); q += (int)blockDim.x) {
+                const int sl = q / TM, tok = q - sl * TM;
+                float2 v = sc[sl * WPS * TM + tok];
+                if constexpr (WPS == 2) { const float2 u = sc[(sl * WPS + 1) * TM + tok]; v.x += u.x; v.y += u.y; }
+                const int m = m0 + tok, slot = (n0 >> 6) + sl;
+                if (m < p.M && slot < nslot && !GTAV_DBG(p, 0x40000)) *(float2*)(p.f_stats_out + ((size_t)m * nslot + slot) * 2) = v;
+            }
+        }
         const int nkt_out = p.N >> 6, last_rt = (p.M - 1) >> 7;
         constexpr int PR = TM / 8;
         for (int q = wraw; q < CT * PR; q += (int)(blockDim.x >> 6)) {
             const int cs = q / PR, pq = q - cs * PR;
             const int gr = m0 + 8 * pq;
             const int rt = gr >> 7;
-            if (rt > last_rt || (n0 >> 6) + cs >= nkt_out) continue;
+            if (rt > last_rt || (n0 >> 6) + cs >= nkt_out || GTAV_DBG(p, 0x20000)) continue;
             const uint4 val = *(const uint4*)(smem + (cs * TM + 8 * pq) * 128 + lane * 16);
             char* dst = (char*)p.f_a + ((size_t)rt * nkt_out + (n0 >> 6) + cs) * TILE_BYTES + ((gr & 127) >> 3) * 1024 + lane * 16;
             if (p.out_sc1) store16q_sc1(dst, val);
@@ -1005,7 +1072,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         // stores per lane.  Works for any block tile whose first token row is a multiple of 8 (96-token tiles included).
         __syncthreads();   // every wave is done reading the last K-step's stage
         if constexpr (FOLD) {
-            fold_stage_tables<TNB, TM, FJ>(p, smem + CT * TM * 128, n0, m0, ft);
+            fold_tables_to_lds<FJ>(ft, smem + CT * TM * 128, (int)threadIdx.x - 64 * WOFF);
             __syncthreads();
         }
         if (compute_wave) {
@@ -1068,7 +1135,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
     }
     if constexpr (FOLD) {   // (EPI_F32: the final projection)
         __syncthreads();   // every wave is done reading the last K-step's stage
-        fold_stage_tables<TNB, TM, FJ>(p, smem, n0, m0, ft);
+        fold_tables_to_lds<FJ>(ft, smem, (int)threadIdx.x - 64 * WOFF);
         __syncthreads();
     }
     if (!compute_wave) return;
@@ -1144,6 +1211,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 v = acc[i][j] + bv;
             }
             if constexpr (EPI == EPI_PARTIAL) {
+                // (fp16 slabs were tried for the large-M launches — half the slab bytes in the GEMM's tail and in the LayerNorm behind it — and
+                // changed nothing: B = 8 kernel time 7.43 ms either way, profiles/round3/fp16_slabs_B8_{on,off}.txt)
                 float* dst = (float*)p.out + ((size_t)ks * p.M + m) * p.ldo + n;
                 if (p.out_sc1) store16_sc1(dst, v);
                 else *(f32x4*)dst = v;
@@ -1192,7 +1261,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
 
 template <int EPIX, int FI, int FJ, int WM, int WN = 2, int WOFF = 0>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][FJ], const f32x4 (&pbias)[FI], char* smem, int n0, int m0, int ks, bool tr) {
-    epilogue<EPIX, FI, FJ, WM, WN, WOFF, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc);   // (the last argument is not read without PRE)
+    static_assert(!epi_is_fold_consumer(EPIX), "a fold consumer passes its prefetched FoldTok");
+    FoldTok<FJ> ft;
+    epilogue<EPIX, FI, FJ, WM, WN, WOFF, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);   // (prope / ft are not read without PRE / FOLD)
 }
 
 template <int EPIX, int NS, int WM, int FJ>
@@ -1215,15 +1286,28 @@ __global__ __launch_bounds__(128 * WM, (WM == 2 && NS <= 2) ? 2 : (WM == 4 ? 2 :
     bool tr = false;
     if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
     f32x4 pbias[4];
-    auto pf = [&]() { prefetch_bias<EPI, 4, WM>(p, n0, pbias); };
+    // (residual prefetch inside the K loop only with the counted-wait rings: the two-stage ring waits vmcnt(0) at every K-step, where one more
+    // load per step — an HBM miss — made every K-step as long as that miss: out-proj at M = 5760 33.5 -> 37.1 us, fc2 69.8 -> 94.8 us)
+    constexpr bool FOLDC = epi_is_fold_consumer(EPIX), FOLDP = EPI == EPI_RESID_FOLD, PREX = FOLDP && NS >= 3;
+    FoldTok<FJ> ft;
+    f32x4 xpre[PREX ? 4 : 1][PREX ? FJ : 1];
+    auto pf = [&]() {
+        prefetch_bias<EPI, 4, WM>(p, n0, pbias);
+        if constexpr (FOLDC) fold_prefetch<TN, TM, FJ>(p, n0, m0, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * (int)(threadIdx.x >> 7)), true, ft);
+    };
     if constexpr (EPI == EPI_QKV) {
         if (tr) mainloop<true, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         else mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    } else if constexpr (PREX) {
+        mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf, [&](int t) { prefetch_resid<4, FJ, WM>(p, n0, m0, xpre, t, t + 1); });
+        prefetch_resid<4, FJ, WM>(p, n0, m0, xpre, nkt, 4 * FJ);      // short K: the tiles the loop did not reach
     } else {
         mainloop<false, NS, WM, FJ>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPIX, 4, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
+    if constexpr (PREX) epilogue<EPIX, 4, FJ, WM, 2, 0, true>(p, acc, pbias, smem, n0, m0, ks, tr, xpre, ft);
+    else if constexpr (FOLDC || FOLDP) epilogue<EPIX, 4, FJ, WM, 2, 0, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);
+    else epilogue<EPIX, 4, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
 
@@ -1414,16 +1498,27 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 && NS == 2 && FI <= 4) ? 4 : (WM
         for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool tr = false;
     f32x4 pbias[FI];
-    auto pf = [&]() { prefetch_bias<EPI, FI, WM>(p, n0, pbias); };
+    constexpr bool FOLDC = epi_is_fold_consumer(EPIX), FOLDP = EPI == EPI_RESID_FOLD, PREX = FOLDP && NS >= 3;   // (see gemm_kernel)
+    FoldTok<FJ> ft;
+    f32x4 xpre[PREX ? FI : 1][PREX ? FJ : 1];
+    auto pf = [&]() {
+        prefetch_bias<EPI, FI, WM>(p, n0, pbias);
+        if constexpr (FOLDC) fold_prefetch<TNB, TM, FJ>(p, n0, m0, (int)threadIdx.x, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * (int)(threadIdx.x >> 7)), true, ft);
+    };
     if constexpr (EPI == EPI_QKV) {
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
         if (tr) mainloop_g<true, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         else mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    } else if constexpr (PREX) {
+        mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf, [&](int t) { prefetch_resid<FI, FJ, WM>(p, n0, m0, xpre, t, t + 1); });
+        prefetch_resid<FI, FJ, WM>(p, n0, m0, xpre, nkt, FI * FJ);
     } else {
         mainloop_g<false, NS, FI, FJ, WM>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
-    epilogue<EPIX, FI, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
+    if constexpr (PREX) epilogue<EPIX, FI, FJ, WM, 2, 0, true>(p, acc, pbias, smem, n0, m0, ks, tr, xpre, ft);
+    else if constexpr (FOLDC || FOLDP) epilogue<EPIX, FI, FJ, WM, 2, 0, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);
+    else epilogue<EPIX, FI, FJ, WM>(p, acc, pbias, smem, n0, m0, ks, tr);
     bs.end(p);
 }
 
@@ -1684,29 +1779,48 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
         for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool tr = false;
     f32x4 pbias[FI];
+    constexpr bool FOLDC = epi_is_fold_consumer(EPIX), FOLDP = EPI == EPI_RESID_FOLD;
+    FoldTok<FJ> ft;
+    // fold consumer: its table chunk and row statistics, fetched by the compute waves behind their first fragment reads' wait (after_prologue runs
+    // on the compute waves only: compute-thread index = threadIdx.x - 64 NL)
+    auto pff = [&]() {
+        if constexpr (FOLDC) {
+            const int cw = (int)(threadIdx.x >> 6) - NL;
+            fold_prefetch<TNB, TM, FJ>(p, n0, m0, (int)threadIdx.x - 64 * NL, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * (cw / WN)), cw >= 0, ft);
+        }
+    };
     if constexpr (EPI == EPI_QKV && FI * FJ <= 6) {   // small wave tiles: the RoPE values of the epilogue are fetched before the main loop (24 registers)
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
         f32x4 prope[FI][FJ];
         auto pfq = [&]() {
             prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias);
             prefetch_rope<FI, FJ, WM, WN, NL>(p, n0, m0, prope);
+            pff();
         };
         if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pfq);
         else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pfq);
         GTAV_STAMP(bs.t[2]);
-        epilogue<EPIX, FI, FJ, WM, WN, NL, true>(p, acc, pbias, smem, n0, m0, ks, tr, prope);
+        epilogue<EPIX, FI, FJ, WM, WN, NL, true>(p, acc, pbias, smem, n0, m0, ks, tr, prope, ft);
     } else if constexpr (EPI == EPI_QKV) {
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
+        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); pff(); };
         if (tr) mainloop_l<true, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         else mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         GTAV_STAMP(bs.t[2]);
-        epilogue<EPIX, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
-    } else {
-        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
+        epilogue<EPIX, FI, FJ, WM, WN, NL, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);
+    } else if constexpr (FOLDP) {
+        f32x4 xpre[FI][FJ];
+        // (compute waves of the loader-wave kernel issue no other vector-memory operation in the K loop and never wait on vmcnt there: the whole
+        // residual tile can be requested up front)
+        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); prefetch_resid<FI, FJ, WM, WN, NL>(p, n0, m0, xpre, 0, FI * FJ); };
         mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
         GTAV_STAMP(bs.t[2]);
-        epilogue<EPIX, FI, FJ, WM, WN, NL>(p, acc, pbias, smem, n0, m0, ks, tr);
+        epilogue<EPIX, FI, FJ, WM, WN, NL, true>(p, acc, pbias, smem, n0, m0, ks, tr, xpre, ft);
+    } else {
+        auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); pff(); };
+        mainloop_l<false, NS, FI, FJ, WN, WM, NL>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        GTAV_STAMP(bs.t[2]);
+        epilogue<EPIX, FI, FJ, WM, WN, NL, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);
     }
     bs.end(p);
 }
@@ -2343,7 +2457,7 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     auto set_gn = [&](int tmb, int tnb) { p.tm.gn = choose_gn(p.M, p.N, p.K, tmb, tnb, splitk); };
     // the LayerNorm-fold epilogues are instantiated for the shapes the heuristic can pick for them (2, 3, 11, 12, 14, 20)
     constexpr bool FOLDISH = EPI == EPI_RESID_FOLD || epi_is_fold_consumer(EPI);
-    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 14 || shape == 20,
+    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20,
                                         "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
     if constexpr (!FOLDISH) {
@@ -2378,6 +2492,11 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
         set_gn(96, 64);
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 2, 3>), grid, dim3(384));
+    } else if (shape == 13) {  // 128 features x 96 tokens, 4 waves of 64 x 48, two-stage ring, two blocks per CU: long-K N = 1024 GEMMs at a few thousand
+                               // tokens in ONE K slice (480 tiles at M = 5760 fill the 512 block slots; 128 x 128 has 360, 128 x 192 only 240)
+        set_gn(96, 128);
+        const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
+        GEMM_LAUNCH((gemm_g_kernel<EPI, 2, 4, 3, 2>), grid, dim3(256));
     } else if (shape == 12) {  // 128 features x 192 tokens, 8 waves of 64 x 48, two blocks per CU (4 waves per SIMD)
         set_gn(192, 128);
         const dim3 grid(cdiv(p.M, 192) * cdiv(p.N, 128) * splitk);
@@ -2502,8 +2621,8 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     if (fold_c || fold_p) {
         GTAV_REQUIRE(p.f_P > 0 && p.f_P % 16 == 0 && p.M % p.f_P == 0, "gemm/fold: %d tokens per frame must be a multiple of 16 and divide M=%d", p.f_P, p.M);
         if (fold_c) {
-            GTAV_REQUIRE(p.f_stats && p.f_c1 && p.f_c2 && p.f_ldc >= p.N && p.f_nslot == p.K / 32 && p.f_nslot % 8 == 0,
-                         "gemm/fold: consumer needs the row statistics (K/32 = %d slots, a multiple of 8) and the c1 / c2 tables", p.K / 32);
+            GTAV_REQUIRE(p.f_stats && p.f_c1 && p.f_c2 && p.f_ldc >= p.N && p.f_nslot == p.K / 64 && p.f_nslot % 4 == 0,
+                         "gemm/fold: consumer needs the row statistics (K/64 = %d slots, a multiple of 4) and the c1 / c2 tables", p.K / 64);
             GTAV_REQUIRE(!p.bias, "gemm/fold: the bias of a fold consumer lives in its c2 table");
             if (epi == EPI_QKV) GTAV_REQUIRE(p.qkv_mode == QKV_TEMPORAL || p.S % 16 == 0, "gemm/fold: spatial QKV needs S %% 16 == 0");
         } else {
@@ -2511,7 +2630,7 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
                          "gemm/fold: producer needs gate, next scale, statistics and operand buffers, N %% 64 == 0");
         }
     }
-    p.debug = g_debug & (3 | 16 | 32 | 2048 | 8192 | 16384);   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
+    p.debug = g_debug & (3 | 16 | 32 | 2048 | 8192 | 16384 | 0x1F0000);   // 0x10000.. : pieces of the fold producer epilogue off (timing, experiments build)   // bit 4: direct (unstaged) QKV epilogue; bit 5 (experiments): per-K-step stamps of the loader-wave kernels
     p.stamps = nullptr;
 #ifdef GTAV_EXPERIMENTS
     p.stamps = g_stamps;            // the tool sizes the buffer for the largest grid it launches (g_stamp_blocks)
@@ -2573,6 +2692,18 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         // below ~320 tiles the 512 block slots are too unevenly filled (fc2 at M = 5760: 240 tiles, 65.7 -> 73.1 us).
         wm = 12;   // 8 waves of 64 x 48 (four per SIMD with the co-resident block): QKV 60.3 -> 54.8, fc1 62.1 -> 59.4 vs the 4-wave form (shape 10)
     }
+    // Narrow outputs (the N = 1024 residual GEMMs) at a few thousand tokens: both two-blocks-per-CU tiles, 128 x 192 (shape 12) and 128 x 96
+    // (shape 13), run a grid that FILLS the 512 block slots once faster than 128 x 128 runs 360-720 blocks: out-proj at M = 5760 20.6 -> 16.8 us
+    // (shape 13: 480 tiles), at M = 11 520 33.4 -> 30.8 us and fc2 97.6 -> 90.2 us (shape 12: 480 tiles; the 256 x 256 tile lost to it),
+    // M = 2880 out-proj 13.7 -> 11.4 us, fc2 34.6 -> 27.9 us (shape 13, two K slices) — profiles/round3/gemm_shapes_*.txt.  The LayerNorm-fold
+    // producer takes the larger tile whenever its grid is more than half full (27.2 us against 33.5 us at M = 5760).
+    bool narrow_pick = false;
+    if (!g_force_wm && blocks128 > 256 && p.N <= 2048 && epi != EPI_QKV) {
+        const int t12 = cdiv(p.M, 192) * cdiv(p.N, 128) * splitk, t13 = cdiv(p.M, 96) * cdiv(p.N, 128) * splitk;
+        if (t12 > 256 && t12 <= 512) wm = 12, narrow_pick = true;
+        else if (t13 > 256 && t13 <= 512 && !fold_p) wm = 13, narrow_pick = true;
+        else if (fold_p && t12 > 128) wm = 12, narrow_pick = true;
+    }
     // large M: the persistent ping-pong kernel (epilogue and next tile's prologue under the other wave group's MFMAs)
     if (!g_force_wm && splitk == 1 && gemm_pp_ok(p.M, p.N, p.K, epi) && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL && p.S % 8 != 0)) wm = 16;
     GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");
@@ -2580,14 +2711,14 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     // store burst per round of 256 tiles) is not hidden by a co-resident block: they win only where the K loop is long
     // relative to the output and the grid is one well-filled round — the N = 1024 residual GEMMs at M >= 11 520
     // (profiles/round1/v12_gemm_256tile_microbench.txt: fc2 129 -> 98 us, out-proj 40 -> 35 us).
-    if (!g_force_wm && splitk == 1 && epi != EPI_QKV && !foldish && p.N % 256 == 0 && p.N <= 1024 && p.K >= 1024) {
+    if (!g_force_wm && splitk == 1 && epi != EPI_QKV && !foldish && !narrow_pick && p.N % 256 == 0 && p.N <= 1024 && p.K >= 1024) {
         const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
         if (t256 * 10 >= rounds * 256 * 7) wm = 7;
     }
-    int ns = g_force_stages ? g_force_stages : (wm == 12 ? 2 : wm >= 8 ? 4 : wm == 3 ? 4 : 2);   // (shapes 20+ carry their ring depth in the template)
+    int ns = g_force_stages ? g_force_stages : ((wm == 12 || wm == 13) ? 2 : wm >= 8 ? 4 : wm == 3 ? 4 : 2);   // (shapes 20+ carry their ring depth in the template)
     // a wave's token span (16 FJ) must not exceed a frame: the skinny 64 x 48 / 64 x 96 tiles span 16 / 32 tokens, the others 48-64
     if (foldish) {
-        const int span = wm == 2 ? 64 : (wm == 3 || wm == 14) ? 32 : wm == 11 ? 16 : 48;
+        const int span = wm == 2 ? 64 : (wm == 3 || wm == 14) ? 32 : wm == 11 ? 16 : 48;   // (12, 13, 20: 48)
         GTAV_REQUIRE(p.f_P >= span, "gemm/fold: frames of %d tokens are shorter than the token span (%d) of a wave of block shape %d", p.f_P, span, wm);
     }
     switch (epi_x) {

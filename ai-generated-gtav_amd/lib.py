@@ -117,6 +117,8 @@ SIGNATURES = {
     "gtav_op_gemm_qkvt_attn": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _i, _p],
     "gtav_op_gemm_splitk_ln": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
+    "gtav_op_gemm_fold_producer": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p],
+    "gtav_op_gemm_fold_consumer": [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],
     "gtav_op_gemm_set_stages": [_i],
     "gtav_op_gemm_set_wm": [_i],

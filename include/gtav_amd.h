@@ -314,6 +314,17 @@ int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16
                            int32_t N, int32_t K, int32_t splitk, float* parts_dev, float* resid_dev, const float* gate_dev,
                            int32_t gate_stride, int32_t rows_per_gate, void* out_f16_dev, const float* shift_dev,
                            const float* scale_dev, int32_t mod_stride, void* stream);
+/* The two halves of a folded LayerNorm seam (model/dit.py:19-27, 200-225) as the model runs them.
+ * producer: resid[m][n] += gate[f][n] (sum_k x[m][k] w[n][k] + bias[n]) in place (f = m / tokens_per_frame, vectors of frame f at
+ *   gate / next_scale + f * mod_stride); a_out (fp16 tile-major [round_up(M,128)][N]) = resid (1 + next_scale[f][n] + 1e-6); stats_out [M][N/64][2] =
+ *   (sum, sum of squares) of the updated row over each 64-feature slot.  N % 64 == 0, tokens_per_frame % 16 == 0 and >= 64, M % tokens_per_frame == 0.
+ * consumer: y[m][n] = (sum_k a[m][k] w[n][k] - mean_m c1[f][n]) rstd_m + c2[f][n] with mean / rstd of row m from stats (K / 64 slots), then epi 0:
+ *   out f32 row-major [M][ldo]; epi 2: GELU-tanh, fp16 tile-major with logical row length ldo.  c1 / c2: row f at + f * ldc. */
+int gtav_op_gemm_fold_producer(const void* x_f16_dev, const void* w_f16_dev, const float* bias_dev, float* resid_dev, int32_t M, int32_t N, int32_t K,
+                               const float* gate_dev, const float* next_scale_dev, int32_t mod_stride, int32_t tokens_per_frame, void* a_out_f16_dev,
+                               float* stats_out_dev, void* stream);
+int gtav_op_gemm_fold_consumer(const void* a_f16_dev, const void* w_f16_dev, int32_t M, int32_t N, int32_t K, int32_t epi, const float* stats_dev,
+                               const float* c1_dev, const float* c2_dev, int32_t ldc, int32_t tokens_per_frame, void* out_dev, int32_t ldo, void* stream);
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K);
 /* (The per-thread hooks the parity tests use to force a GEMM block shape / pipeline depth are declared in gtav_amd_testing.h: they are
  * not part of the product interface.) */
