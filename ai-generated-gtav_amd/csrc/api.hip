@@ -288,8 +288,13 @@ struct gtav_dit {
     // consumer: ctab [max_rows][CTW] (built next to the modulation table, one grouped GEMM), ctab_cur [maxB * maxT][CTW] = the rows of the
     // current sampler step (gathered with mod_cur).  Groups are ordered fc1 seams, to_qkv seams, final: a launch over the first n covers a prefix.
     struct Fold {
-        bool ok = false;              // geometry allows it (tokens per frame % 16 == 0 and >= 64, D % 256 == 0) and the buffers exist
+        bool geom_ok = false;         // tokens per frame % 16 == 0 and >= 64, D % 256 == 0
+        bool ok = false;              // ... and the buffers exist (fold_alloc: first gtav_dit_set_fold that enables anything)
         int mode = 1;                 // 0 = never, 1 = heuristic (min_m_a / min_m_b), 2 = every seam at every M (tests)
+        // Measured (profiles/round3/fold_v*_ab_B{1,8}.txt, one process per A/B): the folded path is CORRECT (tests/test_gpu_fold.py) but not
+        // faster on MI355X at any size tried — B = 8 forward 8.11 ms unfolded, 8.36 ms with seam A folded, 9.03 ms with both; B = 1 2.33 /
+        // 2.47 ms — so the default thresholds never fold; gtav_dit_set_fold(h, 1, a, b) / (h, 2, ..) select it (DESIGN.md 4.7 has the why:
+        // the LayerNorm's bytes move into GEMM tails that every resident block reaches at the same time).
         int min_m_a = 1 << 30, min_m_b = 1 << 30;
         int CTW = 0, n_groups = 0, n_groups_a = 0, Rp = 0;
         std::vector<int> col_c;       // column of seam s's c1 in a ctab row (c2 follows at + N_s): s = 2 hb (to_qkv), 2 hb + 1 (fc1), 4 L (final)
@@ -329,6 +334,62 @@ struct gtav_dit {
         f16 *g_d = nullptr, *g_h = nullptr, *g_u = nullptr, *g_qkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dfo = nullptr;
     } tr;
 };
+
+// LayerNorm fold: tables, statistics and the grouped-GEMM descriptors, allocated by the first gtav_dit_set_fold that can fold anything
+static int fold_alloc(gtav_dit* h) {
+    gtav_dit::Fold& f = h->fold;
+    if (f.ok) return 0;
+    GTAV_REQUIRE(f.geom_ok, "dit_set_fold: this geometry has no LayerNorm fold (tokens per frame %d must be a multiple of 16 and >= 64, hidden %% 256 == 0)", h->P);
+    Arena& a = h->arena;
+    const int D = h->D;
+    const size_t Mx = round_up(h->Mmax, 128);
+    int rc = 0;
+#define A_(expr) do { if (!rc) rc = (expr); } while (0)
+    {
+        const int nhb = h->L * 2, nseam = 2 * nhb + 1;
+        // ctab row: [fc1 seams | to_qkv seams | final], each seam c1 [N] then c2 [N]
+        f.col_c.assign(nseam, 0);
+        int col = 0;
+        for (int hb = 0; hb < nhb; ++hb) { f.col_c[2 * hb + 1] = col; col += 2 * h->Hm; }
+        for (int hb = 0; hb < nhb; ++hb) { f.col_c[2 * hb] = col; col += 2 * 3 * D; }
+        f.col_c[2 * nhb] = col; col += 2 * h->Nfin;
+        f.CTW = col;
+        f.n_groups = 2 * nseam; f.n_groups_a = 2 * nhb;
+        f.Rp = round_up(h->max_rows, 128);
+        A_(a.alloc_t(&f.ctab, (size_t)h->max_rows * f.CTW));
+        A_(a.alloc_t(&f.ctab_cur, (size_t)h->maxB * h->maxT * f.CTW));
+        A_(a.alloc_t(&f.stats, Mx * (size_t)(D / 64) * 2));
+        A_(a.alloc_t(&f.sx, (size_t)f.n_groups * f.Rp * D));
+        A_(a.alloc_t(&f.groups_dev, f.n_groups)); A_(a.alloc_t(&f.gcol_dev, f.n_groups)); A_(a.alloc_t(&f.gscale_dev, f.n_groups));
+        if (!rc) {
+            // group 2 q + kind (kind 0: scale -> c1, kind 1: shift -> c2), q = position of the seam in the ctab row order
+            std::vector<GemmGroup> groups(f.n_groups);
+            std::vector<int> gcol(f.n_groups), gsc(f.n_groups);
+            auto add = [&](int q, int seam, const f16* W, int N, const float* bias, int shift_col, int scale_col) {
+                for (int kind = 0; kind < 2; ++kind) {
+                    GemmGroup& g = groups[2 * q + kind];
+                    g.X = f.sx + (size_t)(2 * q + kind) * f.Rp * D; g.W = W; g.N = N; g.ldo = f.CTW;
+                    g.out = f.ctab + f.col_c[seam] + (kind ? N : 0); g.bias = kind ? bias : nullptr;
+                    gcol[2 * q + kind] = kind ? shift_col : scale_col; gsc[2 * q + kind] = kind ? 0 : 1;
+                }
+            };
+            for (int hb = 0; hb < nhb; ++hb) {   // chunk order of a half-block's modulation: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+                add(hb, 2 * hb + 1, h->halves[hb].w_fc1, h->Hm, h->halves[hb].b_fc1, (hb * 6 + 3) * D, (hb * 6 + 4) * D);
+                add(nhb + hb, 2 * hb, h->halves[hb].w_qkv, 3 * D, nullptr, (hb * 6 + 0) * D, (hb * 6 + 1) * D);
+            }
+            add(2 * nhb, 2 * nhb, h->w_final, h->Nfin, h->b_final, h->L * 12 * D, h->L * 12 * D + D);
+            if (hipMemcpy(f.groups_dev, groups.data(), groups.size() * sizeof(GemmGroup), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(f.gcol_dev, gcol.data(), gcol.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(f.gscale_dev, gsc.data(), gsc.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("dit_create: upload of the LayerNorm-fold group tables failed");
+                rc = 1;
+            }
+            f.ok = !rc;
+        }
+    }
+#undef A_
+    return rc;
+}
 
 // LayerNorm fold: which seams run folded at M tokens (seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection)
 static void fold_policy(const gtav_dit* h, int M, bool& fa, bool& fb) {
@@ -593,50 +654,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT));
     A_(a.alloc_t(&h->mod_cur, (size_t)h->maxB * h->maxT * h->MODW)); A_(a.alloc_t(&h->mod_last, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->mod_changed, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
     h->use_graph = GTAV_ENV_INT("GTAV_GRAPH", 1) != 0;   // the shipped library reads no environment: gtav_dit_set_graph() is the switch
-    if (!rc && h->P % 16 == 0 && h->P >= 64 && D % 256 == 0 && h->Hm % 128 == 0 && h->Nfin % 4 == 0) {
-        gtav_dit::Fold& f = h->fold;
-        const int nhb = h->L * 2, nseam = 2 * nhb + 1;
-        // ctab row: [fc1 seams | to_qkv seams | final], each seam c1 [N] then c2 [N]
-        f.col_c.assign(nseam, 0);
-        int col = 0;
-        for (int hb = 0; hb < nhb; ++hb) { f.col_c[2 * hb + 1] = col; col += 2 * h->Hm; }
-        for (int hb = 0; hb < nhb; ++hb) { f.col_c[2 * hb] = col; col += 2 * 3 * D; }
-        f.col_c[2 * nhb] = col; col += 2 * h->Nfin;
-        f.CTW = col;
-        f.n_groups = 2 * nseam; f.n_groups_a = 2 * nhb;
-        f.Rp = round_up(h->max_rows, 128);
-        A_(a.alloc_t(&f.ctab, (size_t)h->max_rows * f.CTW));
-        A_(a.alloc_t(&f.ctab_cur, (size_t)h->maxB * h->maxT * f.CTW));
-        A_(a.alloc_t(&f.stats, Mx * (size_t)(D / 64) * 2));
-        A_(a.alloc_t(&f.sx, (size_t)f.n_groups * f.Rp * D));
-        A_(a.alloc_t(&f.groups_dev, f.n_groups)); A_(a.alloc_t(&f.gcol_dev, f.n_groups)); A_(a.alloc_t(&f.gscale_dev, f.n_groups));
-        if (!rc) {
-            // group 2 q + kind (kind 0: scale -> c1, kind 1: shift -> c2), q = position of the seam in the ctab row order
-            std::vector<GemmGroup> groups(f.n_groups);
-            std::vector<int> gcol(f.n_groups), gsc(f.n_groups);
-            auto add = [&](int q, int seam, const f16* W, int N, const float* bias, int shift_col, int scale_col) {
-                for (int kind = 0; kind < 2; ++kind) {
-                    GemmGroup& g = groups[2 * q + kind];
-                    g.X = f.sx + (size_t)(2 * q + kind) * f.Rp * D; g.W = W; g.N = N; g.ldo = f.CTW;
-                    g.out = f.ctab + f.col_c[seam] + (kind ? N : 0); g.bias = kind ? bias : nullptr;
-                    gcol[2 * q + kind] = kind ? shift_col : scale_col; gsc[2 * q + kind] = kind ? 0 : 1;
-                }
-            };
-            for (int hb = 0; hb < nhb; ++hb) {   // chunk order of a half-block's modulation: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-                add(hb, 2 * hb + 1, h->halves[hb].w_fc1, h->Hm, h->halves[hb].b_fc1, (hb * 6 + 3) * D, (hb * 6 + 4) * D);
-                add(nhb + hb, 2 * hb, h->halves[hb].w_qkv, 3 * D, nullptr, (hb * 6 + 0) * D, (hb * 6 + 1) * D);
-            }
-            add(2 * nhb, 2 * nhb, h->w_final, h->Nfin, h->b_final, h->L * 12 * D, h->L * 12 * D + D);
-            if (hipMemcpy(f.groups_dev, groups.data(), groups.size() * sizeof(GemmGroup), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(f.gcol_dev, gcol.data(), gcol.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(f.gscale_dev, gsc.data(), gsc.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-                set_error("dit_create: upload of the LayerNorm-fold group tables failed");
-                rc = 1;
-            }
-            f.ok = !rc;
-            f.min_m_a = 1024; f.min_m_b = 1024;   // measured thresholds: DESIGN.md 4.7
-        }
-    }
+    h->fold.geom_ok = h->P % 16 == 0 && h->P >= 64 && D % 256 == 0 && h->Hm % 128 == 0 && h->Nfin % 4 == 0;   // buffers: gtav_dit_set_fold (fold_alloc)
 #undef A_
     if (rc) {
         delete h;
@@ -873,14 +891,14 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable) {
 
 int gtav_dit_set_fold(gtav_dit* h, int32_t mode, int32_t min_tokens_a, int32_t min_tokens_b) {
     GTAV_REQUIRE(h && mode >= 0 && mode <= 2, "dit_set_fold: mode %d", mode);
-    GTAV_REQUIRE(mode == 0 || h->fold.ok, "dit_set_fold: this geometry has no LayerNorm fold (tokens per frame %d must be a multiple of 16 and >= 64)", h->P);
+    if (min_tokens_a >= 0) h->fold.min_m_a = min_tokens_a;
+    if (min_tokens_b >= 0) h->fold.min_m_b = min_tokens_b;
+    if (mode == 2 || (mode == 1 && (h->fold.min_m_a < (1 << 30) || h->fold.min_m_b < (1 << 30)))) RET_IF(fold_alloc(h));
     for (auto& kv : h->graphs)       // captured sampler steps contain the other kernel sequence
         if (kv.second) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
     h->prepared.valid = false;       // the per-frame tables were built for the old policy
     h->fold.mode = mode;
-    if (min_tokens_a >= 0) h->fold.min_m_a = min_tokens_a;
-    if (min_tokens_b >= 0) h->fold.min_m_b = min_tokens_b;
     return 0;
 }
 

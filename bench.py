@@ -15,8 +15,10 @@ Launching: `python bench.py --gpus N` with WORLD_SIZE unset starts N rank proces
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     — the dominant kernel (fc1 GEMM with the GELU epilogue, csrc/gemm.hip), timed in situ with HIP events attached to
-                 the kernel's own dispatch (hipExtLaunchKernel) during real forwards; algorithmic FLOPs per launch / mean duration
+  roofline     — the dominant kernel = the GEMM class (to_qkv / out-proj / fc1 / fc2, csrc/gemm.hip) with the LARGEST time per forward, timed
+                 in situ with HIP events attached to the kernel's own dispatch (hipExtLaunchKernel) during real forwards; algorithmic FLOPs
+                 per launch / mean duration; plus the FLOP-weighted aggregate over the four GEMM classes, the worst class and every class's
+                 fraction; `traffic` / `mfma_busy_pmc` from the committed rocprofv3 --pmc passes on the same kernel source (profiles/traffic.json)
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py, fp32 torch CPU kernels — the reference's own CPU path) on the host cores, a
                  bounded sample extrapolated to the clip (rank 0, N = 1 only)
   config2/3    — the batch-8 action-conditioned leg: frames/s (window + context-cached), forward time, fc1 in situ, per-class ms
@@ -255,19 +257,19 @@ def rank_main(args):
             dist.destroy_process_group()
 
 
-def traffic_for(M):
-    """HBM bytes per fc1 launch from the committed rocprofv3 --pmc passes (profiles/traffic.json, written by tools/gemm_traffic.sh
-    from the torch-free driver tools/gemm_pmc).  The file records the sha of csrc/gemm.hip it was measured on: a different kernel
-    source means the number is stale and `traffic` is reported as null instead."""
+def traffic_for(cls, M):
+    """HBM bytes per launch and MFMA-busy fraction of GEMM class `cls` ("qkv", "out", "fc1", "fc2") at M tokens from the committed rocprofv3
+    --pmc passes (profiles/traffic.json, written by tools/gemm_traffic.sh from the torch-free driver tools/gemm_pmc).  The file records the sha
+    of csrc/gemm.hip it was measured on: a different kernel source means the numbers are stale and they are reported as null instead."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
-        return None, "profiles/traffic.json missing"
+        return None, None, "profiles/traffic.json missing"
     tj = json.load(open(tpath))
     sha = hashlib.sha256(open(os.path.join(ROOT, "ai-generated-gtav_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
     if tj.get("gemm_hip_sha16") != sha:
-        return None, "profiles/traffic.json was measured on another build of csrc/gemm.hip (stale)"
-    ent = tj.get("fc1_M%d" % M)
-    return (ent or {}).get("hbm_bytes_per_launch"), tj.get("source", "")
+        return None, None, "profiles/traffic.json was measured on another build of csrc/gemm.hip (stale)"
+    ent = tj.get("%s_M%d" % (cls, M)) or {}
+    return ent.get("hbm_bytes_per_launch"), ent.get("mfma_busy"), tj.get("source", "")
 
 
 def bench_generate(args, world, rank, dev, dist, torch):
@@ -364,24 +366,37 @@ def bench_generate(args, world, rank, dev, dist, torch):
         M = b * 5 * P_TOK
         flops_fc1 = 2.0 * M * HM * D_MODEL
         ev_ms, ev_n = prof.pop("empty_event_pair")
-        ms_fc1, n_fc1 = prof["gemm_fc1"]
-        avg_fc1_ms = ms_fc1 / max(n_fc1, 1)
-        ach = flops_fc1 / (avg_fc1_ms * 1e-3) / 1e12
-        traffic, tsrc = traffic_for(M)
-        roofline = {"kernel": "fc1 GEMM + GELU-tanh epilogue (csrc/gemm.hip, M=%d N=4096 K=1024, fp16 MFMA)" % M, "bound": "mfma",
-                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                    "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": round(avg_fc1_ms * 1e3, 2), "launches_timed": int(n_fc1),
-                    "flops_per_launch": flops_fc1, "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
-                    "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2)}
         classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
         # per GEMM class: achieved TFLOP/s from its algorithmic FLOPs (2 M N K per launch)
         gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": flops_fc1,
                  "gemm_fc2": flops_fc1}
+        shape_of = {"gemm_qkv": "to_qkv GEMM + RoPE / head-layout epilogue (N=3072 K=1024)", "gemm_out": "out-proj GEMM (N=1024 K=1024, residual epilogue / split-K slabs)",
+                    "gemm_fc1": "fc1 GEMM + GELU-tanh epilogue (N=4096 K=1024)", "gemm_fc2": "fc2 GEMM (N=1024 K=4096, residual epilogue / split-K slabs)"}
+        tot_fl = tot_ms = 0.0
         for k, fl in gflop.items():
             ms, n = prof[k]
             if n:
                 classes[k]["us_per_launch"] = round(ms / n * 1e3, 2)
                 classes[k]["tflops"] = round(fl / (ms / n * 1e-3) / 1e12, 1)
+                classes[k]["frac_of_mfma_peak"] = round(fl / (ms / n * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+                tot_fl += fl * n
+                tot_ms += ms
+        # the roofline object describes the DOMINANT kernel: the GEMM class with the largest time per forward (not the best-looking one)
+        dom = max(gflop, key=lambda k: prof[k][0])
+        ms_d, n_d = prof[dom]
+        avg_ms = ms_d / max(n_d, 1)
+        ach = gflop[dom] / (avg_ms * 1e-3) / 1e12
+        traffic, mfma_busy, tsrc = traffic_for(dom.replace("gemm_", ""), M)
+        worst = min(gflop, key=lambda k: classes[k].get("tflops", 1e30))
+        roofline = {"kernel": "%s, csrc/gemm.hip, M=%d, fp16 MFMA (the GEMM class with the largest time per forward)" % (shape_of[dom], M), "bound": "mfma",
+                    "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "traffic": traffic, "mfma_busy_pmc": mfma_busy, "traffic_source": tsrc, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": int(n_d),
+                    "flops_per_launch": gflop[dom], "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
+                    "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2),
+                    "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,
+                    "gemm_aggregate_note": "FLOP-weighted over the four GEMM classes: sum of 2 M N K over their launches / sum of their launch times",
+                    "worst_class": {"kernel": shape_of[worst], "frac": classes[worst].get("frac_of_mfma_peak")},
+                    "per_class_frac": {k.replace("gemm_", ""): classes[k].get("frac_of_mfma_peak") for k in gflop}}
         fwd_flops = dit_forward_flops(M, b * 5, 15, b)
         step_tflops = fwd_flops / (fwd_ms * 1e-3) / 1e12
         dit_step = {"forward_ms_B%d_T5" % b: round(fwd_ms, 3), "executed_tflop_per_forward": round(fwd_flops / 1e12, 4),
@@ -422,6 +437,30 @@ def bench_generate(args, world, rank, dev, dist, torch):
                    "roofline": broof, "dit_step": bstep}
         batched.update(algo_report(Bb, bres, args.batched_clips))
         del binp
+
+    # ---- multi-GPU self-validation (N > 1, outside every timed region): rank 0 recomputes the shard of the LAST rank on its own GPU (same
+    # per-GPU batch, same kernels, inputs a function of the global sample ids) for a short clip and requires the all-gathered latents of that
+    # shard to be EQUAL bit for bit — wrong gather order, wrong sharding or a rank-dependent result fails the run instead of passing silently ----
+    shard_check = None
+    if world > 1:
+        from gtav_amd.generate import shard_inputs as _si
+        ct, cs = n_prompt + 2, 3
+        _, fr_me, nz_me = _si(world * B, rank, world, n_prompt, ct, (FH, FW), (LH, LW), seed=4242)
+        xg, _ = generate_clip(dit, vae, fr_me.to(dev), nz_me.to(dev), ct, cs, None, ctx_cache=False) if vae is not None else (None, None)
+        if xg is not None and rank == 0:
+            other = world - 1
+            _, fr_o, nz_o = _si(world * B, other, world, n_prompt, ct, (FH, FW), (LH, LW), seed=4242)
+            xo, _ = generate_clip(dit, vae, fr_o.to(dev), nz_o.to(dev), ct, cs, None, ctx_cache=False, gather=False)
+            same = bool(torch.equal(xg[other * B:(other + 1) * B], xo)) and bool(torch.equal(xg[:B], xg[:B]))
+            shard_check = {"passed": same, "what": "latents of rank %d's shard (global samples %d..%d) as all-gathered == recomputed on rank 0, bit for bit; "
+                                                   "%d-frame clip, %d noise steps" % (other, other * B, (other + 1) * B - 1, ct, cs),
+                           "per_sample_abs_sum": [round(float(v), 6) for v in xg.abs().sum(dim=(1, 2, 3, 4)).cpu()]}
+            if not same:
+                sys.stderr.write("bench.py: SHARD SELF-CHECK FAILED: the gathered latents of rank %d differ from rank 0's recomputation\n" % other)
+        elif xg is not None and world > 1:
+            pass   # (the other ranks only take part in the gather)
+        if world > 1:
+            dist.barrier()
 
     # ---- bounded training leg (N = 1): the optimisation step of SURVEY.md 8(f)1 on latents already in HBM (the VAE encode of the trainer
     # is measured by --mode train / train_step) ----
@@ -542,6 +581,8 @@ def bench_generate(args, world, rank, dev, dist, torch):
             line["config2" if world == 1 else "config3"] = batched
         if train_leg is not None:
             line["train_step"] = train_leg
+        if shard_check is not None:
+            line["shard_self_check"] = shard_check
         print(json.dumps(line))
 
 

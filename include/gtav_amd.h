@@ -29,7 +29,7 @@
  *                            synchronous hipMemcpy (the multi-tensor AdamW tables)
  *   gtav_dit_train_stats     copies four floats back and synchronises `stream`
  *   gtav_dit_get_opt_step / gtav_dit_set_opt_step   copy the optimizer's control words and synchronise `stream`
- *   gtav_dit_set_fold        destroys the captured graphs of the handle
+ *   gtav_dit_set_fold        destroys the captured graphs of the handle; the first enabling call allocates the fold's tables (hipMalloc + hipMemset)
  *   gtav_comm_unique_id / gtav_comm_init / gtav_comm_destroy   dlopen of librccl.so on first use; RCCL's own bootstrap (blocking)
  * The library reads no environment variables (RCCL, once loaded, reads its own NCCL_* / RCCL_* variables).
  */
@@ -122,10 +122,12 @@ int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
  * (model/dit.py:19-27, 200-225: out-proj -> fc1 = seam A, fc2 -> next to_qkv / final projection = seam B) can run inside the two GEMM
  * epilogues instead of as a launch of its own: the producer updates the residual in place and emits x (1 + scale) plus per-row partial
  * sums, the consumer applies (acc - mean c1) rstd + c2 with per-frame tables c1 / c2 built next to the adaLN table.  Same arithmetic up to
- * fp32 summation order and one fp16 rounding of a differently scaled operand.  mode 0 = never, 1 = where it is measured faster (default:
- * a seam folds at >= min_tokens tokens per forward), 2 = every seam at every size.  min_tokens_a / _b < 0 keep the current thresholds.
- * Drops the captured graphs and the prepared frame of the handle; ignored (never folded) on handles with training enabled or
- * gtav_dit_set_fused_temporal on, and on geometries whose frames are not a multiple of 16 (>= 64) tokens. */
+ * fp32 summation order and one fp16 rounding of a differently scaled operand.  mode 0 = never, 1 = a seam folds at >= min_tokens tokens
+ * per forward (the default mode; the default thresholds are "never": on MI355X the folded path measured slower than the separate LayerNorm
+ * launch at every size tried), 2 = every seam at every size.  min_tokens_a / _b < 0 keep the current thresholds.
+ * The first call that can fold anything allocates the tables (hipMalloc + hipMemset; fails on geometries whose frames are not a multiple of
+ * 16 and >= 64 tokens); every call drops the captured graphs and the prepared frame of the handle.  Never folded on handles with training
+ * enabled or gtav_dit_set_fused_temporal on. */
 int gtav_dit_set_fold(gtav_dit* h, int32_t mode, int32_t min_tokens_a, int32_t min_tokens_b);
 
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by

@@ -671,3 +671,33 @@ def test_read_prompt_frame_and_video_out(tmp_path):
     out = write_video(str(tmp_path / "clip.mp4"), frames, fps=10)          # no torchvision here: lands as Motion-JPEG AVI
     back = read_avi_mjpeg(out)
     assert back.shape == frames.shape and (back.int() - frames.int()).abs().float().mean().item() < 2.0
+
+
+def test_config0_production_size_vs_reference_golden(full_dit, full_vae):
+    """BASELINE configs[0] at PRODUCTION size (fixture G9: the reference's DiT-S/2 — 16 blocks, 608 M parameters — and its full ViT-L/20 VAE
+    through the reference's own vae_encode / denoise_step loop / decode tail, generate.py:50-66,186-244): dummy-ramp prompt frame ->
+    4-frame / 10-step rollout (33 full-size forwards, windows of 2, 3 and 4 frames) -> frames and bytes, through the product's harness."""
+    from gtav_amd.dummy_dataset import ImageDataset
+    from gtav_amd.generate import generate_latents, vae_decode_frames, vae_encode
+    m, _, _ = full_dit
+    v, _, _ = full_vae
+    g = load_file(os.path.join(GOLD, "g9_config0_full.safetensors"))
+    clip = ImageDataset(split="test")[0]["video"]
+    assert torch.equal(clip[None, :1, :, ::8, ::8], g["prompt_frames"])
+    x0 = vae_encode(clip[None, :1].to(dev()), v, 1)
+    e_enc = rel_l2(x0, g["latents_prompt"])
+    lat = generate_latents(m, x0, 4, 10, g["noise"], g["actions"])
+    e_lat = rel_l2(lat, g["latents_final"])
+    lat_c = generate_latents(m, x0, 4, 10, g["noise"], g["actions"], ctx_cache=True)
+    f32 = vae_decode_frames(lat, v, to_uint8=False)
+    u8 = vae_decode_frames(lat, v, to_uint8=True)
+    ref_f = g["frames_f32_stride4"]
+    got_f = f32.cpu().permute(0, 1, 3, 4, 2)[:, :, ::4, ::4]
+    e_img = rel_l2(got_f, ref_f)
+    dmax = (got_f - ref_f).abs().max().item() * 255
+    diff = (u8.cpu()[:, :, ::4, ::4].int() - g["frames_u8_stride4"].int()).abs()
+    print(f"config0 full size: encode {e_enc:.2e} latents {e_lat:.2e} (cached vs window {rel_l2(lat_c, lat):.1e}) frames {e_img:.2e} "
+          f"(max |err| {dmax:.3f} of 255); {int((diff > 0).sum())} of {diff.numel()} bytes differ, max {int(diff.max())}")
+    # 33 chained full-size forwards: per-forward error 6-9e-4 (TOL_FULL), accumulated over the rollout
+    assert e_enc < TOL_FULL and e_lat < 5e-3 and e_img < 5e-3 and rel_l2(lat_c, lat) < 1e-4
+    assert diff.max().item() <= 2 and int((diff > 0).sum()) < 0.3 * diff.numel()

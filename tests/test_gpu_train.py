@@ -327,3 +327,159 @@ def test_overlapped_all_reduce_path_single_rank_process_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# round 3: checkpoint / resume (train_dit.py:765-849), overflow by fp16 saturation, the general frame loop
+# ------------------------------------------------------------------------------------------------------------------------
+def _step_inputs(B=2, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(B, 5, 16, 8, 16, generator=g) * 0.5
+    a = torch.zeros(B, 5, 25)
+    a[:, :, 3] = 1
+    tgt, ctx = torch.tensor([30, 10][:B]), torch.tensor([5, 20][:B])
+    cn = torch.randn(B, 4, 16, 8, 16, generator=g)
+    nz = torch.randn(B, 1, 16, 8, 16, generator=g)
+    return lat, a, tgt, ctx, cn, nz
+
+
+def test_save_state_load_state_resumes_bit_exactly(tmp_path):
+    """accelerator.save_state / load_state (train_dit.py:765-849): three optimisation steps straight == two steps, save_state, a FRESH
+    model (new handle: masters, AdamW moments, step counters, loss scale restored through the C-ABI), load_state, one more step — the
+    weights must be EQUAL bit for bit, and step.json carries step / epoch / skip_iter like the reference's load_checkpoint."""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT
+    from gtav_amd.train import load_state, save_state, training_step
+    lat, a, tgt, ctx, cn, nz = _step_inputs()
+    kw = dict(lr=3e-4, weight_decay=0.01, max_grad_norm=1.0)
+    sd = W.synth_state_dict(W.dit_param_shapes(**KW), seed=1)
+
+    def fresh():
+        m = DiT(**KW, max_batch=2, max_frames=5, init_weights=False, trainable=True)
+        m.load_state_dict(sd)
+        return m
+    m1 = fresh()
+    for _ in range(3):
+        training_step(m1, lat, a, tgt, ctx, cn, nz, **kw)
+    m1.pull_weights()
+    straight = {k: v.clone() for k, v in m1._sd.items()}
+    m2 = fresh()
+    for _ in range(2):
+        training_step(m2, lat, a, tgt, ctx, cn, nz, **kw)
+    ck = str(tmp_path / "train_checkpoints" / "dit_last")
+    save_state(m2, ck, global_step=2, epoch=0)
+    opt = m2.opt_state_dict()
+    assert int(opt["step"][0]) == 2 and int(opt["step"][1]) == 0 and float(opt["v.blocks.0.s_mlp.fc1.weight"].abs().max()) > 0
+    del m2
+    m3 = DiT(**KW, max_batch=2, max_frames=5, init_weights=True, trainable=True)         # other weights until load_state
+    st = load_state(m3, ck, steps_per_epoch=7, gradient_accumulation_steps=4)
+    assert st["step"] == 2 and st["epoch"] == 0 and st["skip_iter"] == 8
+    training_step(m3, lat, a, tgt, ctx, cn, nz, **kw)
+    m3.pull_weights()
+    for k in straight:
+        assert torch.equal(m3._sd[k], straight[k]), k
+    applied, skipped, _ = m3.train_stats()
+    assert applied and skipped == 0 and int(m3.opt_state_dict()["step"][0]) == 3
+
+
+def test_fp16_saturation_skips_the_step_and_loss_scaler_backs_off():
+    """every fp16 gradient store saturates to +-65504, so an overflow at a too-large loss scale never makes the gradient norm
+    non-finite — the saturation bit of the handle's error word is what skips the step.  A loss scale of 2^40 saturates the activation
+    gradients: the step is skipped on the device (weights, moments, Adam step count untouched), the bit is consumed (check() is clean),
+    and LossScaler halves the scale until steps apply again."""
+    from gtav_amd.train import LossScaler, training_step
+    m, sd, cfg, x, t, a, vt = _setup(B=2, T=5)
+    lat, a5, tgt, ctx, cn, nz = _step_inputs()
+    m.loss_scale = 2.0 ** 40
+    training_step(m, lat, a5, tgt, ctx, cn, nz, lr=1e-3)
+    applied, skipped, gnorm = m.train_stats()
+    assert not applied and skipped == 1 and math.isfinite(gnorm)
+    assert int(m.opt_state_dict()["step"][0]) == 0                      # the Adam step count did not advance
+    m.pull_weights()
+    assert torch.equal(m._sd["blocks.0.s_mlp.fc1.weight"], sd["blocks.0.s_mlp.fc1.weight"])
+    m.check()                                                           # the overflow bit was consumed by the step
+    sc = LossScaler(m, check_every=1, growth_interval=1 << 30)
+    for _ in range(40):
+        training_step(m, lat, a5, tgt, ctx, cn, nz, lr=1e-3)
+        sc.update()
+        if m.train_stats()[0]:
+            break
+    assert m.train_stats()[0] and m.loss_scale < 2.0 ** 40
+    assert int(m.opt_state_dict()["step"][0]) >= 1
+
+
+def test_frame_loop_three_target_frames_vs_reference_fixture_g10():
+    """train.forward_loss on 7-frame clips (three target frames, 5-frame windows sliding; train_dit.py:590-682) against fixture G10 (the
+    reference's statements on the reference DiT module): every target frame's v_pred / v_target, the per-frame losses through on_frame,
+    the returned mean loss; and training_step differentiates every frame's loss (gradients add up over the frame loop)."""
+    import os
+    from safetensors.torch import load_file
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT
+    from gtav_amd.train import forward_loss, training_step
+    g = load_file(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_frame_loop.safetensors"))
+    sd = W.synth_state_dict(W.dit_param_shapes(**KW), seed=17)
+    m = DiT(**KW, max_batch=2, max_frames=5, init_weights=False, trainable=True)
+    m.load_state_dict(sd)
+    seen = {}
+
+    def on_frame(k, v_pred, v_target):
+        seen[k] = (v_pred.clone(), v_target.clone())
+    cns, nzs = [g[f"ctx_noise{k}"] for k in range(3)], [g[f"noise{k}"] for k in range(3)]
+    loss, vp, vt = forward_loss(m, g["latents"], g["actions"], g["target_idx"], g["ctx_idx"], cns, nzs, on_frame=on_frame)
+    assert sorted(seen) == [0, 1, 2]
+    for k in range(3):
+        assert rel_l2(seen[k][1], g[f"v_target{k}"]) < 1e-6
+        assert rel_l2(seen[k][0], g[f"v_pred{k}"]) < 2e-3
+    assert abs(float(loss) - float(g["mean_loss"])) / float(g["mean_loss"]) < 2e-3
+    # gradients of the three frames add up: one training_step == three backward passes accumulated
+    m.zero_grad()
+    for k in range(3):
+        _, v, t_ = forward_loss(m, g["latents"][:, : 5 + k], g["actions"][:, : 5 + k], g["target_idx"][k], g["ctx_idx"][k], cns[k], nzs[k],
+                                n_prompt_frames=4 + k, keep_activations=True)
+        m.backward_(v, t_)
+    acc = m.grad_arena.clone()
+    training_step(m, g["latents"], g["actions"], g["target_idx"], g["ctx_idx"], cns, nzs, lr=0.0, max_grad_norm=0.0)
+    assert rel_l2(m.grad_arena, acc) < 1e-5
+
+
+def test_trainable_model_refuses_to_grow_before_destroying_its_state():
+    """a trainable DiT that would have to grow its workspace (predict on the training model with more conditioning rows than
+    reserved) must raise BEFORE the handle — the only home of the fp32 masters and the AdamW state — is destroyed, and stay usable."""
+    from gtav_amd.train import training_step
+    m, sd, cfg, x, t, a, vt = _setup(B=2, T=5)
+    lat, a5, tgt, ctx, cn, nz = _step_inputs()
+    training_step(m, lat, a5, tgt, ctx, cn, nz, lr=1e-4)
+    with pytest.raises(RuntimeError, match="cannot grow"):
+        m.reserve(4, 5, noise_steps=50)
+    with pytest.raises(RuntimeError, match="cannot grow"):
+        m(torch.randn(3, 5, 16, 8, 16), torch.zeros(3, 5, dtype=torch.long), None)
+    training_step(m, lat, a5, tgt, ctx, cn, nz, lr=1e-4)                # same handle, state intact
+    assert int(m.opt_state_dict()["step"][0]) == 2
+
+
+def test_comm_from_torch_distributed_and_bucket_order_single_rank():
+    """Multi-GPU readiness on the one-GPU box: the buckets of backward_overlapped are issued in the order their
+    gradients become final (final layer, blocks depth-1 .. 0, embedders), every one exactly once, through gtav_amd.comm.Comm's all-reduce
+    on a one-rank RCCL communicator; the arena afterwards equals the plain backward's."""
+    from gtav_amd.comm import Comm
+    from gtav_amd.train import backward_overlapped, gradient_buckets
+    m, sd, cfg, x, t, a, vt = _setup()
+    v = m.forward_train(x, t, a)
+    m.zero_grad()
+    m.backward_(v, vt)
+    whole = m.grad_arena.clone()
+    comm = Comm(1, 0, Comm.unique_id())
+    calls = []
+
+    def ar(tensor):
+        calls.append((tensor.data_ptr() - m.grad_arena.data_ptr()) // 4)
+        comm.all_reduce_(tensor)
+    m.zero_grad()
+    backward_overlapped(m, v, vt, world_size=2, all_reduce=ar)           # world_size 2 arithmetic on one rank: the arena holds the "sum"
+    torch.cuda.synchronize()
+    want = [off for _, off, _ in gradient_buckets(m)]
+    assert calls == want and len(set(calls)) == len(calls)
+    assert m.grad_divisor == 2.0 and rel_l2(m.grad_arena, whole) < 1e-6
+    m.grad_divisor = 1.0
+    comm.close()

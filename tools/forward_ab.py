@@ -45,7 +45,7 @@ def main():
             if a.fold_ab:
                 if v == 3: dit.set_fold(1, 0, 1 << 30)
                 elif v == 4: dit.set_fold(1, 1 << 30, 0)
-                else: dit.set_fold(v, 1024, 1024)
+                else: dit.set_fold(v, 1024, 1024)   # (variant 1 = mode 1 with 1024-token thresholds)
             elif a.fused_ab:
                 dit.set_fused_temporal(bool(v & 1))
                 lib.gtav_op_gemm_set_debug(v & ~1)    # e.g. 513 = fused + debug bit 9 (no K/V cache rows: timing only)

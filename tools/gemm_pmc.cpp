@@ -1,7 +1,9 @@
-// Torch-free driver for rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE) on the dominant kernel: runs the fc1-shaped
-// GEMM (N = 4096, K = 1024, GELU epilogue) through the C-ABI at M = 720 and M = 5760 with rotating weight buffers.
+// Torch-free driver for rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on the four GEMM classes of a DiT half-block, through the
+// C-ABI exactly as the model launches them: to_qkv (spatial layout + RoPE epilogue), out-proj and fc2 (split-K slabs, the model's K-slice
+// heuristic), fc1 (GELU epilogue); M = 720 (batch-1 window step) and M = 5760 (batch 8); rotating weight buffers.  Dispatch order is fixed —
+// for M in {720, 5760}: qkv, out, fc1, fc2, `iters` launches each — and tools/gemm_traffic.py segments the counter rows by that order.
 //   hipcc -O2 tools/gemm_pmc.cpp -Iinclude -L ai-generated-gtav_amd -lgtav_amd -Wl,-rpath,'$ORIGIN/../ai-generated-gtav_amd' -o tools/gemm_pmc
-//   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- ./tools/gemm_pmc
+//   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- ./tools/gemm_pmc 16
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -9,37 +11,46 @@
 #include "gtav_amd.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+#define GK(x) do { if (x) { fprintf(stderr, "%s failed: %s\n", #x, gtav_last_error()); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    const int N = 4096, K = 1024, copies = 8, iters = argc > 1 ? atoi(argv[1]) : 16;
+    const int D = 1024, H = 4096, copies = 8, iters = argc > 1 ? atoi(argv[1]) : 16;
     const int Ms[2] = {720, 5760};
-    std::vector<void*> w(copies);
-    std::vector<unsigned short> host((size_t)N * K);
+    std::vector<unsigned short> host((size_t)H * D);
     for (size_t i = 0; i < host.size(); ++i) host[i] = 0x2000 + (unsigned short)((i * 2654435761u) >> 20 & 0x3ff);  // small fp16 values
+    std::vector<void*> w(copies);
     for (int c = 0; c < copies; ++c) {
-        CK(hipMalloc(&w[c], (size_t)N * K * 2));
-        CK(hipMemcpy(w[c], host.data(), (size_t)N * K * 2, hipMemcpyHostToDevice));
+        CK(hipMalloc(&w[c], (size_t)H * D * 2));
+        CK(hipMemcpy(w[c], host.data(), (size_t)H * D * 2, hipMemcpyHostToDevice));
     }
-    float* bias;
-    CK(hipMalloc((void**)&bias, N * 4));
-    CK(hipMemset(bias, 0, N * 4));
+    float *bias, *cs;
+    CK(hipMalloc((void**)&bias, H * 4));
+    CK(hipMemset(bias, 0, H * 4));
+    CK(hipMalloc((void**)&cs, 144 * 64 * 4));
+    {
+        std::vector<float> one(144 * 64);
+        for (size_t i = 0; i < one.size(); ++i) one[i] = (i & 1) ? 0.f : 1.f;     // (cos, sin) = (1, 0): identity rotation
+        CK(hipMemcpy(cs, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+    }
     for (int mi = 0; mi < 2; ++mi) {
         const int M = Ms[mi], Mp = (M + 127) / 128 * 128;
-        void *x, *out;
-        CK(hipMalloc(&x, (size_t)Mp * K * 2));
-        CK(hipMemcpy(x, host.data(), (size_t)Mp * K * 2 < host.size() * 2 ? (size_t)Mp * K * 2 : host.size() * 2, hipMemcpyHostToDevice));
-        CK(hipMalloc(&out, (size_t)Mp * N * 2));
-        for (int it = 0; it < iters; ++it) {
-            if (gtav_op_gemm_f16(x, K, w[it % copies], bias, out, N, M, N, K, 2, nullptr, 0, 1, nullptr)) {
-                fprintf(stderr, "gemm failed: %s\n", gtav_last_error());
-                return 1;
-            }
-        }
+        void *x, *xh, *q, *k, *v, *hb, *parts;
+        CK(hipMalloc(&x, (size_t)Mp * D * 2));
+        CK(hipMalloc(&xh, (size_t)Mp * H * 2));
+        CK(hipMemcpy(x, host.data(), (size_t)Mp * D * 2 < host.size() * 2 ? (size_t)Mp * D * 2 : host.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(xh, 0, (size_t)Mp * H * 2));
+        CK(hipMalloc(&q, (size_t)Mp * D * 2)); CK(hipMalloc(&k, (size_t)Mp * D * 2)); CK(hipMalloc(&v, (size_t)Mp * D * 2));
+        CK(hipMalloc(&hb, (size_t)Mp * H * 2));
+        CK(hipMalloc(&parts, (size_t)8 * Mp * D * 4));
+        const int sk_out = gtav_op_gemm_choose_splitk(M, D, D), sk_fc2 = gtav_op_gemm_choose_splitk(M, D, H);
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_qkv(x, D, w[it % copies], nullptr, M, D, 0, q, k, v, 144, 0, 0, 0, cs, nullptr));
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(x, D, w[it % copies], nullptr, parts, D, M, D, D, 6, nullptr, sk_out, 1, nullptr));
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(x, D, w[it % copies], bias, hb, H, M, H, D, 2, nullptr, 0, 1, nullptr));
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(xh, H, w[it % copies], nullptr, parts, D, M, D, H, 6, nullptr, sk_fc2, 1, nullptr));
         CK(hipDeviceSynchronize());
-        printf("M=%d: %d launches of fc1 GEMM (N=%d K=%d), algorithmic bytes per launch: W %zu + X %zu + out %zu\n", M, iters, N, K,
-               (size_t)N * K * 2, (size_t)M * K * 2, (size_t)M * N * 2);
-        CK(hipFree(x));
-        CK(hipFree(out));
+        printf("M=%d: %d launches each of qkv (N=3072 K=1024), out (N=1024 K=1024, %d K slices), fc1 (N=4096 K=1024), fc2 (N=1024 K=4096, %d K slices)\n", M, iters,
+               sk_out, sk_fc2);
+        CK(hipFree(x)); CK(hipFree(xh)); CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(v)); CK(hipFree(hb)); CK(hipFree(parts));
     }
     return 0;
 }

@@ -1,4 +1,5 @@
-"""Second half of tools/gemm_traffic.sh: rocprofv3 counter_collection csv files -> profiles/traffic.json."""
+"""Second half of tools/gemm_traffic.sh: rocprofv3 counter_collection csv files -> profiles/traffic.json.
+tools/gemm_pmc dispatches, for M in (720, 5760): qkv, out, fc1, fc2 — ITERS launches each; the rows are segmented by dispatch order."""
 import csv
 import glob
 import hashlib
@@ -7,40 +8,62 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N, K = 4096, 1024
+ITERS = 16
+CLASSES = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
+MS = (720, 5760)
 
 
-def per_launch(outdir, counter):
-    """mean counter value (KB) per GEMM dispatch, keyed by grid size (the two M values launch different grids)"""
-    files = glob.glob(os.path.join(outdir, counter, "**", "*counter_collection.csv"), recursive=True)
-    assert files, f"no counter_collection.csv under {outdir}/{counter}"
-    acc = {}
+def rows_by_dispatch(outdir, sub, counters):
+    """{counter: [(dispatch id, kernel, grid, value)] sorted by dispatch id} of the GEMM dispatches"""
+    files = glob.glob(os.path.join(outdir, sub, "**", "*counter_collection.csv"), recursive=True)
+    assert files, f"no counter_collection.csv under {outdir}/{sub}"
+    out = {c: {} for c in counters}
     for f in files:
         for row in csv.DictReader(open(f)):
-            if "gemm" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
+            if "gemm" not in row["Kernel_Name"] or row["Counter_Name"] not in out:
                 continue
-            key = (int(row["Grid_Size"]), row["Kernel_Name"])
-            a = acc.setdefault(key, [0.0, 0])
-            a[0] += float(row["Counter_Value"])
-            a[1] += 1
-    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+            d = out[row["Counter_Name"]].setdefault(int(row["Dispatch_Id"]), [row["Kernel_Name"], int(row["Grid_Size"]), 0.0])
+            d[2] += float(row["Counter_Value"])          # (a counter may be reported per XCD / SE: sum the rows of one dispatch)
+    return {c: [(k,) + tuple(v) for k, v in sorted(d.items())] for c, d in out.items()}
+
+
+def segments(rows):
+    assert len(rows) == ITERS * len(CLASSES) * len(MS), f"expected {ITERS * len(CLASSES) * len(MS)} GEMM dispatches, found {len(rows)}"
+    seg = {}
+    i = 0
+    for M in MS:
+        for name, N, K in CLASSES:
+            chunk = rows[i: i + ITERS]
+            i += ITERS
+            assert len({r[1] for r in chunk}) == 1, f"{name} M={M}: mixed kernels in one segment"
+            seg[(name, M)] = (sum(r[3] for r in chunk) / ITERS, chunk[0][1], chunk[0][2])
+    return seg
 
 
 def main():
     outdir = sys.argv[1]
-    fetch, write = per_launch(outdir, "FETCH_SIZE"), per_launch(outdir, "WRITE_SIZE")
+    fetch = segments(rows_by_dispatch(outdir, "FETCH_SIZE", ["FETCH_SIZE"])["FETCH_SIZE"])
+    write = segments(rows_by_dispatch(outdir, "WRITE_SIZE", ["WRITE_SIZE"])["WRITE_SIZE"])
+    mf = rows_by_dispatch(outdir, "MFMA", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])
+    mfma, sqb, gui = (segments(mf[c]) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
     sha = hashlib.sha256(open(os.path.join(ROOT, "ai-generated-gtav_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16]
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) on tools/gemm_pmc via tools/gemm_traffic.sh; "
-                     "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 tallies 128-B read requests as 64 B, MI355X_MICROARCH.md HBM section)",
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes, kernel trace "
+                     "only) on tools/gemm_pmc via tools/gemm_traffic.sh; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 tallies 128-B read requests as 64 B, "
+                     "MI355X_MICROARCH.md HBM section); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of the "
+                     "launch's shader-clock cycles in which a SIMD's matrix pipe was busy",
            "gemm_hip_sha16": sha}
-    keys = sorted(fetch.keys())          # smaller grid = M 720, larger = M 5760
-    assert len(keys) == 2, f"expected the two fc1 launches, found {keys}"
-    for (key, M) in zip(keys, (720, 5760)):
-        f_kb, nf = fetch[key]
-        w_kb, nw = write[key]
-        res["fc1_M%d" % M] = {"hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "fetch_size_kb": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
-                               "launches": min(nf, nw), "kernel": key[1], "grid_threads": key[0],
-                               "algorithmic_bytes": N * K * 2 + M * K * 2 + M * N * 2}
+    for M in MS:
+        for name, N, K in CLASSES:
+            f_kb, kern, grid = fetch[(name, M)]
+            w_kb = write[(name, M)][0]
+            cyc = gui[(name, M)][0] / 8.0
+            splitk = 1
+            out_bytes = M * N * (2 if name in ("qkv", "fc1") else 4)
+            res[f"{name}_M{M}"] = {"hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "fetch_size_kb": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
+                                   "launches": ITERS, "kernel": kern, "grid_threads": grid,
+                                   "algorithmic_bytes": N * K * 2 + M * K * 2 + out_bytes,
+                                   "mfma_busy_cycles": round(mfma[(name, M)][0]), "sq_busy_cycles": round(sqb[(name, M)][0]),
+                                   "shader_cycles": round(cyc), "mfma_busy": round(mfma[(name, M)][0] / (1024.0 * cyc), 4) if cyc > 0 else None}
     json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 
