@@ -321,7 +321,8 @@ struct gtav_dit {
         std::vector<Slot*> params;          // trainable slots in a fixed (sorted-by-name) order
         float* grad_arena = nullptr;        // all gradients, contiguous (one all-reduce); caller-owned when passed to train_enable
         size_t grad_count = 0;
-        float* ctl = nullptr;               // [8]: sumsq, step coefficient, skipped steps, grad norm
+        float* ctl = nullptr;               // [8]: sumsq, step coefficient, skipped steps, grad norm, applied steps, bias corrections
+        float *red_ws = nullptr, *sumsq_part = nullptr;   // partial sums of the fixed-order reductions (bias gradients, gradient norm)
         AdamParam* adam_params = nullptr;   // device tables of the multi-tensor AdamW launch
         AdamItem* adam_items = nullptr;
         int adam_n_items = 0;
@@ -988,6 +989,8 @@ int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena
         }
     }
     RET_IF(a.alloc_t(&t.ctl, 8));
+    RET_IF(a.alloc_t(&t.red_ws, colsum_workspace(h->Mmax > h->max_rows ? h->Mmax : h->max_rows, h->Hm_pad > 6 * D ? h->Hm_pad : 6 * D)));
+    RET_IF(a.alloc_t(&t.sumsq_part, (size_t)sumsq_parts(count)));
     {
         std::vector<AdamParam> ap;
         std::vector<AdamItem> ai;
@@ -1208,7 +1211,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     // gradient of one adaLN projection (rows [row0, row0 + n) of W_ada / b_ada) from the dmod columns its LayerNorm / gate backward filled
     auto ada_grads = [&](size_t row0, int n, const std::string& wn, const std::string& bn) -> int {
         RET_IF(launch_gemm_tn_f32(dmod + row0, MODW, h->Sc, D, rows, n, D, slot(wn).grad, D, s));
-        return launch_colsum_f32(dmod + row0, MODW, rows, n, slot(bn).grad, s);
+        return launch_colsum_f32(dmod + row0, MODW, rows, n, slot(bn).grad, tr.red_ws, s);
     };
     // ---- phase 0: loss -> final projection -> final LayerNorm ----
     if (phase_begin <= 0 && 0 < phase_end) {
@@ -1217,7 +1220,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         Slot& wf = slot("final_layer.linear.weight");
         // db: column sums over the 64-wide (zero-padded) dfo, only the first Nfin belong to the bias: sum into a scratch row first
         GTAV_CHECK_HIP(hipMemsetAsync(tr.dSc, 0, 64 * sizeof(float), s));
-        RET_IF(launch_colsum_tiled_f16(tr.dfo, M, 64, tr.dSc, s));
+        RET_IF(launch_colsum_tiled_f16(tr.dfo, M, 64, tr.dSc, tr.red_ws, s));
         RET_IF(launch_add_f32(slot("final_layer.linear.bias").grad, tr.dSc, slot("final_layer.linear.bias").grad, h->Nfin, s));
         // dW_final [Nfin][D] += dfo^T xnF   (M = Nfin rows of the 64-row transposed operand)
         RET_IF(launch_transpose_tiled_f16(tr.dfo, M, 64, tr.tA, s));
@@ -1249,11 +1252,11 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         // r_{2i+2} = r_{2i+1} + gate_mlp y2
         RET_IF(launch_gate_bwd(tr.dres, mb + 5 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
         RET_IF(launch_frame_reduce_gate(tr.dres, b.y2, NB, P, D, dmb + 5 * D, MODW, s));
-        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "mlp.fc2.bias").grad, s));
+        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "mlp.fc2.bias").grad, tr.red_ws, s));
         RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "mlp.fc2.weight").wT, Hp, D, EPI_F16_TILED, tr.g_h, Hp));
         RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
-        RET_IF(launch_colsum_tiled_f16(tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, s));
+        RET_IF(launch_colsum_tiled_f16(tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, tr.red_ws, s));
         RET_IF(gemm_dw(tr.g_u, Hp, b.xnB, D, slot(P_ + "mlp.fc1.weight").grad));
         RET_IF(gemm_dx(tr.g_u, slot(P_ + "mlp.fc1.weight").wT, D, Hp, EPI_F32, tr.dtmp, D));
         RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i + 1], mb + 4 * D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
@@ -1261,7 +1264,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         // r_{2i+1} = r_{2i} + gate_msa y1
         RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
         RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
-        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "attn.to_out.bias").grad, s));
+        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, s));
         RET_IF(gemm_dw(tr.g_d, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "attn.to_out.weight").wT, D, D, EPI_F16, tr.dao, D));
         if (hf == 0) RET_IF(launch_attn_spatial_bwd(b.q, b.k, b.v, tr.dao, NB, h->heads, P, D, h->rope_s.cs_dev, tr.g_qkv, h->err_flag, s));
@@ -1275,7 +1278,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     }
     if (!(phase_begin <= L + 1 && L + 1 < phase_end)) return 0;
     // ---- phase L + 1: patch embedding: r_0 = xp W_pe^T + b_pe ----
-    RET_IF(launch_colsum_f32(tr.dres, D, M, D, slot("x_embedder.proj.bias").grad, s));
+    RET_IF(launch_colsum_f32(tr.dres, D, M, D, slot("x_embedder.proj.bias").grad, tr.red_ws, s));
     RET_IF(launch_to_tiled_f16(tr.dres, M, D, tr.g_d, h->err_flag, s));
     {
         Slot& wpe = slot("x_embedder.proj.weight");
@@ -1286,15 +1289,15 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     // projection (their own gradients were taken block by block above) ----
     RET_IF(launch_ada_bwd_dx(dmod, MODW, h->w_ada, D, rows, tr.dSc, tr.ada_part, s));
     RET_IF(launch_silu_bwd(tr.dSc, D, tr.cpre, D, tr.dc, D, rows, D, s));
-    RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("t_embedder.mlp.2.bias").grad, s));
+    RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("t_embedder.mlp.2.bias").grad, tr.red_ws, s));
     RET_IF(launch_gemm_tn_f32(tr.dc, D, h->HC, ldhc, rows, D, D, slot("t_embedder.mlp.2.weight").grad, D, s));
     if (tr.have_actions) {
-        RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("external_cond.bias").grad, s));
+        RET_IF(launch_colsum_f32(tr.dc, D, rows, D, slot("external_cond.bias").grad, tr.red_ws, s));
         RET_IF(launch_gemm_tn_f32(tr.dc, D, h->HC + D, ldhc, rows, D, h->A, slot("external_cond.weight").grad, h->A, s));
     }
     RET_IF(launch_gemm_nn_f32(tr.dc, D, h->w_t2cat, ldhc, rows, D, D, tr.dh0, D, s));
     RET_IF(launch_silu_bwd(tr.dh0, D, tr.z0, D, tr.dz0, D, rows, D, s));
-    RET_IF(launch_colsum_f32(tr.dz0, D, rows, D, slot("t_embedder.mlp.0.bias").grad, s));
+    RET_IF(launch_colsum_f32(tr.dz0, D, rows, D, slot("t_embedder.mlp.0.bias").grad, tr.red_ws, s));
     RET_IF(launch_gemm_tn_f32(tr.dz0, D, h->E, 256, rows, D, 256, slot("t_embedder.mlp.0.weight").grad, 256, s));
     return 0;
 }
@@ -1331,11 +1334,10 @@ int gtav_dit_adamw_step(gtav_dit* h, float lr, float beta1, float beta2, float e
     GTAV_REQUIRE(h && h->tr.on, "adamw_step: training is not enabled");
     hipStream_t s = (hipStream_t)stream;
     gtav_dit::Train& tr = h->tr;
-    GTAV_CHECK_HIP(hipMemsetAsync(tr.ctl, 0, 2 * sizeof(float), s));
-    RET_IF(launch_sumsq(tr.grad_arena, tr.grad_count, tr.ctl, s));
+    RET_IF(launch_sumsq(tr.grad_arena, tr.grad_count, tr.sumsq_part, s));
     // overflow (non-finite norm, or a saturated fp16 gradient / activation recorded in the error word) skips the step on the device; the
     // Adam step count and its bias corrections live in ctl[4..6] and advance only with applied steps
-    RET_IF(launch_clip_coef(tr.ctl, 1.0f / (tr.loss_scale * tr.grad_div), max_grad_norm, beta1, beta2, h->err_flag, s));
+    RET_IF(launch_clip_coef(tr.ctl, tr.sumsq_part, sumsq_parts(tr.grad_count), 1.0f / (tr.loss_scale * tr.grad_div), max_grad_norm, beta1, beta2, h->err_flag, s));
     // one launch: AdamW on every parameter + the fp16 W / W^T operands of the GEMM weights rewritten from the updated masters
     RET_IF(launch_adamw_multi(tr.adam_params, tr.adam_items, tr.adam_n_items, tr.ctl, lr, beta1, beta2, eps, weight_decay, s));
     RET_IF(launch_add_f32(h->b_t2, h->b_ext, h->b_t2a, h->D, s));   // fused bias of c when actions are given (gtav_dit_finalize)

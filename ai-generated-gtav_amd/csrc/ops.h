@@ -153,8 +153,10 @@ int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats,
                            hipStream_t stream);
 int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int rows_per_mod, int M, int D, f16* dy_tiled, int* err_flag, hipStream_t stream);
 int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream);
-int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, hipStream_t stream);     // db[n] += sum_m dy[m][n]
-int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, hipStream_t stream);   // db[n] += sum_m a[m][n]
+// column sums in a fixed order (no float atomics): ws = colsum_workspace(M, N) floats of scratch for the per-row-split partial sums
+size_t colsum_workspace(int M, int N);
+int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, float* ws, hipStream_t stream);     // db[n] += sum_m dy[m][n]
+int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, float* ws, hipStream_t stream);   // db[n] += sum_m a[m][n]
 int launch_to_tiled_f16(const float* a, int M, int D, f16* out, int* err_flag, hipStream_t stream);
 int launch_mse_bwd_patch(const float* vpred, const float* vtarget, int B, int T, int C, int H, int W, int p, float scale, f16* dfo, int ldf, int* err_flag,
                          hipStream_t stream);
@@ -182,9 +184,11 @@ struct AdamItem { int param; unsigned start; };   // GEMM weight: tile index (ro
 // norm, [4] applied steps (the Adam step count), [5] / [6] bias corrections of the step being applied (written by clip_coef on the device)
 int launch_adamw_multi(const AdamParam* params, const AdamItem* items, int n_items, const float* ctl, float lr, float beta1, float beta2, float eps, float wd,
                        hipStream_t stream);
-int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream);
-// err_flag (optional): ERR_F16_SAT / ERR_NONFINITE in the handle's error word count as overflow (step skipped) and are cleared
-int launch_clip_coef(float* ctl, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream);
+int sumsq_parts(size_t n);                                                         // per-block partial sums written by launch_sumsq
+int launch_sumsq(const float* g, size_t n, float* part, hipStream_t stream);
+// adds the partial sums in order (ctl[0]); err_flag (optional): ERR_F16_SAT / ERR_NONFINITE in the handle's error word count as overflow
+// (step skipped) and are cleared
+int launch_clip_coef(float* ctl, const float* part, int nparts, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream);
 int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,
                  float wd, hipStream_t stream);
 

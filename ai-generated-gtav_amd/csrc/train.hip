@@ -190,7 +190,16 @@ __global__ __launch_bounds__(256) void frame_reduce_gate_kernel(const float* __r
 
 // db[n] += sum_m dY[m][n] for a tile-major fp16 dY (logical [M][N], N % 64 == 0).  Block = one 64-column tile column x a slice of rows;
 // thread = (8-column chunk, row lane): one 16-byte load per row.
-__global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block) {
+// Row splits: with `ws` the per-split column sums go to ws[split][N] and colsum_reduce_kernel adds them to db in split order — a fixed
+// summation order (bit-reproducible gradients: the resume test compares weights bit for bit); without it (one split) the block adds directly.
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int splits, int N, float* __restrict__ db) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float t = 0.f;
+    for (int sp = 0; sp < splits; ++sp) t += ws[(size_t)sp * N + n];
+    db[n] += t;
+}
+__global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block, float* __restrict__ ws) {
     __shared__ float part[32][65];
     const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int n0 = blockIdx.x * 64;
@@ -208,16 +217,18 @@ __global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict
     if (threadIdx.x < 64) {
         float t = 0.f;
         for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
-        atomicAdd(db + n0 + threadIdx.x, t);
+        if (ws) ws[(size_t)blockIdx.y * N + n0 + threadIdx.x] = t;
+        else db[n0 + threadIdx.x] += t;      // single split: the only block of this column tile
     }
 }
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ db, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ db, int rows_per_block, float* __restrict__ ws) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int r_begin = blockIdx.y * rows_per_block, r_end = min(M, r_begin + rows_per_block);
     float s = 0.f;
     for (int r = r_begin; r < r_end; ++r) s += a[(size_t)r * lda + n];
-    atomicAdd(db + n, s);
+    if (ws) ws[(size_t)blockIdx.y * N + n] = s;
+    else db[n] += s;
 }
 
 // fp32 row-major [M][D] -> fp16 tile-major (the patch-embedding gradient as a dW operand)
@@ -933,15 +944,24 @@ __global__ void ada_reduce_kernel(const float* __restrict__ part, int nchunk, si
 //   ctl[4] = number of APPLIED steps (the Adam step count t: a skipped step does not advance it), ctl[5] / ctl[6] = the bias
 //   corrections 1 - beta1^t / 1 - beta2^t of the step being applied, computed here on the device so that m / v and t stay in step.
 // ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ ctl) {
+// (per-block partial sums, added up in block order by clip_coef_kernel: no float atomics, the norm — and with it the clip coefficient and every
+// AdamW update — is bit-reproducible from run to run)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     __shared__ float red[16];
     float a = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += g[i] * g[i];
     const float t = block_sum(a, red);
-    if (threadIdx.x == 0) atomicAdd(ctl, t);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
-__global__ void clip_coef_kernel(float* ctl, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag) {
-    const float norm = sqrtf(ctl[0]) * inv_scale;
+__global__ __launch_bounds__(256) void clip_coef_kernel(float* ctl, const float* __restrict__ part, int nparts, float inv_scale, float max_norm, float beta1, float beta2,
+                                                        int* err_flag) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+    const float ssq = block_sum(a, red);
+    if (threadIdx.x != 0) return;
+    ctl[0] = ssq;
+    const float norm = sqrtf(ssq) * inv_scale;
     bool overflow = !(norm == norm) || isinf(norm);
     if (err_flag) {
         const int bits = *err_flag & (ERR_F16_SAT | ERR_NONFINITE);
@@ -1103,16 +1123,21 @@ int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P,
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, hipStream_t stream) {
+size_t colsum_workspace(int M, int N) { return (size_t)cdiv(M, 256) * (size_t)round_up(N, 256); }
+int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, float* ws, hipStream_t stream) {
     GTAV_REQUIRE(N % 64 == 0, "colsum: N=%d must be a multiple of 64", N);
     const int splits = cdiv(M, 512);
-    hipLaunchKernelGGL(colsum_tiled_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dy, M, N, db, cdiv(M, splits));
+    GTAV_REQUIRE(splits == 1 || ws, "colsum: %d row splits need the partial-sum workspace", splits);
+    hipLaunchKernelGGL(colsum_tiled_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dy, M, N, db, cdiv(M, splits), splits > 1 ? ws : nullptr);
+    if (splits > 1) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, ws, splits, N, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, hipStream_t stream) {
+int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, float* ws, hipStream_t stream) {
     const int splits = cdiv(M, 256);
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(N, 256), splits), dim3(256), 0, stream, a, lda, M, N, db, cdiv(M, splits));
+    GTAV_REQUIRE(splits == 1 || ws, "colsum: %d row splits need the partial-sum workspace", splits);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(N, 256), splits), dim3(256), 0, stream, a, lda, M, N, db, cdiv(M, splits), splits > 1 ? ws : nullptr);
+    if (splits > 1) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, ws, splits, N, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1217,13 +1242,14 @@ int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R,
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_sumsq(const float* g, size_t n, float* ctl, hipStream_t stream) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, stream, g, n, ctl);
+int sumsq_parts(size_t n) { return grid_for(n, 256 * 8); }
+int launch_sumsq(const float* g, size_t n, float* part, hipStream_t stream) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(sumsq_parts(n)), dim3(256), 0, stream, g, n, part);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
-int launch_clip_coef(float* ctl, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream) {
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, stream, ctl, inv_scale, max_norm, beta1, beta2, err_flag);
+int launch_clip_coef(float* ctl, const float* part, int nparts, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, stream, ctl, part, nparts, inv_scale, max_norm, beta1, beta2, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
