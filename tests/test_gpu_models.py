@@ -701,3 +701,58 @@ def test_config0_production_size_vs_reference_golden(full_dit, full_vae):
     # 33 chained full-size forwards: per-forward error 6-9e-4 (TOL_FULL), accumulated over the rollout
     assert e_enc < TOL_FULL and e_lat < 5e-3 and e_img < 5e-3 and rel_l2(lat_c, lat) < 1e-4
     assert diff.max().item() <= 2 and int((diff > 0).sum()) < 0.3 * diff.numel()
+
+
+def test_full_size_checkpoint_in_the_reference_writers_convention(tmp_path, full_dit):
+    """a FULL-SIZE checkpoint file as the reference's own writer leaves it — `accelerator.save(unwrap(dit).state_dict(),
+    path, safe_serialization=True)` (train_dit.py:758-762) de-duplicates the 34 shared rotary `freqs` aliases down to `spatial_rotary_emb.freqs`
+    / `temporal_rotary_emb.freqs` — loaded through load_state_dict_file -> load_state_dict -> the C-ABI on the GPU, gives the
+    same forward as the in-memory weights; and train.save_model writes that same convention back (key set and values equal)."""
+    from safetensors.torch import save_file
+    from gtav_amd.train import save_model
+    from gtav_amd.weights import load_state_dict_file
+    m, sd, cfg = full_dit
+    x, t, a = _inputs(cfg, 1, 3, seed=23)
+    want = m(x, t, a).clone()
+    path = str(tmp_path / "dit_epoch_1_920000.safetensors")
+    on_disk = {k: v.contiguous() for k, v in sd.items()}
+    on_disk["spatial_rotary_emb.freqs"] = W.rope_freqs_pixel(32, 256)
+    on_disk["temporal_rotary_emb.freqs"] = W.rope_freqs_lang(64)
+    save_file(on_disk, path)                                           # 2.4 GB of fp32, 324 entries
+    m2 = DiT_models["DiT-S/2"](init_weights=False, max_batch=1)
+    missing, unexpected = m2.load_state_dict(load_state_dict_file(path))
+    assert not missing and not unexpected
+    assert torch.equal(m2(x, t, a), want)
+    out = str(tmp_path / "resaved.safetensors")
+    save_model(m2, out)
+    back = load_state_dict_file(out)
+    assert set(back) == set(on_disk)
+    for k in ("blocks.7.t_attn.to_qkv.weight", "final_layer.adaLN_modulation.1.bias", "spatial_rotary_emb.freqs", "temporal_rotary_emb.freqs"):
+        assert torch.equal(back[k], on_disk[k]), k
+
+
+def test_visualize_step_debug_grid(tmp_path):
+    """utils.visualize_step (reference utils.py:104-211): same signature; the three image rows are the VAE decode of the original / noisy /
+    denoised latents clamped to [0, 1] (against the oracle decode), x_start = (x_noisy - sqrt(1 - a) v) / sqrt(a) when no `pred` is given, and a
+    PNG lands where the reference puts it."""
+    from gtav_amd.utils import alphas_cumprod, visualize_step
+    vsd = W.synth_state_dict(W.vae_param_shapes(**SMALL_VAE), seed=5)
+    v = AutoencoderKL(**SMALL_VAE, init_weights=False)
+    v.load_state_dict(vsd)
+    vcfg = O.VAEConfig(**SMALL_VAE)
+    g = torch.Generator().manual_seed(4)
+    h, w = 64 // 8, 96 // 8
+    x = torch.randn(1, 3, 16, h, w, generator=g) * 0.05
+    nz = torch.randn(1, 3, 16, h, w, generator=g)
+    ac = alphas_cumprod(1e-6)
+    step = 400
+    xn = ac[step].sqrt() * x + (1 - ac[step]).sqrt() * nz
+    vp = torch.randn(1, 3, 16, h, w, generator=g) * 0.1
+    path, imgs = visualize_step(x, xn, nz, vp, step, v, ac, name="grid.png", out_dir=str(tmp_path))
+    assert os.path.getsize(path) > 10_000
+    with torch.no_grad():
+        ref = lambda lat: ((O.vae_decode(vsd, vcfg, (lat / 0.07843137255).reshape(3, 16, h * w).permute(0, 2, 1)) + 1) / 2).clamp(0, 1)
+        assert rel_l2(imgs["orig"][0], ref(x[0])) < TOL_SMALL and rel_l2(imgs["noisy"][0], ref(xn[0])) < TOL_SMALL
+        xs = (xn - (1 - ac[step]).sqrt() * vp) / ac[step].sqrt()
+        assert rel_l2(imgs["denoised"][0], ref(xs[0])) < TOL_SMALL
+    assert float(imgs["orig"].min()) >= 0.0 and float(imgs["orig"].max()) <= 1.0
