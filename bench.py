@@ -451,16 +451,13 @@ def bench_generate(args, world, rank, dev, dist, torch):
             other = world - 1
             _, fr_o, nz_o = _si(world * B, other, world, n_prompt, ct, (FH, FW), (LH, LW), seed=4242)
             xo, _ = generate_clip(dit, vae, fr_o.to(dev), nz_o.to(dev), ct, cs, None, ctx_cache=False, gather=False)
-            same = bool(torch.equal(xg[other * B:(other + 1) * B], xo)) and bool(torch.equal(xg[:B], xg[:B]))
+            same = bool(torch.equal(xg[other * B:(other + 1) * B], xo))
             shard_check = {"passed": same, "what": "latents of rank %d's shard (global samples %d..%d) as all-gathered == recomputed on rank 0, bit for bit; "
                                                    "%d-frame clip, %d noise steps" % (other, other * B, (other + 1) * B - 1, ct, cs),
                            "per_sample_abs_sum": [round(float(v), 6) for v in xg.abs().sum(dim=(1, 2, 3, 4)).cpu()]}
             if not same:
                 sys.stderr.write("bench.py: SHARD SELF-CHECK FAILED: the gathered latents of rank %d differ from rank 0's recomputation\n" % other)
-        elif xg is not None and world > 1:
-            pass   # (the other ranks only take part in the gather)
-        if world > 1:
-            dist.barrier()
+        dist.barrier()       # (the other ranks only took part in the gather)
 
     # ---- bounded training leg (N = 1): the optimisation step of SURVEY.md 8(f)1 on latents already in HBM (the VAE encode of the trainer
     # is measured by --mode train / train_step) ----
