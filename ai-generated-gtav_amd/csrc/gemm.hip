@@ -1958,6 +1958,179 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
     bs.end(p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent loader-wave GEMM for large M (shape 30, round 3).
+//
+// What the round-3 measurements say about the large-M launches: the 512 resident blocks of a launch are in the same phase, so
+// the prologue (first tiles from HBM: 2.2 us) and the epilogue (24 MB of stores in one burst: 5.7 us) of every tile are exposed — 31 % of a residency
+// round — and nothing of it can hide under the NEXT tile of the same block while the waves that store are the waves that wait for fills: vmcnt retires in
+// issue order, so a wave with stores in flight cannot see its younger fills land.  Here the roles are split for good:
+//   * 4 loader waves own every LDS-DMA fill and run AHEAD across tile boundaries (the ring never drains: a tile's first K-steps are already in flight
+//     while the compute waves finish the previous tile);
+//   * 8 compute waves (64 x 48 each, 128 features x 192 tokens per block) never wait on vmcnt: MFMAs from LDS fragments, then the epilogue of the tile
+//     STRAIGHT FROM REGISTERS (pairs of lanes exchange halves for 16-byte stores; no LDS staging, no barrier), whose stores drain under the next tile's K loop;
+//   * one block per CU, persistent over tiles blockIdx + i gridDim of the XCD-aware order; ONE s_barrier per K-step shared by all 12 waves.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lp_tile_of(const GemmParams& p, int v, int tiles_m, int tiles_n, int TNB, int TM, int& n0, int& m0) {
+    const int T = tiles_m * tiles_n;
+    const int xcd = v & 7, qq = T >> 3, rr = T & 7;
+    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (v >> 3);
+    int gn = p.tm.gn;
+    const int group = tiles_m * gn;
+    const int ng = tile_id / group, rem = tile_id - ng * group;
+    const int n_first = ng * gn;
+    if (n_first + gn > tiles_n) gn = tiles_n - n_first;
+    const int tile_m = rem / gn, tile_n = n_first + (rem - tile_m * gn);
+    n0 = tile_n * TNB;
+    m0 = tile_m * TM;
+}
+
+template <int EPI, int NS>
+__global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
+    constexpr int FI = 4, FJ = 3, WN = 2, WM = 4, NL = 4, TNB = 128, TM = 192;
+    constexpr int WPC = 2 * FI * WN, XPC = 2 * FJ * WM, NP = WPC + XPC, G = NP / NL, STAGE_BYTES = NP * 1024;
+    static_assert(NP % NL == 0, "pieces divide over the loader waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wraw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nktot = p.K / TK, nkt = nktot;
+    const int tiles_m = (p.M + TM - 1) / TM, tiles_n = (p.N + TNB - 1) / TNB, T = tiles_m * tiles_n;
+    const int nblk = gridDim.x;
+    const int ntile = (T - (int)blockIdx.x + nblk - 1) / nblk;       // tiles of this block (grid <= T)
+    if (wraw < NL) {
+        // ------------------------------------------------ loader wave ------------------------------------------------
+        const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
+        const unsigned voff = (unsigned)lane * 16u;
+        const unsigned smem0 = lds_offset(smem);
+        const char* sb[G];
+        auto setup = [&](int ti) {
+            int n0, m0;
+            lp_tile_of(p, (int)blockIdx.x + ti * nblk, tiles_m, tiles_n, TNB, TM, n0, m0);
+#pragma unroll
+            for (int i = 0; i < G; ++i) {
+                const int q = wraw * G + i;
+                const bool isw = q < WPC;
+                const int row = isw ? n0 + 8 * q : m0 + 8 * (q - WPC);
+                int rt = row >> 7;
+                const int lim = isw ? last_wt : last_rt;
+                rt = rt < lim ? rt : lim;
+                sb[i] = (const char*)(isw ? p.W : p.X) + (size_t)rt * nktot * TILE_BYTES + ((row & 127) >> 3) * 1024;
+            }
+        };
+        const int S = ntile * nkt;
+        int it = 0, ik = 0, islot = 0;                                // next K-step to issue: tile it, step ik, ring slot islot
+        auto issue = [&]() {
+            if (ik == 0) setup(it);
+            const unsigned so = smem0 + (unsigned)islot * STAGE_BYTES + (unsigned)(wraw * G) * 1024u;
+            const size_t go = (size_t)ik * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < G; ++i) glds16_s(sb[i] + go, voff, so + i * 1024);
+            if (++ik == nkt) { ik = 0; ++it; }
+            if (++islot == NS) islot = 0;
+        };
+        const int npro = S < NS - 1 ? S : NS - 1;
+        for (int g = 0; g < npro; ++g) issue();
+        for (int g = 0; g < S; ++g) {
+            wait_vm_ring<NS, G>(S - 1 - g);                           // this wave's share of step g has landed
+            wg_barrier();
+            if (g + NS - 1 < S) issue();
+        }
+        return;
+    }
+    // ------------------------------------------------ compute wave ------------------------------------------------
+    const int w = wraw - NL, wn = w % WN, wm = w / WN, li = lane & 15, g4 = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+        const int ch = ((4 * sh + g4) ^ (li & 7)) << 4;
+        woff[sh] = (16 * FI * wn + li) * 128 + ch;
+        xoff[sh] = WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
+    }
+    int slot = 0;
+    float amax = 0.f;
+    for (int ti = 0; ti < ntile; ++ti) {
+        int n0, m0;
+        lp_tile_of(p, (int)blockIdx.x + ti * nblk, tiles_m, tiles_n, TNB, TM, n0, m0);
+        f32x4 acc[FI][FJ];
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 pbias[FI];
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4;
+            pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI != EPI_PARTIAL && p.bias && n < p.N) pbias[i] = *(const f32x4*)(p.bias + n);
+        }
+        f16x8 wa[FI], xa[FJ], wb[FI], xb[FJ];
+        auto rdh = [&](const char* b, int sh, f16x8 (&wf)[FI], f16x8 (&xf)[FJ]) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i) wf[i] = *(const f16x8*)(b + woff[sh] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) xf[j] = *(const f16x8*)(b + xoff[sh] + j * 16 * 128);
+        };
+        auto mmh = [&](const f16x8 (&wf)[FI], const f16x8 (&xf)[FJ]) {
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        };
+        for (int t = 0; t < nkt; ++t) {
+            wait_lgkm0();
+            wg_barrier();
+            const char* b = smem + slot * STAGE_BYTES;
+            if (t > 0) {
+                rdh(b, 0, wa, xa);
+                mmh(wb, xb);
+                interleave_mfma_dsread<FI * FJ, FI + FJ>();
+            } else {
+                rdh(b, 0, wa, xa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rdh(b, 1, wb, xb);
+            mmh(wa, xa);
+            interleave_mfma_dsread<FI * FJ, FI + FJ>();
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+        mmh(wb, xb);
+        // ---- epilogue straight from the accumulators (no LDS, no barrier): the stores drain under the next tile's K loop ----
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4;
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int m = m0 + 16 * FJ * wm + 16 * j + li;
+                const bool ok = n < p.N && m < p.M;
+                const f32x4 v = acc[i][j] + pbias[i];
+                if constexpr (EPI == EPI_PARTIAL) {
+                    if (ok) {
+                        float* dst = (float*)p.out + (size_t)m * p.ldo + n;
+                        if (p.out_sc1) store16_sc1(dst, v);
+                        else *(f32x4*)dst = v;
+                    }
+                } else {
+                    const float xin[4] = {v[0], v[1], v[2], v[3]};
+                    float yo[4];
+                    if constexpr (EPI == EPI_GELU_TANH) gelu_tanh_f4(xin, yo);
+                    else { yo[0] = xin[0]; yo[1] = xin[1]; yo[2] = xin[2]; yo[3] = xin[3]; }
+                    const uint2 mine = pack4(amax, yo[0], yo[1], yo[2], yo[3]);
+                    // lanes (li, g) and (li, g ^ 1) hold adjacent 4-feature groups of one token: one 16-byte store per pair
+                    const unsigned o0 = __shfl_xor(mine.x, 16, 64), o1 = __shfl_xor(mine.y, 16, 64);
+                    if (ok && !(lane & 16)) {
+                        f16* dst = (f16*)p.out + tiled_off(m, n, p.ldo);
+                        if (p.out_sc1) store16_sc1(dst, u32x4{mine.x, mine.y, o0, o1});
+                        else *(uint4*)dst = uint4{mine.x, mine.y, o0, o1};
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI != EPI_PARTIAL) sat_report(amax, p.err_flag);
+}
+
 #ifdef GTAV_EXPERIMENTS   // measured slower than shape 12 (profiles/round2/pp_stamps_v1.txt): not in the product library
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent ping-pong GEMM for large M (shape 16): one 1024-thread block per CU, two groups of 8 waves.
@@ -2297,7 +2470,14 @@ static int g_stamp_blocks = 0;
 void gemm_set_stamps(unsigned long long* buf, int max_blocks) { g_stamps = buf; g_stamp_blocks = max_blocks; }
 #endif
 
+// The persistent loader-wave kernel (shape 31) takes the narrow residual GEMMs (N <= 2048: out-proj, fc2) in ONE K slice once its 128 x 192 tiles cover
+// most of the chip (>= 160 tiles): measured against the heuristic's own choice, split-K included (profiles/round3/persistent_loader_kernel_vs_heuristic_*.txt) —
+// M = 4320: out-proj 17.2 -> 13.2 us, fc2 47.1 -> 36.3 us; M = 5760: 17.5 -> 14.3, 51.0 -> 45.1; M = 8640: 27.5 -> 24.0, 78.6 -> 75.0; M = 11 520: 27.9 -> 25.1,
+// 87.6 -> 84.5; at 120 tiles (M = 2880) it loses (12.0 -> 12.8, 31.7 -> 34.0) and the split-K shapes stay.  One slab also halves what the LayerNorm behind fc2 reads.
+static int g_lp_enable = GTAV_ENV_INT("GTAV_LP", 1);   // experiments build: 0 = round-2 selection, for A/B runs
+static bool lp_takes(int M, int N, int K) { return g_lp_enable && N <= 2048 && N % 8 == 0 && K >= 512 && cdiv(M, 192) * cdiv(N, 128) >= 160; }
 int gemm_choose_splitk(int M, int N, int K) {
+    if (lp_takes(M, N, K)) return 1;
 #ifdef GTAV_EXPERIMENTS
     if (g_debug & 256) return 1;   // A/B with GTAV_RESID_INPLACE_MIN_M=1: full-K residual GEMMs on 64 x 48 tiles + in-place epilogue (measured slower, profiles/round2/forward_ab_B1_inplace_fullK.txt)
 #endif
@@ -2451,6 +2631,26 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
     return 0;
 }
 
+// persistent loader-wave kernel (shape 30): one block per CU, dynamic LDS = ring of NS x 40 KiB
+template <int EPI, int NS>
+static int launch_lp(const GemmParams& p, hipStream_t stream) {
+    constexpr int LDS = NS * 40 * 1024;
+    static unsigned long long attr_devs = 0;
+    int dev = 0;
+    const int cus = device_cus(&dev);
+    GTAV_REQUIRE(cus > 0, "gemm: no current device");
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lp_kernel<EPI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_devs |= 1ull << (dev & 63);
+    }
+    GemmParams q = p;
+    const int T = cdiv(p.M, 192) * cdiv(p.N, 128);
+    q.tm.gn = choose_gn(p.M, p.N, p.K, 192, 128, 1);
+    GTAV_LAUNCH((gemm_lp_kernel<EPI, NS>), dim3(T < cus ? T : cus), dim3(768), LDS, stream, q);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int EPI>
 static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hipStream_t stream) {
     GemmParams p = p_in;
@@ -2460,6 +2660,14 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20,
                                         "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
+    if (shape == 30 || shape == 31) {   // persistent loader-wave kernel, 128 x 192 tiles: 30 = 4-stage ring (160 KiB), 31 = 3 stages
+        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
+            GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");
+            return shape == 30 ? launch_lp<EPI, 4>(p, stream) : launch_lp<EPI, 3>(p, stream);
+        } else {
+            GTAV_REQUIRE(false, "gemm: the persistent loader-wave kernel (shape %d) has no epilogue %d", shape, (int)EPI);
+        }
+    }
     if constexpr (!FOLDISH) {
 #ifdef GTAV_EXPERIMENTS
     // measured slower than the shapes the heuristic picks: kept for A/B runs in the experiments build only
@@ -2704,6 +2912,7 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         else if (t13 > 256 && t13 <= 512 && !fold_p) wm = 13, narrow_pick = true;
         else if (fold_p && t12 > 128) wm = 12, narrow_pick = true;
     }
+    if (!g_force_wm && epi_x == EPI_PARTIAL && splitk == 1 && lp_takes(p.M, p.N, p.K)) wm = 31, narrow_pick = true;
     // large M: the persistent ping-pong kernel (epilogue and next tile's prologue under the other wave group's MFMAs)
     if (!g_force_wm && splitk == 1 && gemm_pp_ok(p.M, p.N, p.K, epi) && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL && p.S % 8 != 0)) wm = 16;
     GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");

@@ -435,3 +435,32 @@ def test_gemm_other_tiles_all_epilogues(shape):
             test_gemm_splitk_partials_reduced_by_layernorm(*args)
     finally:
         lib.gtav_op_gemm_set_wm(0)
+
+
+@pytest.mark.parametrize("shape", [30, 31])
+@pytest.mark.parametrize("M,N,K", [(5760, 4096, 1024), (5760, 1024, 4096), (2312, 384, 896), (192, 128, 64), (11520, 1024, 1024), (100, 256, 128)])
+def test_persistent_loader_wave_kernel(shape, M, N, K):
+    """Block shapes 30 / 31 (round 3): the persistent loader-wave kernel — one block per CU walking several 128 x 192 tiles with the LDS ring
+    running on across tile boundaries, epilogue straight from the accumulators — on the GELU (fp16 tile-major) and full-K slab (fp32) epilogues:
+    one tile per block, several tiles per block (960 tiles on 256 CUs), ragged token / feature edges, K of 1, 2, 14, 16 and 64 K-steps; two runs
+    must agree bit for bit (a fill that lands after its first read, or a ring slot refilled too early, shows up as run-to-run differences)."""
+    lib = L.load()
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    w16, xd, bd = pad_weight_f16(w), to_tiled_f16(x), b.to(dev())
+    pre = x.float() @ w.half().float().t()
+    try:
+        lib.gtav_op_gemm_set_wm(shape)
+        outs = []
+        for _ in range(2):
+            out = torch.zeros(((M + 127) // 128 * 128, N), device=dev(), dtype=torch.float16)
+            gemm(xd, w16, bd, M, N, K, 2, out, N)
+            outs.append(out.clone())
+        assert torch.equal(outs[0], outs[1])
+        assert rel_l2(untile(outs[0], M, N).float(), torch.nn.functional.gelu(pre + b, approximate="tanh")) < 6e-4
+        parts = torch.full((M, N), float("nan"), device=dev())
+        L.check(lib.gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), 0, parts.data_ptr(), N, M, N, K, 6, 0, 1, 1, stream()))
+        assert rel_l2(parts, pre) < 2e-5
+    finally:
+        lib.gtav_op_gemm_set_wm(0)
