@@ -1986,9 +1986,10 @@ __device__ __forceinline__ void lp_tile_of(const GemmParams& p, int v, int tiles
     m0 = tile_m * TM;
 }
 
-template <int EPI, int NS>
+template <int EPI, int NS, int FI = 4, int FJ = 3, int WN = 2, int WM = 4>
 __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
-    constexpr int FI = 4, FJ = 3, WN = 2, WM = 4, NL = 4, TNB = 128, TM = 192;
+    static_assert(WN * WM == 8, "8 compute waves");
+    constexpr int NL = 4, TNB = 16 * FI * WN, TM = 16 * FJ * WM;
     constexpr int WPC = 2 * FI * WN, XPC = 2 * FJ * WM, NP = WPC + XPC, G = NP / NL, STAGE_BYTES = NP * 1024;
     static_assert(NP % NL == 0, "pieces divide over the loader waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2632,21 +2633,22 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
 }
 
 // persistent loader-wave kernel (shape 30): one block per CU, dynamic LDS = ring of NS x 40 KiB
-template <int EPI, int NS>
+template <int EPI, int NS, int FI = 4, int FJ = 3, int WN = 2, int WM = 4>
 static int launch_lp(const GemmParams& p, hipStream_t stream) {
-    constexpr int LDS = NS * 40 * 1024;
+    constexpr int TNB = 16 * FI * WN, TM = 16 * FJ * WM;
+    constexpr int LDS = NS * (TNB + TM) * 128;
     static unsigned long long attr_devs = 0;
     int dev = 0;
     const int cus = device_cus(&dev);
     GTAV_REQUIRE(cus > 0, "gemm: no current device");
     if (!(attr_devs >> (dev & 63) & 1)) {
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lp_kernel<EPI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lp_kernel<EPI, NS, FI, FJ, WN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_devs |= 1ull << (dev & 63);
     }
     GemmParams q = p;
-    const int T = cdiv(p.M, 192) * cdiv(p.N, 128);
-    q.tm.gn = choose_gn(p.M, p.N, p.K, 192, 128, 1);
-    GTAV_LAUNCH((gemm_lp_kernel<EPI, NS>), dim3(T < cus ? T : cus), dim3(768), LDS, stream, q);
+    const int T = cdiv(p.M, TM) * cdiv(p.N, TNB);
+    q.tm.gn = choose_gn(p.M, p.N, p.K, TM, TNB, 1);
+    GTAV_LAUNCH((gemm_lp_kernel<EPI, NS, FI, FJ, WN, WM>), dim3(T < cus ? T : cus), dim3(768), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -2660,10 +2662,19 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20,
                                         "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
-    if (shape == 30 || shape == 31) {   // persistent loader-wave kernel, 128 x 192 tiles: 30 = 4-stage ring (160 KiB), 31 = 3 stages
+    if (shape >= 30 && shape <= 33) {   // persistent loader-wave kernel: 30 / 31 = 128 x 192 tiles, 4- / 3-stage ring; 32 = 256 x 128, 33 = 128 x 256 (3 stages)
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");
-            return shape == 30 ? launch_lp<EPI, 4>(p, stream) : launch_lp<EPI, 3>(p, stream);
+#ifdef GTAV_EXPERIMENTS
+            // measured against shape 31 / the two-blocks-per-CU shapes: 30 ties 31; 32 / 33 win back to back on cold operands (fc1 at
+            // M = 5760 67 -> 57 us) and LOSE inside the forward (54 -> 59-60 us), profiles/round3/*persistent*256x128*
+            if (shape == 30) return launch_lp<EPI, 4>(p, stream);
+            if (shape == 32) return launch_lp<EPI, 3, 4, 4, 4, 2>(p, stream);
+            if (shape == 33) return launch_lp<EPI, 3, 4, 4, 2, 4>(p, stream);
+#else
+            GTAV_REQUIRE(shape == 31, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
+#endif
+            return launch_lp<EPI, 3>(p, stream);
         } else {
             GTAV_REQUIRE(false, "gemm: the persistent loader-wave kernel (shape %d) has no epilogue %d", shape, (int)EPI);
         }
@@ -2913,6 +2924,9 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         else if (fold_p && t12 > 128) wm = 12, narrow_pick = true;
     }
     if (!g_force_wm && epi_x == EPI_PARTIAL && splitk == 1 && lp_takes(p.M, p.N, p.K)) wm = 31, narrow_pick = true;
+#ifdef GTAV_EXPERIMENTS
+    if (!g_force_wm && epi_x == EPI_GELU_TANH && (g_debug & 0x600000) && cdiv(p.M, 128) * cdiv(p.N, 256) >= 512) wm = (g_debug & 0x200000) ? 33 : 32;   // A/B of the persistent 128 x 256 / 256 x 128 tiles for fc1 (debug bits 21 / 22)
+#endif
     // large M: the persistent ping-pong kernel (epilogue and next tile's prologue under the other wave group's MFMAs)
     if (!g_force_wm && splitk == 1 && gemm_pp_ok(p.M, p.N, p.K, epi) && !(epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL && p.S % 8 != 0)) wm = 16;
     GTAV_REQUIRE(!(wm == 8 && epi == EPI_QKV && p.qkv_mode == QKV_SPATIAL), "gemm: 96-feature tiles straddle the K / V boundary (spatial QKV)");

@@ -437,10 +437,10 @@ def test_gemm_other_tiles_all_epilogues(shape):
         lib.gtav_op_gemm_set_wm(0)
 
 
-@pytest.mark.parametrize("shape", [30, 31])
+@pytest.mark.parametrize("shape", [31])
 @pytest.mark.parametrize("M,N,K", [(5760, 4096, 1024), (5760, 1024, 4096), (2312, 384, 896), (192, 128, 64), (11520, 1024, 1024), (100, 256, 128)])
 def test_persistent_loader_wave_kernel(shape, M, N, K):
-    """Block shapes 30 / 31 (round 3): the persistent loader-wave kernel — one block per CU walking several 128 x 192 tiles with the LDS ring
+    """Block shape 31 (round 3; 30 / 32 / 33, its 4-stage and 256 x 128 / 128 x 256 forms, live in the experiments build and passed this test there): the persistent loader-wave kernel — one block per CU walking several 128 x 192 tiles with the LDS ring
     running on across tile boundaries, epilogue straight from the accumulators — on the GELU (fp16 tile-major) and full-K slab (fp32) epilogues:
     one tile per block, several tiles per block (960 tiles on 256 CUs), ragged token / feature edges, K of 1, 2, 14, 16 and 64 K-steps; two runs
     must agree bit for bit (a fill that lands after its first read, or a ring slot refilled too early, shows up as run-to-run differences)."""
