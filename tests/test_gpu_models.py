@@ -344,6 +344,22 @@ def test_g256_geometry_preset():
     assert rel_l2(m(x, t, a), ref) < TOL_SMALL
 
 
+def test_g256_geometry_full_width_forward():
+    """The g256 preset at PRODUCTION widths (hidden 1024, 16 blocks, 16 heads on a 16 x 16 latent grid: 64 tokens per frame, M = 320 for the
+    5-frame window and M = 64 for a context-cached step — the 64 x 96 / 64 x 48 tile shapes with 64-token frames, which the native geometry
+    never runs at full width), against the CPU oracle at the north-star bound."""
+    dkw = dict(input_h=16, input_w=16, patch_size=2, in_channels=16, hidden_size=1024, depth=16, num_heads=16, external_cond_dim=25)
+    m, sd, cfg = _mk_dit(dkw, seed=14, max_batch=1)
+    for T, actions in ((5, True), (1, False)):
+        x, t, a = _inputs(cfg, 1, T, seed=15 + T, actions=actions)
+        with torch.no_grad():
+            ref = O.dit_forward(sd, cfg, x, t, a)
+        e = rel_l2(m(x, t, a), ref)
+        print(f"g256 full width T={T}: {e:.2e}")
+        assert e < TOL_FULL
+    m.check()
+
+
 def test_constructor_variants():
     """external_cond_dim = 0 (nn.Identity in the reference, model/dit.py:263-267), a non-variational VAE
     (model/vae.py:316-317) and growing `max_frames` after construction (generate.py:139)."""
