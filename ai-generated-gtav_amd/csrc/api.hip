@@ -333,8 +333,13 @@ struct gtav_dit {
         float *z0 = nullptr, *cpre = nullptr;                   // pre-SiLU values of the conditioning path
         float *dres = nullptr, *dtmp = nullptr, *stats = nullptr, *dmod = nullptr, *dSc = nullptr, *ada_part = nullptr, *dc = nullptr, *dh0 = nullptr, *dz0 = nullptr;
         f16 *g_d = nullptr, *g_h = nullptr, *g_u = nullptr, *g_qkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dfo = nullptr;
+        // grouped weight gradients (launch_gemm_dw_grouped): the transposed operand pairs of a half-block's four dW GEMMs (fc2, fc1, out-proj, QKV)
+        // stay alive until its ONE grouped launch; null when the widths are not multiples of 256
+        f16 *tAg[4] = {nullptr, nullptr, nullptr, nullptr}, *tBg[4] = {nullptr, nullptr, nullptr, nullptr};
     } tr;
 };
+
+static int g_dw_grouped = GTAV_ENV_INT("GTAV_DW_GROUPED", 1);   // experiments build: 0 = one launch per weight gradient (A/B runs)
 
 // LayerNorm fold: tables, statistics and the grouped-GEMM descriptors, allocated by the first gtav_dit_set_fold that can fold anything
 static int fold_alloc(gtav_dit* h) {
@@ -1038,6 +1043,10 @@ int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena
     RET_IF(a.alloc_t(&t.dao, Mm * D)); RET_IF(a.alloc_t(&t.dfo, Mx * 64));
     const size_t widest = (size_t)(Hp > 3 * D ? Hp : 3 * D);
     RET_IF(a.alloc_t(&t.tA, widest * Mp)); RET_IF(a.alloc_t(&t.tB, widest * Mp));
+    if (D % 256 == 0 && Hp % 256 == 0) {   // (rows of the transposed images: fc2 dY / X, fc1, out-proj, QKV)
+        const size_t ra[4] = {(size_t)D, (size_t)Hp, (size_t)D, (size_t)3 * D}, rb[4] = {(size_t)Hp, (size_t)D, (size_t)D, (size_t)D};
+        for (int i = 0; i < 4; ++i) { RET_IF(a.alloc_t(&t.tAg[i], ra[i] * Mp)); RET_IF(a.alloc_t(&t.tBg[i], rb[i] * Mp)); }
+    }
     t.on = true;
     return 0;
 }
@@ -1190,7 +1199,28 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         return launch_gemm(q, epi, s);
     };
     // dW[n][k] += sum_m dY[m][n] X[m][k]: both operands transposed to [.][Mp] (tokens are the contraction), accumulating epilogue
-    auto gemm_dw = [&](const f16* dY, int N, const f16* X, int K, float* grad) -> int {
+    // Half-blocks of production widths defer their four dW GEMMs into ONE grouped launch of 256 x 256 tiles (flush_dw; gemm.h)
+    GemmDwGroup dwg[GEMM_DW_MAX_GROUPS];
+    int ndw = 0;
+    bool defer_dw = false;
+    if (tr.tAg[0] && g_dw_grouped) {
+        const GemmDwGroup probe[4] = {{tr.tAg[0], tr.tBg[0], tr.dres, D, Hp, Hp}, {tr.tAg[1], tr.tBg[1], tr.dres, Hp, D, D}, {tr.tAg[2], tr.tBg[2], tr.dres, D, D, D},
+                                      {tr.tAg[3], tr.tBg[3], tr.dres, 3 * D, D, D}};
+        defer_dw = gemm_dw_grouped_ok(probe, 4, Mp);
+    }
+    auto flush_dw = [&]() -> int {
+        if (!ndw) return 0;
+        const int n = ndw;
+        ndw = 0;
+        return launch_gemm_dw_grouped(dwg, n, Mp, h->err_flag, s);
+    };
+    auto gemm_dw = [&](const f16* dY, int N, const f16* X, int K, float* grad, int slot_i = -1) -> int {
+        if (defer_dw && slot_i >= 0) {
+            RET_IF(launch_transpose_tiled_f16(dY, M, N, tr.tAg[slot_i], s));
+            RET_IF(launch_transpose_tiled_f16(X, M, K, tr.tBg[slot_i], s));
+            dwg[ndw++] = GemmDwGroup{tr.tAg[slot_i], tr.tBg[slot_i], grad, N, K, K};
+            return 0;
+        }
         if (gemm_tn_pays(N, K, M)) {   // contraction over the rows of the tile-major operands themselves (transposing LDS reads): no transposes
             GemmParams q;
             memset(&q, 0, sizeof(q));
@@ -1253,11 +1283,11 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         RET_IF(launch_gate_bwd(tr.dres, mb + 5 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
         RET_IF(launch_frame_reduce_gate(tr.dres, b.y2, NB, P, D, dmb + 5 * D, MODW, s));
         RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "mlp.fc2.bias").grad, tr.red_ws, s));
-        RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad));
+        RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad, 0));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "mlp.fc2.weight").wT, Hp, D, EPI_F16_TILED, tr.g_h, Hp));
         RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
         RET_IF(launch_colsum_tiled_f16(tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, tr.red_ws, s));
-        RET_IF(gemm_dw(tr.g_u, Hp, b.xnB, D, slot(P_ + "mlp.fc1.weight").grad));
+        RET_IF(gemm_dw(tr.g_u, Hp, b.xnB, D, slot(P_ + "mlp.fc1.weight").grad, 1));
         RET_IF(gemm_dx(tr.g_u, slot(P_ + "mlp.fc1.weight").wT, D, Hp, EPI_F32, tr.dtmp, D));
         RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i + 1], mb + 4 * D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
         RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i + 1], tr.stats, NB, P, D, dmb + 3 * D, dmb + 4 * D, MODW, s));
@@ -1265,11 +1295,12 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
         RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
         RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, s));
-        RET_IF(gemm_dw(tr.g_d, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad));
+        RET_IF(gemm_dw(tr.g_d, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad, 2));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "attn.to_out.weight").wT, D, D, EPI_F16, tr.dao, D));
         if (hf == 0) RET_IF(launch_attn_spatial_bwd(b.q, b.k, b.v, tr.dao, NB, h->heads, P, D, h->rope_s.cs_dev, tr.g_qkv, h->err_flag, s));
         else RET_IF(launch_attn_temporal_bwd(b.q, b.k, tr.dao, B, P, D, T, h->maxT, h->rope_t.cs_dev, tr.g_qkv, h->err_flag, s));
-        RET_IF(gemm_dw(tr.g_qkv, 3 * D, b.xnA, D, slot(P_ + "attn.to_qkv.weight").grad));
+        RET_IF(gemm_dw(tr.g_qkv, 3 * D, b.xnA, D, slot(P_ + "attn.to_qkv.weight").grad, 3));
+        RET_IF(flush_dw());
         RET_IF(gemm_dx(tr.g_qkv, slot(P_ + "attn.to_qkv.weight").wT, D, 3 * D, EPI_F32, tr.dtmp, D));
         RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i], mb + D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
         RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i], tr.stats, NB, P, D, dmb, dmb + D, MODW, s));
@@ -1768,6 +1799,13 @@ int gtav_op_gemm_tn(const void* x, const void* w, int32_t M, int32_t N, int32_t 
     memset(&q, 0, sizeof(q));
     q.X = (const f16*)x; q.ldx = M; q.W = (const f16*)w; q.M = M; q.N = N; q.K = K; q.out = out; q.ldo = ldo;
     return launch_gemm_tn(q, (hipStream_t)stream);
+}
+int gtav_op_gemm_dw_grouped(int32_t n, const void* const* x, const void* const* w, float* const* out, const int32_t* M, const int32_t* N, const int32_t* ldo,
+                            int32_t K, void* stream) {
+    GTAV_REQUIRE(n >= 1 && n <= GEMM_DW_MAX_GROUPS && x && w && out && M && N && ldo, "op_gemm_dw_grouped: 1 .. %d groups", GEMM_DW_MAX_GROUPS);
+    GemmDwGroup g[GEMM_DW_MAX_GROUPS];
+    for (int i = 0; i < n; ++i) g[i] = GemmDwGroup{(const f16*)x[i], (const f16*)w[i], out[i], M[i], N[i], ldo[i]};
+    return launch_gemm_dw_grouped(g, n, K, nullptr, (hipStream_t)stream);
 }
 int gtav_op_gemm_splitk_ln(const void* x, int32_t ldx, const void* w, const float* bias, int32_t M, int32_t N, int32_t K,
                            int32_t splitk, float* parts, float* resid, const float* gate, int32_t gate_stride,

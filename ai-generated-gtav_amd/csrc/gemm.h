@@ -90,6 +90,14 @@ struct GemmGroup { const f16* X; const f16* W; float* out; const float* bias; in
 // blockIdx.y = group; every group has the same M and K; out is f32 row-major with leading dimension ldo.  `groups` is a DEVICE array.
 int launch_gemm_grouped(const GemmGroup* groups_dev, int n_groups, int max_N, int M, int K, hipStream_t stream);
 
+// Grouped weight-gradient launch (training): out_g[m][n] (f32 row-major, ldo) += sum_k X_g[m][k] W_g[n][k] for up to GEMM_DW_MAX_GROUPS
+// independent GEMMs that share the contraction length K (the tokens), as ONE grid of 256 x 256 tiles.  X_g / W_g tile-major [M_g][K] / [N_g][K];
+// M_g, N_g multiples of 256.  gemm_dw_grouped_ok: shapes fit and the grouped grid is between half a round and two rounds of tiles.
+constexpr int GEMM_DW_MAX_GROUPS = 4;
+struct GemmDwGroup { const f16* X; const f16* W; float* out; int M; int N; int ldo; };
+bool gemm_dw_grouped_ok(const GemmDwGroup* g, int n, int K);
+int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hipStream_t stream);
+
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 // Temporal QKV projection + causal temporal attention in one launch (gemm.hip: gemm_qkvt_attn_kernel): X rows in the LayerNorm's

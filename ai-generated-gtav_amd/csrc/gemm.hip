@@ -1470,6 +1470,48 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     bs.end(p);
 }
 
+// Grouped weight-gradient launch (launch_gemm_dw_grouped; training): the four dW GEMMs of a half-block — outputs
+// 4096 x 1024, 1024 x 4096, 3072 x 1024 and 1024 x 1024, contraction over the 11 520 tokens of a batch-16 step — as ONE grid of 256 x 256
+// tiles (64 + 64 + 48 + 16 = 192 tiles: one per CU, one round).  Alone each of them fills the chip only with 128 x 128 tiles, whose
+// L2 -> LDS fill per FLOP is twice that of the 256 x 256 tile, and the long K loop is bound by exactly that fill (tools/dw_bench.py:
+// 137 + 119 + 92 + 56 us one after the other against ~250 us for ANY number of 256 x 256 tiles up to one per CU).  Blocks of one XCD take a
+// contiguous run of the (group, m-tile, n-tile) order, n fastest, so they share the rows of X and the W panels of their group in that
+// XCD's L2.  Epilogue: out += acc (EPI_RESID without gate or bias), every output tile owned by exactly one block.
+struct GemmDwGroups {
+    GemmDwGroup g[GEMM_DW_MAX_GROUPS];
+    int first[GEMM_DW_MAX_GROUPS + 1];   // first[i] = tiles of groups 0 .. i-1
+    int n;
+};
+__global__ __launch_bounds__(512, 1) void gemm256_dw_grouped_kernel(GemmParams p0, GemmDwGroups gs) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES];
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_DW_MAX_GROUPS; ++i)
+        if (i < gs.n && swz >= gs.first[i]) gi = i;
+    GemmParams p = p0;
+    p.X = gs.g[gi].X; p.W = gs.g[gi].W; p.out = gs.g[gi].out; p.M = gs.g[gi].M; p.N = gs.g[gi].N; p.ldo = gs.g[gi].ldo;
+    const int t = swz - gs.first[gi], tiles_n = p.N >> 8;
+    const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+    const int n0 = tile_n * 256, m0 = tile_m * 256;
+    BlockStamps bs;
+    bs.begin(p);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pbias[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mainloop256<false>(p, smem, n0, m0, 0, p.K / TK, acc, bs, []() {});
+    GTAV_STAMP(bs.t[2]);
+    epilogue<EPI_RESID, 8, 4, 4>(p, acc, pbias, smem, n0, m0, 0, false);
+    bs.end(p);
+}
+
 // Experiment of round 2, NOT kept — de-phasing the two co-resident blocks of a CU (shape 12, large M).  The per-block timeline
 // (tools/gemm_stamps.py, profiles/round2/stamps_lockstep.txt) shows the 512 blocks of a residency round in lockstep: prologue 2 us,
 // main loop 21.6 us, epilogue 6.1 us, all at the same time on every CU.  Making the second block to arrive on a CU (a ticket from a
@@ -2818,6 +2860,44 @@ int launch_gemm_tn(const GemmParams& p_in, hipStream_t stream) {
     p.tm.gn = choose_gn(p.M, p.N, p.K, 128, 128, 1);
     const dim3 grid((p.M / 128) * (p.N / 128));
     GTAV_LAUNCH((gemm_tn_kernel<4>), grid, dim3(512), 0, stream, p);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+bool gemm_dw_grouped_ok(const GemmDwGroup* g, int n, int K) {
+    if (!g || n < 1 || n > GEMM_DW_MAX_GROUPS || K <= 0 || K % TK) return false;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (g[i].M <= 0 || g[i].N <= 0 || g[i].M % 256 || g[i].N % 256 || g[i].ldo < g[i].N || g[i].ldo % 4) return false;
+        tiles += (g[i].M >> 8) * (g[i].N >> 8);
+    }
+    // worth it from half a round of 256 x 256 tiles on (below that the 128 x 128 grids of the single launches cover more CUs) up to
+    // two rounds; K long enough that the one-tile-per-CU prologue / epilogue do not matter
+    int dev = 0;
+    const int cus = device_cus(&dev);
+    return cus > 0 && 2 * tiles >= cus && tiles <= 2 * cus && K >= 2048;
+}
+
+int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(g && n >= 1 && n <= GEMM_DW_MAX_GROUPS && K > 0 && K % TK == 0, "gemm_dw_grouped: bad arguments (n=%d K=%d)", n, K);
+    GemmDwGroups gs;
+    memset(&gs, 0, sizeof(gs));
+    gs.n = n;
+    for (int i = 0; i < n; ++i) {
+        GTAV_REQUIRE(g[i].X && g[i].W && g[i].out && g[i].M > 0 && g[i].N > 0 && g[i].M % 256 == 0 && g[i].N % 256 == 0 && g[i].ldo >= g[i].N && g[i].ldo % 4 == 0,
+                     "gemm_dw_grouped: group %d: M=%d, N=%d must be multiples of 256, ldo=%d >= N", i, g[i].M, g[i].N, g[i].ldo);
+        GTAV_REQUIRE(((uintptr_t)g[i].X & 15) == 0 && ((uintptr_t)g[i].W & 15) == 0 && ((uintptr_t)g[i].out & 15) == 0, "gemm_dw_grouped: group %d: operands must be 16-byte aligned", i);
+        gs.g[i] = g[i];
+        gs.first[i + 1] = gs.first[i] + (g[i].M >> 8) * (g[i].N >> 8);
+    }
+    for (int i = n + 1; i <= GEMM_DW_MAX_GROUPS; ++i) gs.first[i] = gs.first[n];
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.K = K; p.splitk = 1; p.err_flag = err_flag; p.rows_per_gate = 1;
+#ifdef GTAV_EXPERIMENTS
+    p.stamps = g_stamps;
+#endif
+    GTAV_LAUNCH(gemm256_dw_grouped_kernel, dim3(gs.first[n]), dim3(512), 0, stream, p, gs);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

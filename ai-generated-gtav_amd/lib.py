@@ -113,6 +113,7 @@ SIGNATURES = {
     "gtav_op_attn_temporal": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "gtav_op_qkv_head_major": [_p, _p, _i, _p],
     "gtav_op_gemm_tn": [_p, _p, _i, _i, _i, _p, _i, _p],
+    "gtav_op_gemm_dw_grouped": [_i, _p, _p, _p, _p, _p, _p, _i, _p],
     "gtav_op_attn_spatial_bwd": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "gtav_op_gemm_qkvt_attn": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _i, _p],

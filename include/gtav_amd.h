@@ -310,6 +310,11 @@ int gtav_op_attn_spatial_bwd(const void* q_dev, const void* k_dev, const void* v
  * both operands the ordinary tile-major fp16 activations [K tokens][features] (x: M features, w: N features); out f32 row-major [M][ldo],
  * accumulated in place.  M, N multiples of 128, K a multiple of 64. */
 int gtav_op_gemm_tn(const void* x_f16_dev, const void* w_f16_dev, int32_t M, int32_t N, int32_t K, float* out_dev, int32_t ldo, void* stream);
+/* The weight-gradient GEMMs of one DiT half-block in ONE launch of 256 x 256 tiles (the training step's dW = dY^T X of fc2, fc1, to_out, to_qkv,
+ * train_dit.py:680): for each of the n <= 4 groups out_g[m][n] (f32 row-major [M_g][ldo_g]) += sum_k x_g[m][k] * w_g[n][k]; x_g / w_g tile-major fp16
+ * [M_g][K] / [N_g][K] (the TRANSPOSED activations: K = tokens); M_g, N_g multiples of 256, K of 64.  The arrays of pointers / sizes are HOST arrays. */
+int gtav_op_gemm_dw_grouped(int32_t n, const void* const* x_f16_dev, const void* const* w_f16_dev, float* const* out_dev, const int32_t* M,
+                            const int32_t* N, const int32_t* ldo, int32_t K, void* stream);
 /* Residual GEMM as the model runs it: split-K partial slabs (parts: splitk*M*N floats; splitk 0 = heuristic) followed by
  * the LayerNorm kernel that reduces them: resid += gate * (sum parts + bias); out = LN(resid) * (1 + scale + 1e-6) + shift. */
 int gtav_op_gemm_splitk_ln(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, int32_t M,

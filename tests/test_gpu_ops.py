@@ -325,6 +325,34 @@ def test_gemm_tn_weight_gradient(T, M, N):
     assert rel_l2(outs[0], ref) < 2e-5
 
 
+@pytest.mark.parametrize("groups,K", [([(1024, 256), (256, 1024), (768, 256), (256, 256)], 320), ([(512, 512)], 64), ([(256, 768), (1280, 256)], 1152),
+                                      ([(1024, 1024), (256, 256), (256, 512)], 128)])
+def test_gemm_dw_grouped_weight_gradients(groups, K):
+    """gemm256_dw_grouped_kernel: one to four weight-gradient GEMMs out_g[m][n] += sum_k X_g[m][k] W_g[n][k] (X_g / W_g = transposed activations,
+    K = tokens) as ONE grid of 256 x 256 tiles: every group's tiles land in its own output (12, 4, 8 and 19 tiles: grids that are and are not
+    multiples of the 8 XCDs), 1 to 18 K-steps, accumulating into non-zero outputs, twice (bitwise equal)."""
+    import ctypes as C
+    lib = L.load()
+    n = len(groups)
+    xs = [_rand(M, K, seed=10 + i).half() for i, (M, N) in enumerate(groups)]
+    ws = [_rand(N, K, scale=1 / math.sqrt(K), seed=20 + i).half() for i, (M, N) in enumerate(groups)]
+    base = [_rand(M, N, seed=30 + i) for i, (M, N) in enumerate(groups)]
+    xd, wd = [to_tiled_f16(x) for x in xs], [to_tiled_f16(w) for w in ws]
+    runs = []
+    for _ in range(2):
+        outs = [b.to(dev()).clone() for b in base]
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ints = lambda v: (C.c_int32 * n)(*v)
+        L.check(lib.gtav_op_gemm_dw_grouped(n, arr(xd), arr(wd), arr(outs), ints([g[0] for g in groups]), ints([g[1] for g in groups]), ints([g[1] for g in groups]),
+                                            K, stream()))
+        torch.cuda.synchronize()
+        runs.append(outs)
+    for i in range(n):
+        assert torch.equal(runs[0][i], runs[1][i])
+        ref = base[i] + xs[i].float() @ ws[i].float().t()
+        assert rel_l2(runs[0][i], ref) < 2e-5, (i, groups[i])
+
+
 def test_ddim_update_matches_reference_formula():
     rows, n = 6, 1000
     x, v = _rand(rows, n, seed=1), _rand(rows, n, seed=2)

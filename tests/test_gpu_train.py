@@ -179,6 +179,40 @@ def test_full_size_gradients_match_autograd():
     assert max(worst.values()) < 1e-2, worst
 
 
+def test_full_size_gradients_grouped_weight_gradient_launch():
+    """DiT-S/2 at its real size with B = 3 clips (M = 2160 tokens): from 2048 tokens on the four weight gradients of a half-block run as ONE
+    grouped launch of 256 x 256 tiles (gemm.h launch_gemm_dw_grouped, 192 tiles) instead of four launches of 128 x 128 tiles — every Linear
+    weight gradient of the first, a middle and the last block against torch autograd, and two backward passes bit-identical."""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT_models
+    from oracle import ref_cpu as O
+    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    g = torch.Generator().manual_seed(12)
+    B = 3
+    x = torch.randn(B, 5, 16, 18, 32, generator=g) * 0.7
+    t = torch.tensor([[15, 15, 15, 15, 420], [15, 15, 15, 15, 77], [15, 15, 15, 15, 901]])
+    a = torch.zeros(B, 5, 25)
+    a[torch.arange(B)[:, None], torch.arange(5)[None], torch.randint(0, 25, (B, 5), generator=g)] = 1
+    vt = torch.randn(B, 1, 16, 18, 32, generator=g)
+    torch.set_num_threads(16)
+    _, v_ref, grads = O.dit_loss_and_grads(sd, O.dit_s_2(), x, t, a, vt)
+    m = DiT_models["DiT-S/2"](init_weights=False, max_batch=B, trainable=True)
+    m.load_state_dict(sd)
+    v = m.forward_train(x, t, a)
+    assert rel_l2(v, v_ref) < 1e-3
+    keys = [f"blocks.{l}.{h}_{n}.weight" for l in (0, 7, 15) for h in "st" for n in ("attn.to_qkv", "attn.to_out", "mlp.fc1", "mlp.fc2")]
+    runs = []
+    for _ in range(2):
+        m.zero_grad()
+        m.backward_(v, vt)
+        m.check()
+        runs.append({k: m.grad(k).clone() for k in keys})
+    assert all(torch.equal(runs[0][k], runs[1][k]) for k in keys)
+    worst = {k: rel_l2(runs[0][k], grads[k]) for k in keys}
+    print("worst weight-gradient error:", max(worst.values()))
+    assert max(worst.values()) < 1e-2, worst
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (1, 5), (5, 5)])
 def test_gradients_other_windows(B, T):
     """Windows of 1, 2 and 5 frames (the temporal attention backward is specialised per window length; T = 1 has one key per query);
