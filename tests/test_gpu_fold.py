@@ -146,7 +146,7 @@ def test_fold_sampler_prepared_steps_graph_and_cached():
     for k, v in outs.items():
         e = rel_l2(v, ref)
         print(f"rollout {k}: {e:.2e}")
-        assert e < 1e-2, k
+        assert e < 3e-3, k
     assert rel_l2(outs[2], outs[0]) < 5e-3
     assert rel_l2(outs[(2, "cached")], outs[2]) < 1e-4          # same kernels on the same rows up to the tile shapes' summation order
     assert torch.equal(outs[(2, "inline")], outs[2])            # hoisted vs per-step tables: the same arithmetic

@@ -19,7 +19,7 @@ from gtav_amd.model.vae import AutoencoderKL, VAE_models  # noqa: E402
 
 TOL_FULL = 1e-3      # north-star bound: full-size DiT / VAE forwards vs the fp32 CPU reference
 TOL_SMALL = 2e-3     # toy widths (hidden 128-256): fewer terms per dot product average the fp16 operand rounding less
-TOL_ROLLOUT = 1e-2   # tens of chained forwards of a toy model
+TOL_ROLLOUT = 3e-3   # tens of chained forwards (toy and full-size models; measured <= 7e-4, pytest -s prints every margin)
 
 
 def rel_l2(a, b):

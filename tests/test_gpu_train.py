@@ -1,15 +1,26 @@
 """SURVEY.md 8(f)1 — DiT training step on the GPU against torch autograd / torch.optim on the CPU oracle.
 Tolerances: the backward pass is mixed precision like the reference's own (fp16 operands here, bf16 autocast there, fp32 master
-weights and gradients in both), so parameter gradients are compared by relative L2 per tensor: <= 1e-2 for every tensor
-(measured 3e-4 .. 3.6e-3, profiles/round2/train_grad_parity.txt); AdamW updates of a step <= 2e-2 of the update's norm."""
+weights and gradients in both), so parameter gradients are compared by relative L2 per tensor: <= 6e-3 for every tensor
+(measured 3e-4 .. 3.5e-3, profiles/round2/train_grad_parity.txt and `pytest -s`); AdamW updates of a step <= 2e-2 of the update's norm."""
 import math
 
 import pytest
 import torch
 
-from helpers import dev, rel_l2
+import os
+
+from helpers import dev
+from helpers import rel_l2 as _rel_l2
+
+
+def rel_l2(a, b):
+    v = _rel_l2(a, b)
+    print(f"[rel_l2 {os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1].split(' ')[0]}] {v:.3e}")   # (-s shows the measured margins)
+    return v
 
 pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 6e-3   # relative L2 per gradient tensor; measured worst 3.5e-3 (toy model, B = 5) / 3.3e-3 (full size), pytest -s prints every margin
 
 KW = dict(input_h=8, input_w=16, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
 
@@ -53,7 +64,7 @@ def test_gradients_match_autograd(actions):
             assert g.abs().max() == 0, k                 # e.g. external_cond.* without actions: unused, gradient None upstream
             continue
         worst[k] = rel_l2(g, gref)
-    bad = {k: v_ for k, v_ in worst.items() if v_ > 1e-2}
+    bad = {k: v_ for k, v_ in worst.items() if v_ > GRAD_TOL}
     assert not bad, f"gradient mismatch: {bad}"
 
 
@@ -103,7 +114,7 @@ def test_adamw_step_matches_torch():
     m.zero_grad()
     m.backward_(v2, vt)
     for k in ("blocks.1.t_mlp.fc1.weight", "blocks.0.s_attn.to_qkv.weight", "t_embedder.mlp.0.weight", "x_embedder.proj.weight"):
-        assert rel_l2(m.grad(k), grads2[k]) < 1e-2, k
+        assert rel_l2(m.grad(k), grads2[k]) < GRAD_TOL, k
 
 
 def test_overflow_skips_the_step():
@@ -176,7 +187,7 @@ def test_full_size_gradients_match_autograd():
             "blocks.7.s_mlp.fc1.weight", "blocks.7.t_mlp.fc2.weight", "blocks.7.t_adaLN_modulation.1.weight", "blocks.15.t_attn.to_qkv.weight",
             "blocks.15.s_mlp.fc2.bias", "final_layer.linear.weight", "final_layer.adaLN_modulation.1.bias"]
     worst = {k: rel_l2(m.grad(k), grads[k]) for k in keys}
-    assert max(worst.values()) < 1e-2, worst
+    assert max(worst.values()) < GRAD_TOL, worst
 
 
 def test_full_size_gradients_grouped_weight_gradient_launch():
@@ -210,7 +221,7 @@ def test_full_size_gradients_grouped_weight_gradient_launch():
     assert all(torch.equal(runs[0][k], runs[1][k]) for k in keys)
     worst = {k: rel_l2(runs[0][k], grads[k]) for k in keys}
     print("worst weight-gradient error:", max(worst.values()))
-    assert max(worst.values()) < 1e-2, worst
+    assert max(worst.values()) < GRAD_TOL, worst
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (1, 5), (5, 5)])
@@ -226,7 +237,7 @@ def test_gradients_other_windows(B, T):
     m.backward_(v, vt)
     m.check()
     worst = {k: rel_l2(m.grad(k), g) for k, g in grads.items() if g.norm() > 0}
-    assert max(worst.values()) < 1e-2, {k: v_ for k, v_ in worst.items() if v_ > 1e-2}
+    assert max(worst.values()) < GRAD_TOL, {k: v_ for k, v_ in worst.items() if v_ > GRAD_TOL}
 
 
 def test_loss_scale_is_transparent_and_micro_batches_accumulate():
@@ -282,9 +293,9 @@ def test_gradients_match_reference_fixture_g8():
     assert len(names) == int(g["names_check"])
     sel = lambda t_: t_.reshape(-1) if t_.numel() <= 4096 else t_.reshape(-1)[::97]
     norms = torch.stack([m.grad(k).norm().cpu() for k in names])
-    assert float(((norms - g["grad_norms"]).abs() / g["grad_norms"]).max()) < 1e-2
+    assert float(((norms - g["grad_norms"]).abs() / g["grad_norms"]).max()) < GRAD_TOL
     for k in names:
-        assert rel_l2(sel(m.grad(k).cpu()), g["grad." + k]) < 1e-2, k
+        assert rel_l2(sel(m.grad(k).cpu()), g["grad." + k]) < GRAD_TOL, k
     m.adamw_step(1e-3, weight_decay=0.01, max_grad_norm=1.0)
     applied, _, total = m.train_stats()
     assert applied and abs(total - float(g["total_grad_norm"])) < 5e-3 * float(g["total_grad_norm"])
