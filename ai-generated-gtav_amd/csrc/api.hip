@@ -282,6 +282,7 @@ struct gtav_dit {
     // forward_ab_B1_fused_temporal.txt).  gtav_dit_set_fused_temporal() is the switch (it allocates the head-major weight copies);
     // handles with training enabled keep the split path (the copies are not refreshed by the optimizer).
     bool fuse_tattn = false;
+    bool w_prefetch = true;   // L2 prefetch of the next GEMM's weight at small M (gemm.h pf_next)
     int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
     // ---- LayerNorm fold (gemm.h EPI_*_FOLD): the LayerNorm + modulate between a residual GEMM and its consumer runs inside the
     // two GEMM epilogues.  Seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection.  Per-frame c1 / c2 tables for every
@@ -463,10 +464,20 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // launches can spread their K loop over all CUs.
     LnPending pend;
     bool have_pend = false;
-    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate) -> int {
+    // L2 prefetch of the NEXT GEMM's weight by the loader-wave kernels (gemm.h pf_next): at the few hundred tokens of a batch-1 step every launch
+    // otherwise starts on weights that come from HBM
+    const bool pf_on = h->w_prefetch && M <= 1536;
+    auto set_pf = [&](GemmParams& q, const f16* Wn, int Nn, int Kn, int skn) {
+        if (!pf_on || !Wn) return;
+        const int nkt = Kn / 64;
+        if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
+        q.pf_next = Wn; q.pf_rt = cdiv(Nn, 128); q.pf_nkt = nkt; q.pf_splitk = skn;
+    };
+    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const f16* Wn = nullptr, int Nn = 0, int Kn = 0) -> int {
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
+        set_pf(q, Wn, Nn, Kn, 1);
         q.splitk = gemm_choose_splitk(M, D, K);
         if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m)) {
             // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
@@ -503,6 +514,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
             if (folded_in) fold_consumer(g, 2 * hb, 3 * D);
+            set_pf(g, w.w_out, D, D, gemm_choose_splitk(M, D, D));
             if (fused_t) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
@@ -523,13 +535,14 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             folded_in = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
+            set_pf(g, w.w_fc2, D, h->Hm_pad, gemm_choose_splitk(M, D, h->Hm_pad));
             if (fold_a) {
                 // seam A: out-proj updates the residual in place and emits fc1's operand + row statistics; fc1 normalises in its epilogue
                 RET_IF(fold_producer(PC_OUT, h->ao, w.w_out, D, w.b_out, mb + 2 * D, mb + 4 * D));
                 fold_consumer(g, 2 * hb + 1, h->Hm);
                 PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH_FOLD, s));
             } else {
-                RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D));
+                RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D, w.w_fc1, h->Hm, D));
                 PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
                 have_pend = false;
                 PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
@@ -540,7 +553,9 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                 RET_IF(fold_producer(PC_FC2, h->hbuf, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, next_scale));
                 folded_in = true;
             } else {
-                RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D));
+                const gtav_dit::Half* nx = hb + 1 < 2 * h->L ? &h->halves[hb + 1] : nullptr;
+                const f16* wq_next = !nx ? nullptr : (hf == 0 && h->fuse_tattn && !h->tr.on && nx->w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0)) ? nx->w_qkv_hm : nx->w_qkv;
+                RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, wq_next, 3 * D, D));
             }
         }
     }
