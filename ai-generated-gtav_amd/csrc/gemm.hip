@@ -118,8 +118,9 @@ struct BlockStamps {
     __device__ __forceinline__ void begin(const GemmParams& p) {
         if (p.stamps) { t[0] = __builtin_amdgcn_s_memrealtime(); c0 = __builtin_amdgcn_s_memtime(); }
     }
+    template <bool PF = false>
     __device__ __forceinline__ void end(const GemmParams& p) {
-        asm volatile("" ::"v"(pf_sink));
+        if constexpr (PF) asm volatile("" ::"v"(pf_sink));
         if (p.stamps && threadIdx.x == 0) {
             t[3] = __builtin_amdgcn_s_memrealtime();
             unsigned long long* d = p.stamps + (size_t)blockIdx.x * ((p.debug & 32) ? 64 : 8);
@@ -137,9 +138,39 @@ struct BlockStamps {
     unsigned long long t[4];
     unsigned pf_sink = 0;   // destination register of l2_prefetch_next's loads: stays allocated until end()
     __device__ __forceinline__ void begin(const GemmParams&) {}
-    __device__ __forceinline__ void end(const GemmParams&) { asm volatile("" ::"v"(pf_sink)); }
+    template <bool PF = false>
+    __device__ __forceinline__ void end(const GemmParams&) {
+        if constexpr (PF) asm volatile("" ::"v"(pf_sink));
+    }
 };
 #endif
+
+// L2 prefetch of the next GEMM's weight (GemmParams::pf_next).  Called by the compute waves of the loader-wave kernels before their first
+// barrier — they issue no other vector-memory instruction until the epilogue, whose first wait on a (younger) bias / RoPE load also proves
+// these loads have returned (loads retire in order) — `sink`, their destination register, stays allocated until BlockStamps::end.  One dword
+// per 128-byte line pulls the line into this XCD's L2; 64 lines per wave-instruction, so a block's share (a few hundred lines) is one
+// instruction per compute wave: nothing beside the ~450 fill instructions of its K loop.
+__device__ __forceinline__ void l2_prefetch_next(const GemmParams& p, int cw, int ncw, int lane, unsigned& sink) {
+    if (!p.pf_next) return;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = ((int)gridDim.x + 7 - xcd) >> 3;   // this block is the j-th of the nb blocks of its XCD
+    const int sk = p.pf_splitk;
+    int ks0, ksn, rt0, rtn;
+    if (sk >= 8) {
+        ksn = sk >> 3; ks0 = xcd * ksn; rt0 = 0; rtn = p.pf_rt;
+    } else {
+        const int per = 8 / sk, part = xcd % per;
+        ks0 = xcd / per; ksn = 1;
+        rt0 = part * p.pf_rt / per; rtn = (part + 1) * p.pf_rt / per - rt0;
+    }
+    const int kpt = p.pf_nkt / sk, kt0 = ks0 * kpt, ktn = ksn * kpt;
+    const int lines = rtn * ktn * 128;
+    const int l0 = (int)((long long)lines * j / nb), l1 = (int)((long long)lines * (j + 1) / nb);
+    for (int l = l0 + 64 * cw + lane; l < l1; l += 64 * ncw) {
+        const int tile = l >> 7, r = tile / ktn;
+        const char* a = (const char*)p.pf_next + ((size_t)(rt0 + r) * p.pf_nkt + kt0 + (tile - r * ktn)) * TILE_BYTES + (l & 127) * 128;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
+    }
+}
 
 // Scheduling directive for a region that holds NM MFMAs and ND independent ds_reads: emit them as MFMA, RPM reads, MFMA, RPM reads,
 // ... until the reads are out, the remaining MFMAs last (sched_group_barrier masks: 0x008 = MFMA, 0x100 = DS read).  The reads go
@@ -437,6 +468,9 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
     // experiments build restores the late fills for A/B runs).  An L2 prefetch wave (one load per 128-byte line of K-step t + 3)
     // changed nothing in the same runs: the K-step is not waiting for the fabric.
     const bool late = w >= 4 && (NS > 2 || GTAV_DBG(p, 2048));
+    // (an L2 prefetch of the next GEMM's weight, l2_prefetch_next, in front of the prologue fills was measured here for the skinny shapes of the
+    // context-cached step, M = 144: 1.49 -> 1.57 ms per step — every wave of these kernels waits on its own vmcnt ring, so the prefetch sits in front of
+    // tile 0; only the loader-wave kernels, whose compute waves never wait on vmcnt in the K loop, carry it)
     const int npro = nkt < NS - 1 ? nkt : NS - 1;
     for (int t = 0; t < npro; ++t) stage(t);
     after_prologue();   // register loads the epilogue wants early (bias): behind the first fills, not in front of them
@@ -1620,33 +1654,6 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_grouped_kernel(GemmParams p0
 // so after barrier t tile t is complete and visible and nobody reads tile t - 1 any more.  Loader waves take part in the epilogue's
 // barriers and in its copy-out loops (they have nothing else to do).
 // ---------------------------------------------------------------------------------------------------------------------
-// L2 prefetch of the next GEMM's weight (GemmParams::pf_next).  Called by the compute waves of the loader-wave kernels before their first
-// barrier: they issue no other vector-memory instruction until the epilogue, whose first wait on a (younger) bias / RoPE load also proves
-// these loads have returned (loads retire in order) — `sink`, their destination register, stays allocated until BlockStamps::end.  One dword
-// per 128-byte line pulls the line into this XCD's L2; 64 lines per wave-instruction, so a block's share (a few hundred lines) is one
-// instruction per compute wave: nothing beside the ~450 fill instructions of its K loop.
-__device__ __forceinline__ void l2_prefetch_next(const GemmParams& p, int cw, int ncw, int lane, unsigned& sink) {
-    if (!p.pf_next) return;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = ((int)gridDim.x + 7 - xcd) >> 3;   // this block is the j-th of the nb blocks of its XCD
-    const int sk = p.pf_splitk;
-    int ks0, ksn, rt0, rtn;
-    if (sk >= 8) {
-        ksn = sk >> 3; ks0 = xcd * ksn; rt0 = 0; rtn = p.pf_rt;
-    } else {
-        const int per = 8 / sk, part = xcd % per;
-        ks0 = xcd / per; ksn = 1;
-        rt0 = part * p.pf_rt / per; rtn = (part + 1) * p.pf_rt / per - rt0;
-    }
-    const int kpt = p.pf_nkt / sk, kt0 = ks0 * kpt, ktn = ksn * kpt;
-    const int lines = rtn * ktn * 128;
-    const int l0 = (int)((long long)lines * j / nb), l1 = (int)((long long)lines * (j + 1) / nb);
-    for (int l = l0 + 64 * cw + lane; l < l1; l += 64 * ncw) {
-        const int tile = l >> 7, r = tile / ktn;
-        const char* a = (const char*)p.pf_next + ((size_t)(rt0 + r) * p.pf_nkt + kt0 + (tile - r * ktn)) * TILE_BYTES + (l & 127) * 128;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
-    }
-}
-
 template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, typename AfterPrologue>
 __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
                                            f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
@@ -1895,7 +1902,7 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
         GTAV_STAMP(bs.t[2]);
         epilogue<EPIX, FI, FJ, WM, WN, NL, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);
     }
-    bs.end(p);
+    bs.template end<true>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2028,7 +2035,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
             store16_sc1((f16*)p.out + tiled_off(row, head * 64 + c * 8, p.D), o8.u);
         }
     }
-    bs.end(p);
+    bs.template end<true>(p);
 }
 
 
@@ -2732,9 +2739,11 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     auto set_gn = [&](int tmb, int tnb) { p.tm.gn = choose_gn(p.M, p.N, p.K, tmb, tnb, splitk); };
     // the LayerNorm-fold epilogues are instantiated for the shapes the heuristic can pick for them (2, 3, 11, 12, 14, 20)
     constexpr bool FOLDISH = EPI == EPI_RESID_FOLD || epi_is_fold_consumer(EPI);
-    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20,
+    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20 || shape == 24 || shape == 26,
                                         "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
+    if (shape == 24) return launch_l<EPI, 4, 2, 1, 2, 3, 2>(p, splitk, stream);   // 64 x 48, 6 compute + 2 loader waves (the skinny shape 11 on the loader-wave kernel)
+    if (shape == 26) return launch_l<EPI, 4, 2, 2, 2, 3, 2>(p, splitk, stream);   // 64 x 96, 6 compute + 2 loader waves (shape 14 likewise)
     if (shape >= 30 && shape <= 33) {   // persistent loader-wave kernel: 30 / 31 = 128 x 192 tiles, 4- / 3-stage ring; 32 = 256 x 128, 33 = 128 x 256 (3 stages)
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");
@@ -3021,6 +3030,13 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     // Round 2: the 128 x 96 tile runs on the loader-wave kernel (shape 20: 4 loader + 8 compute waves, fills and MFMAs overlap by
     // construction): QKV 14.1 -> 10.7 us, fc1 13.3 -> 10.9, fc2 12.0 -> 10.2, out-proj 6.6 -> 6.1 at M = 720 (profiles/round2).
     if (!g_force_wm && !(g_debug & 64) && (wm == 9 || (wm == 8 && g_l_for_8))) wm = (g_debug & 128) ? 25 : 20;   // debug bit 6 (experiments build): round-1 shapes, for A/B runs in one process
+    // Round 3: the skinny tiles on the loader-wave kernel too (6 compute + 2 loader waves): M = 144 QKV 8.45 -> 7.34 us, fc1 7.75 -> 6.83, out-proj 5.00 -> 4.68;
+    // M = 288 QKV 10.3 -> 8.4, fc1 9.7 -> 8.4 (profiles/round3/skinny_loader_wave_shapes_M144_M288.txt); their compute waves carry the next-weight L2 prefetch.
+    // The 8-slice fc2 at M = 288 stays on the all-waves-fill kernel (7.4 against 8.3 us).
+    if (!g_force_wm && !(g_debug & 64)) {
+        if (wm == 11) wm = 24;
+        else if (wm == 14 && !(epi_x == EPI_PARTIAL && splitk >= 8)) wm = 26;
+    }
     if (!g_force_wm && wm == 2 && cdiv(p.M, 192) * cdiv(p.N, 128) * splitk >= 320) {
         // large M: 128 x 192 tiles (4 waves of 64 x 96, still two blocks per CU) move 17 % fewer fill bytes per FLOP than
         // 128 x 128: QKV 62.6 -> 55.5 us, fc1 63.8 -> 61.1 us at M = 5760 (profiles/round1/v17_gemm_128x192_microbench.txt);
@@ -3057,7 +3073,7 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     int ns = g_force_stages ? g_force_stages : ((wm == 12 || wm == 13) ? 2 : wm >= 8 ? 4 : wm == 3 ? 4 : 2);   // (shapes 20+ carry their ring depth in the template)
     // a wave's token span (16 FJ) must not exceed a frame: the skinny 64 x 48 / 64 x 96 tiles span 16 / 32 tokens, the others 48-64
     if (foldish) {
-        const int span = wm == 2 ? 64 : (wm == 3 || wm == 14) ? 32 : wm == 11 ? 16 : 48;   // (12, 13, 20: 48)
+        const int span = wm == 2 ? 64 : (wm == 3 || wm == 14 || wm == 26) ? 32 : (wm == 11 || wm == 24) ? 16 : 48;   // (12, 13, 20: 48)
         GTAV_REQUIRE(p.f_P >= span, "gemm/fold: frames of %d tokens are shorter than the token span (%d) of a wave of block shape %d", p.f_P, span, wm);
     }
     switch (epi_x) {

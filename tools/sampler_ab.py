@@ -1,0 +1,71 @@
+"""A/B of GEMM debug bits on the CAPTURED sampler step (hipGraph replay, the path the headline measures) in ONE process on ONE GPU: a fresh
+DiT handle per variant (a captured step bakes the kernel parameters in), variants alternating.  Experiments build.
+Usage (GPU box): python tools/sampler_ab.py [--variants 0 8388608] [--batch 1] [--frames 3] [--steps 50] [--cached]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from gtav_amd import lib as L  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", type=int, nargs="+", default=[0, 8388608])
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=3, help="generated frames per measurement")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--cached", action="store_true")
+    ap.add_argument("--actions", action="store_true")
+    ap.add_argument("--graph-ab", action="store_true", help="every variant also with eager (stream-ordered) launches instead of the captured graph")
+    a = ap.parse_args()
+    lib = L.load_experiments()
+    import gtav_amd.weights as W
+    from gtav_amd.generate import generate_latents
+    from gtav_amd.model.dit import DiT_models
+    dev = torch.device("cuda", 0)
+    B = a.batch
+    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    g = torch.Generator().manual_seed(3)
+    n_prompt, total = 4, 4 + a.frames
+    x0 = torch.randn(B, n_prompt, 16, 18, 32, generator=g) * 0.5
+    nz = torch.randn(B, total - n_prompt, 16, 18, 32, generator=g)
+    act = None
+    if a.actions:
+        act = torch.zeros(B, total, 25)
+        act[:, :, 3] = 1
+    models = {}
+    for v in a.variants:
+        for graph in ((True, False) if a.graph_ab else (True,)):
+            lib.gtav_op_gemm_set_debug(v)
+            m = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+            m.load_state_dict(sd)
+            generate_latents(m, x0, total, 4, nz, act, ctx_cache=a.cached)   # builds the handle; warm-up + capture under this variant's bits
+            if not graph:
+                m.set_graph(False)
+                generate_latents(m, x0, total, 4, nz, act, ctx_cache=a.cached)
+            torch.cuda.synchronize()
+            models[(v, graph)] = m
+    ref = None
+    for r in range(a.rounds):
+        for (v, graph), m in models.items():
+            lib.gtav_op_gemm_set_debug(v)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = generate_latents(m, x0, total, a.steps, nz, act, ctx_cache=a.cached)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if ref is None:
+                ref = out.clone()
+            nf = a.frames * (a.steps + 1)
+            print(f"round {r} variant {v:9d} {'graph' if graph else 'eager'}: {dt / nf * 1e3:.4f} ms per sampler step ({nf} steps, batch {B}, {'cached' if a.cached else 'window'}), "
+                  f"rel diff vs first {((out - ref).norm() / ref.norm()).item():.1e}", flush=True)
+    lib.gtav_op_gemm_set_debug(0)
+
+
+if __name__ == "__main__":
+    main()
