@@ -466,7 +466,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     bool have_pend = false;
     // L2 prefetch of the NEXT GEMM's weight by the loader-wave kernels (gemm.h pf_next): at the few hundred tokens of a batch-1 step every launch
     // otherwise starts on weights that come from HBM
-    static const int pf_max_m = GTAV_ENV_INT("GTAV_PF_MAX_M", 1536);   // (experiments build: A/B at larger M)
+    const int pf_max_m = 1536;   // (above: measured slower, the persistent large-M kernels lose more than their successors gain)
     // (not at the 144 tokens of a context-cached step: those launches are short weight streams themselves, and a second stream beside them cost
     // 1.5 % of the step — profiles/round3/sampler_ab_cached_skinny_shapes_and_prefetch.txt)
     const bool pf_on = h->w_prefetch && M >= 512 && M <= pf_max_m;

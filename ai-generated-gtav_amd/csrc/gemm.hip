@@ -2130,6 +2130,8 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
     }
     int slot = 0;
     float amax = 0.f;
+    // (the next-weight L2 prefetch of the small-M loader-wave kernels, l2_prefetch_next, was tried here for the to_qkv / fc1 launch behind this one at
+    // M = 5760: out-proj 16.9 -> 18.8 us, fc2 52.5 -> 54.2, consumers unchanged — profiles/round3/forward_ab_B8_next_weight_prefetch_persistent_kernel.txt)
     for (int ti = 0; ti < ntile; ++ti) {
         int n0, m0;
         lp_tile_of(p, (int)blockIdx.x + ti * nblk, tiles_m, tiles_n, TNB, TM, n0, m0);
@@ -2952,6 +2954,7 @@ int launch_gemm_grouped(const GemmGroup* groups_dev, int n_groups, int max_N, in
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
 
 int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     GemmParams p = p_in;
