@@ -469,12 +469,15 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     const int pf_max_m = 1536;   // (above: measured slower, the persistent large-M kernels lose more than their successors gain)
     // (not at the 144 tokens of a context-cached step: those launches are short weight streams themselves, and a second stream beside them cost
     // 1.5 % of the step — profiles/round3/sampler_ab_cached_skinny_shapes_and_prefetch.txt)
+    // (Prefetching for to_qkv / fc1 from the LayerNorm launch right in front of them instead — 64 extra blocks beside its row blocks — gained nothing
+    // for the consumers and made every LayerNorm 1.6 us longer: profiles/round3/*prefetch_from_layernorm_vs_from_gemm.txt.  The issuing GEMM pays
+    // 0.6-0.9 us for its prefetch, the consumer gains 1.5-2 us.)
     const bool pf_on = h->w_prefetch && M >= 512 && M <= pf_max_m;
     auto set_pf = [&](GemmParams& q, const f16* Wn, int Nn, int Kn, int skn) {
         if (!pf_on || !Wn) return;
         const int nkt = Kn / 64;
         if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
-        q.pf_next = Wn; q.pf_rt = cdiv(Nn, 128); q.pf_nkt = nkt; q.pf_splitk = skn;
+        q.pf = PrefetchDesc{Wn, cdiv(Nn, 128), nkt, skn};
     };
     auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const f16* Wn = nullptr, int Nn = 0, int Kn = 0) -> int {
         GemmParams q;

@@ -80,6 +80,42 @@ __host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
            (size_t)(((((k >> 3) & 7) ^ (r & 7)) << 3) + (k & 7));
 }
 
+// ---- L2 prefetch of a weight the NEXT launch will stream ---------------------------------------------
+// A batch-1 step streams all 1.2 GB of weights from HBM, so every GEMM launch starts on a cold W.  The launch in front of it (whose own memory
+// traffic is small) touches ONE dword per 128-byte line of the slice of W that the blocks of each XCD will stream: blocks with equal
+// blockIdx % 8 share an XCD and its L2 (tools/xcd_start.hip), clean lines survive a kernel boundary (tools/l2_persist.hip: 0.56 us per 32 KiB
+// block from the same XCD's L2, 1.3 us from another XCD's / the Infinity Cache, 3.1 us from HBM), and the consumer's tile map gives XCD x a
+// contiguous eighth of its (K slice, row panel) order.  W is tile-major [rt row tiles of 128][nkt K tiles of 64] x 16 KiB; with `splitk` K
+// slices the XCDs split K first, then the row tiles (gemm.hip tile_map).  Speed only: nothing depends on where a block really runs.
+struct PrefetchDesc {
+    const void* next;     // nullptr = off
+    int rt, nkt, splitk;  // splitk >= 1, nkt % splitk == 0, splitk divides 8 or is a multiple of 8
+};
+// The caller is thread `t` of the `nt` threads of the j-th of `nb` prefetching blocks of XCD `xcd`.  `sink` receives every load: keep it alive
+// (asm volatile("" :: "v"(sink))) until a later wait proves the loads returned, or until the wave ends.
+__device__ __forceinline__ void l2_prefetch_slice(const PrefetchDesc& d, int xcd, int j, int nb, int t, int nt, unsigned& sink) {
+    const int sk = d.splitk;
+    int ks0, ksn, rt0, rtn;
+    if (sk >= 8) {
+        ksn = sk >> 3; ks0 = xcd * ksn; rt0 = 0; rtn = d.rt;
+    } else {
+        const int per = 8 / sk, part = xcd % per;
+        ks0 = xcd / per; ksn = 1;
+        rt0 = part * d.rt / per; rtn = (part + 1) * d.rt / per - rt0;
+    }
+    const int kpt = d.nkt / sk, kt0 = ks0 * kpt, ktn = ksn * kpt;
+    const int lines = rtn * ktn * 128;
+    const int l0 = (int)((long long)lines * j / nb), l1 = (int)((long long)lines * (j + 1) / nb);
+    for (int l = l0 + t; l < l1; l += nt) {
+        const int tile = l >> 7, r = tile / ktn;
+        const char* a = (const char*)d.next + ((size_t)(rt0 + r) * d.nkt + kt0 + (tile - r * ktn)) * 16384 + (l & 127) * 128;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
+    }
+}
+static inline bool prefetch_desc_ok(const PrefetchDesc& d) {
+    return !d.next || (d.rt > 0 && d.nkt > 0 && d.splitk >= 1 && d.nkt % d.splitk == 0 && (d.splitk >= 8 ? d.splitk % 8 == 0 : 8 % d.splitk == 0));
+}
+
 // ---- fp32 -> fp16 with saturation -------------------------------------------------------------
 // The reference runs this path under bf16 autocast (fp32 exponent range); our inter-kernel activations are fp16, so a
 // plain conversion would turn |x| > 65504 into inf and the next GEMM into NaN.  Every fp16 store of an activation goes

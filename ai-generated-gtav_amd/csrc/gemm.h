@@ -83,13 +83,8 @@ struct GemmParams {
     float* f_stats_out;     // [M][N / 32][2]
     const float* f_scale;   // scale vectors of the NEXT LayerNorm: row r at f_scale + r * gate_stride
     f16* f_a;               // tile-major [round_up(M, 128)][N]
-    // ---- L2 prefetch of the NEXT GEMM's weight (loader-wave kernels at small M) ----
-    // While this launch's K loop runs, its compute waves touch one dword per 128-byte line of the slice of the next GEMM's W that the blocks of
-    // their XCD will stream in that launch (tile-major [pf_rt row tiles][pf_nkt K tiles] of 16 KiB; with pf_splitk K slices the XCDs split K
-    // first, then the row tiles, like tile_map): the weights of a batch-1 step (1.2 GB per forward) otherwise arrive from HBM at the head of
-    // every launch.  nullptr = off.
-    const void* pf_next;
-    int pf_rt, pf_nkt, pf_splitk;
+    // ---- L2 prefetch of the NEXT GEMM's weight by the compute waves of the loader-wave kernels at small M (common.h PrefetchDesc) ----
+    PrefetchDesc pf;
 };
 
 // One group of a grouped launch (launch_gemm_grouped): out[m][n] = sum_k X[m][k] W[n][k] + bias[n], m < M (common), n < N.

@@ -145,31 +145,15 @@ struct BlockStamps {
 };
 #endif
 
-// L2 prefetch of the next GEMM's weight (GemmParams::pf_next).  Called by the compute waves of the loader-wave kernels before their first
-// barrier — they issue no other vector-memory instruction until the epilogue, whose first wait on a (younger) bias / RoPE load also proves
-// these loads have returned (loads retire in order) — `sink`, their destination register, stays allocated until BlockStamps::end.  One dword
-// per 128-byte line pulls the line into this XCD's L2; 64 lines per wave-instruction, so a block's share (a few hundred lines) is one
-// instruction per compute wave: nothing beside the ~450 fill instructions of its K loop.
+// L2 prefetch of the next GEMM's weight (GemmParams::pf, common.h l2_prefetch_slice).  Called by the compute waves of the loader-wave kernels
+// before their first barrier — they issue no other vector-memory instruction until the epilogue, whose first wait on a (younger) bias / RoPE
+// load also proves these loads have returned (loads retire in order) — `sink`, their destination register, stays allocated until
+// BlockStamps::end.  64 lines per wave-instruction, so a block's share (a few hundred lines) is one instruction per compute wave: nothing
+// beside the ~450 fill instructions of its K loop.
 __device__ __forceinline__ void l2_prefetch_next(const GemmParams& p, int cw, int ncw, int lane, unsigned& sink) {
-    if (!p.pf_next) return;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nb = ((int)gridDim.x + 7 - xcd) >> 3;   // this block is the j-th of the nb blocks of its XCD
-    const int sk = p.pf_splitk;
-    int ks0, ksn, rt0, rtn;
-    if (sk >= 8) {
-        ksn = sk >> 3; ks0 = xcd * ksn; rt0 = 0; rtn = p.pf_rt;
-    } else {
-        const int per = 8 / sk, part = xcd % per;
-        ks0 = xcd / per; ksn = 1;
-        rt0 = part * p.pf_rt / per; rtn = (part + 1) * p.pf_rt / per - rt0;
-    }
-    const int kpt = p.pf_nkt / sk, kt0 = ks0 * kpt, ktn = ksn * kpt;
-    const int lines = rtn * ktn * 128;
-    const int l0 = (int)((long long)lines * j / nb), l1 = (int)((long long)lines * (j + 1) / nb);
-    for (int l = l0 + 64 * cw + lane; l < l1; l += 64 * ncw) {
-        const int tile = l >> 7, r = tile / ktn;
-        const char* a = (const char*)p.pf_next + ((size_t)(rt0 + r) * p.pf_nkt + kt0 + (tile - r * ktn)) * TILE_BYTES + (l & 127) * 128;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
-    }
+    if (!p.pf.next) return;
+    const int xcd = blockIdx.x & 7;
+    l2_prefetch_slice(p.pf, xcd, (int)blockIdx.x >> 3, ((int)gridDim.x + 7 - xcd) >> 3, 64 * cw + lane, 64 * ncw, sink);
 }
 
 // Scheduling directive for a region that holds NM MFMAs and ND independent ds_reads: emit them as MFMA, RPM reads, MFMA, RPM reads,
@@ -1728,6 +1712,8 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
         woff[s] = (16 * FI * wn + li) * 128 + ch;
         xoff[s] = WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
     }
+    // (issued a few K-steps into the loop instead, past the launch's own first fills, the prefetch made the step 4 % SLOWER than no prefetch:
+    // profiles/round3/sampler_ab_window_prefetch_issued_mid_loop.txt)
     l2_prefetch_next(p, w, NCW, lane, bs.pf_sink);   // (before the epilogue's own early loads: older, so the epilogue's first wait covers them)
     after_prologue();   // register loads the epilogue wants early (bias)
     auto rd = [&](int t, f16x8 (&wf)[2][FI], f16x8 (&xf)[2][FJ]) {
@@ -2983,11 +2969,8 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     // frames/s) and back-to-back (profiles/round1/v13_gemm_sc1_stores_microbench.txt).  8-byte sc1 stores are SLOWER (one
     // fabric write each), so the unstaged epilogues keep plain stores.  Debug bit 3 turns it off (experiments).
     p.out_sc1 = (g_debug & 8) ? 0 : 1;
-    if (p.pf_next) {
-        GTAV_REQUIRE(p.pf_rt > 0 && p.pf_nkt > 0 && p.pf_splitk >= 1 && p.pf_nkt % p.pf_splitk == 0 && (p.pf_splitk >= 8 ? p.pf_splitk % 8 == 0 : 8 % p.pf_splitk == 0),
-                     "gemm: bad prefetch descriptor (row tiles %d, K tiles %d, K slices %d)", p.pf_rt, p.pf_nkt, p.pf_splitk);
-        if (g_debug & 0x800000) p.pf_next = nullptr;   // experiments build: A/B
-    }
+    GTAV_REQUIRE(prefetch_desc_ok(p.pf), "gemm: bad prefetch descriptor (row tiles %d, K tiles %d, K slices %d)", p.pf.rt, p.pf.nkt, p.pf.splitk);
+    if (g_debug & 0x800000) p.pf.next = nullptr;   // experiments build: A/B
     GTAV_REQUIRE(p.K > 0 && p.K % TK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, TK);
     GTAV_REQUIRE(p.M > 0 && p.N > 0 && p.N % 4 == 0, "gemm: bad M=%d N=%d", p.M, p.N);
     GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--cached", action="store_true")
     ap.add_argument("--actions", action="store_true")
+    ap.add_argument("--fused-ab", action="store_true", help="every variant also with the fused temporal QKV + attention kernel")
     ap.add_argument("--graph-ab", action="store_true", help="every variant also with eager (stream-ordered) launches instead of the captured graph")
     a = ap.parse_args()
     lib = L.load_experiments()
@@ -40,10 +41,12 @@ def main():
         act[:, :, 3] = 1
     models = {}
     for v in a.variants:
-        for graph in ((True, False) if a.graph_ab else (True,)):
+        for graph in ((True, False) if a.graph_ab else ((True, "fused") if a.fused_ab else (True,))):
             lib.gtav_op_gemm_set_debug(v)
             m = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
             m.load_state_dict(sd)
+            if graph == "fused":
+                m.set_fused_temporal(True)
             generate_latents(m, x0, total, 4, nz, act, ctx_cache=a.cached)   # builds the handle; warm-up + capture under this variant's bits
             if not graph:
                 m.set_graph(False)
@@ -62,7 +65,7 @@ def main():
             if ref is None:
                 ref = out.clone()
             nf = a.frames * (a.steps + 1)
-            print(f"round {r} variant {v:9d} {'graph' if graph else 'eager'}: {dt / nf * 1e3:.4f} ms per sampler step ({nf} steps, batch {B}, {'cached' if a.cached else 'window'}), "
+            print(f"round {r} variant {v:9d} {'graph+fused-temporal' if graph == 'fused' else 'graph' if graph else 'eager'}: {dt / nf * 1e3:.4f} ms per sampler step ({nf} steps, batch {B}, {'cached' if a.cached else 'window'}), "
                   f"rel diff vs first {((out - ref).norm() / ref.norm()).item():.1e}", flush=True)
     lib.gtav_op_gemm_set_debug(0)
 
