@@ -477,7 +477,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         if (!pf_on || !Wn) return;
         const int nkt = Kn / 64;
         if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
-        q.pf = PrefetchDesc{Wn, cdiv(Nn, 128), nkt, skn, 0};
+        q.pf = PrefetchDesc{Wn, cdiv(Nn, 128), nkt, skn};
     };
     auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const f16* Wn = nullptr, int Nn = 0, int Kn = 0) -> int {
         GemmParams q;

@@ -90,7 +90,6 @@ __host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
 struct PrefetchDesc {
     const void* next;     // nullptr = off
     int rt, nkt, splitk;  // splitk >= 1, nkt % splitk == 0, splitk divides 8 or is a multiple of 8
-    int kt_lim;           // > 0: only the first kt_lim K tiles of every K slice (the head of the consumer's K loop); 0 = all
 };
 // The caller is thread `t` of the `nt` threads of the j-th of `nb` prefetching blocks of XCD `xcd`.  `sink` receives every load: keep it alive
 // (asm volatile("" :: "v"(sink))) until a later wait proves the loads returned, or until the wave ends.
@@ -104,9 +103,7 @@ __device__ __forceinline__ void l2_prefetch_slice(const PrefetchDesc& d, int xcd
         ks0 = xcd / per; ksn = 1;
         rt0 = part * d.rt / per; rtn = (part + 1) * d.rt / per - rt0;
     }
-    const int kpt = d.nkt / sk, kt0 = ks0 * kpt;
-    int ktn = ksn * kpt;
-    if (d.kt_lim > 0 && ksn == 1 && d.kt_lim < ktn) ktn = d.kt_lim;
+    const int kpt = d.nkt / sk, kt0 = ks0 * kpt, ktn = ksn * kpt;
     const int lines = rtn * ktn * 128;
     const int l0 = (int)((long long)lines * j / nb), l1 = (int)((long long)lines * (j + 1) / nb);
     for (int l = l0 + t; l < l1; l += nt) {

@@ -2971,8 +2971,6 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     p.out_sc1 = (g_debug & 8) ? 0 : 1;
     GTAV_REQUIRE(prefetch_desc_ok(p.pf), "gemm: bad prefetch descriptor (row tiles %d, K tiles %d, K slices %d)", p.pf.rt, p.pf.nkt, p.pf.splitk);
     if (g_debug & 0x800000) p.pf.next = nullptr;   // experiments build: A/B
-    if (p.pf.next && (g_debug & 0x2000000)) p.pf.kt_lim = (p.pf.nkt / p.pf.splitk + 1) / 2;   // experiments build: first half of every K slice only
-    if (p.pf.next && (g_debug & 0x4000000)) p.pf.kt_lim = (p.pf.nkt / p.pf.splitk + 3) / 4;   //                    first quarter
     GTAV_REQUIRE(p.K > 0 && p.K % TK == 0, "gemm: K=%d must be a positive multiple of %d", p.K, TK);
     GTAV_REQUIRE(p.M > 0 && p.N > 0 && p.N % 4 == 0, "gemm: bad M=%d N=%d", p.M, p.N);
     GTAV_REQUIRE(((uintptr_t)p.X & 15) == 0 && ((uintptr_t)p.W & 15) == 0, "gemm: operands must be 16-byte aligned");
