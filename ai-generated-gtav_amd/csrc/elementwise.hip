@@ -144,7 +144,9 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, av = v, bv = v;
     const float kshift = xr[0];   // the shift of the one-pass statistics below (same cache line as thread 0's own load)
     if (act) {
-        v = *(const f32x4*)(xr + c);
+        // the row and the split-K slabs are read ONCE: non-temporal loads, so that they do not push the next GEMM's prefetched weight slice (DESIGN.md 4.10:
+        // 1 MiB per XCD, issued one or two launches earlier) out of the 4 MiB L2 — a plain stream of 3 MiB per XCD through it does (tools/l2_persist.hip)
+        v = (pd.flags & 4) ? __builtin_nontemporal_load((const f32x4*)(xr + c)) : *(const f32x4*)(xr + c);
         av = *(const f32x4*)(a + c);
         bv = *(const f32x4*)(b + c);
     }
@@ -154,7 +156,10 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         // `sp < nsplit` tests).  Unused slab slots re-read slab 0 (an L1 hit) and are not added; the order of the adds
         // (bias, slab 0, slab 1, ...) is unchanged.
         const float* pp = pd.parts + (size_t)m * pd.ld + c;
-        auto slab = [&](int sp) -> f32x4 { return *(const f32x4*)(pp + (size_t)sp * pd.slab_stride); };
+        auto slab = [&](int sp) -> f32x4 {
+            const f32x4* q = (const f32x4*)(pp + (size_t)sp * pd.slab_stride);
+            return (pd.flags & 4) ? __builtin_nontemporal_load(q) : *q;
+        };
         f32x4 g4 = f32x4{1.f, 1.f, 1.f, 1.f};
         if (pd.gate) {
             int gr = m / pd.rows_per_gate;
@@ -638,7 +643,7 @@ __global__ void qkv_head_major_kernel(const f16* __restrict__ src, f16* __restri
 }  // namespace
 
 // -DGTAV_EXPERIMENTS builds: GTAV_LN_FLAGS (see LnPending::flags)
-static int g_ln_flags = GTAV_ENV_INT("GTAV_LN_FLAGS", 3);   // default: all stores written through (B = 1: LN 0.57 -> 0.54 ms per forward)
+static int g_ln_flags = GTAV_ENV_INT("GTAV_LN_FLAGS", 7);   // default: all stores written through (B = 1: LN 0.57 -> 0.54 ms per forward)
 
 // One block per row at every M since the write-through stores: B = 8 (M = 5760) LN 1.71 -> 1.43 ms per forward against the
 // wave-per-row kernel, M = 11 520 / 46 080 neutral.  GTAV_LN_ROWBLOCK_MAX restores a threshold for experiments.

@@ -2727,11 +2727,15 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     auto set_gn = [&](int tmb, int tnb) { p.tm.gn = choose_gn(p.M, p.N, p.K, tmb, tnb, splitk); };
     // the LayerNorm-fold epilogues are instantiated for the shapes the heuristic can pick for them (2, 3, 11, 12, 14, 20)
     constexpr bool FOLDISH = EPI == EPI_RESID_FOLD || epi_is_fold_consumer(EPI);
-    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20 || shape == 24 || shape == 26,
+    if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20 || shape == 24 || shape == 26 || shape == 27 || shape == 28,
                                         "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
     if (shape == 24) return launch_l<EPI, 4, 2, 1, 2, 3, 2>(p, splitk, stream);   // 64 x 48, 6 compute + 2 loader waves (the skinny shape 11 on the loader-wave kernel)
     if (shape == 26) return launch_l<EPI, 4, 2, 2, 2, 3, 2>(p, splitk, stream);   // 64 x 96, 6 compute + 2 loader waves (shape 14 likewise)
+#ifdef GTAV_EXPERIMENTS
+    if (shape == 27) return launch_l<EPI, 8, 2, 1, 2, 3, 2>(p, splitk, stream);   // shape 24 with an 8-stage ring (112 KiB): seven K-steps of W in flight per CU
+    if (shape == 28) return launch_l<EPI, 8, 2, 1, 2, 3, 4>(p, splitk, stream);   // ... and four loader waves
+#endif
     if (shape >= 30 && shape <= 33) {   // persistent loader-wave kernel: 30 / 31 = 128 x 192 tiles, 4- / 3-stage ring; 32 = 256 x 128, 33 = 128 x 256 (3 stages)
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");

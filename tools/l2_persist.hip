@@ -69,5 +69,24 @@ int main() {
             if (report(names[variant])) return 1;
         }
     }
+    // How much may another launch stream through the L2 between the prefetch and the re-read before the lines are gone?  (The GEMM that issues the
+    // prefetch streams ~2.5 MB per XCD of its own operands afterwards.)  touch slice x -> stream `mb` MiB per XCD of a third buffer -> re-read slice x.
+    printf("re-read of the same XCD's 1 MiB slice after another launch streamed N MiB per XCD through the L2 (stream-ordered)\n");
+    uint4* buf3;
+    const size_t b3 = 16ull * (8 << 20);   // 16 regions of 8 MiB (1 MiB per XCD each); the loop below uses regions 0 .. 11
+    CK(hipMalloc(&buf3, b3));
+    CK(hipMemset(buf3, 1, b3));
+    for (int half_mb = 0; half_mb <= 12; half_mb += (half_mb < 4 ? 1 : 2)) {
+        hipLaunchKernelGGL(sweep, dim3(2048), dim3(256), 0, s, big, bigb / 16);
+        CK(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(touch, dim3(NBLK), dim3(256), 0, s, buf, 0, (unsigned long long*)nullptr, sink);
+        for (int k = 0; k < half_mb && k < 16; ++k)   // each launch reads one 8 MiB region = 1 MiB per XCD
+            hipLaunchKernelGGL(touch, dim3(NBLK), dim3(256), 0, s, buf3 + (size_t)k * ((8 << 20) / 16), 0, (unsigned long long*)nullptr, sink);
+        hipLaunchKernelGGL(touch, dim3(NBLK), dim3(256), 0, s, buf, 0, t, sink);
+        CK(hipStreamSynchronize(s));
+        char name[64];
+        snprintf(name, sizeof(name), "%d MiB per XCD in between", half_mb);
+        if (report(name)) return 1;
+    }
     return 0;
 }
