@@ -120,56 +120,45 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx,
 // ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS: the default at every M.  With a few hundred rows
 // the wave-per-row kernel leaves most CUs idle (720 rows: 8.5 us vs 14.7); at thousands of rows the 4x larger number of
 // independent blocks still keeps more loads in flight (5760 rows: 22 us vs 26).
+#ifdef GTAV_EXPERIMENTS   // timing experiments (WRONG results): GTAV_LN_FLAGS bits 8.. switch pieces of the row-block kernel off (tools/ln_bench.py)
+#define LN_DBG(pd, b) ((pd).flags & (b))
+#else
+#define LN_DBG(pd, b) false
+#endif
 template <int MODE, bool PEND>
 __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
                                                            const float* __restrict__ p0, const float* __restrict__ p1,
                                                            int mod_stride, const int* __restrict__ rows, int rows_per_mod,
                                                            LnPending pd) {
     __shared__ float red[16];
+    // A block lives ~3 us and most of it is latency, so the head is laid out by hand (round 3): the loads that come from memory / the Infinity Cache —
+    // the residual row and the split-K slabs — are requested FIRST (they need five kernel arguments); the block-uniform table indices and the statistics'
+    // shift follow as SCALAR loads (their own counter: in flight beside the vector loads); the per-frame vectors (L2 hits) are requested last, as soon as
+    // the indices are back.  Before, hipcc had strung seven dependent s_load / s_waitcnt round trips in front of the first slab load.
     const int m = blockIdx.x;
     const int c = threadIdx.x * 4;
     const int nw = (blockDim.x + 63) >> 6, wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* xr = x + (size_t)m * ldx;
     const bool act = c < D;
-    const float *a, *b;
-    if (MODE == 0) {
-        int row = m / rows_per_mod;
-        if (rows) row = rows[row];
-        a = p1 + (size_t)row * mod_stride;
-        b = p0 + (size_t)row * mod_stride;
-    } else {
-        a = p0;
-        b = p1;
-    }
+    const bool nt = PEND && (pd.flags & 4);   // the row and the slabs are read ONCE: non-temporal loads keep them from pushing the next GEMM's prefetched
+                                              // weight slice out of the 4 MiB L2
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, av = v, bv = v;
-    const float kshift = xr[0];   // the shift of the one-pass statistics below (same cache line as thread 0's own load)
-    if (act) {
-        // the row and the split-K slabs are read ONCE: non-temporal loads, so that they do not push the next GEMM's prefetched weight slice (DESIGN.md 4.10:
-        // 1 MiB per XCD, issued one or two launches earlier) out of the 4 MiB L2 — a plain stream of 3 MiB per XCD through it does (tools/l2_persist.hip)
-        v = (pd.flags & 4) ? __builtin_nontemporal_load((const f32x4*)(xr + c)) : *(const f32x4*)(xr + c);
-        av = *(const f32x4*)(a + c);
-        bv = *(const f32x4*)(b + c);
-    }
+    if (act) v = nt ? __builtin_nontemporal_load((const f32x4*)(xr + c)) : *(const f32x4*)(xr + c);
+    f32x4 sl[8];
+    int nchunk = 0;
     if (PEND && act) {
-        // every load of the pending update is issued before the first add: the split-K slabs are independent, and a
-        // load-add-load-add chain costs one memory round trip per slab (the compiler does not hoist loads across the
-        // `sp < nsplit` tests).  Unused slab slots re-read slab 0 (an L1 hit) and are not added; the order of the adds
-        // (bias, slab 0, slab 1, ...) is unchanged.
+        // every load of the pending update is issued before the first add: the split-K slabs are independent, and a load-add-load-add chain costs
+        // one memory round trip per slab.  Unused slots of a chunk re-read slab 0 (an L1 hit) and are not added; the order of the adds (bias, slab 0,
+        // slab 1, ...) is fixed.
         const float* pp = pd.parts + (size_t)m * pd.ld + c;
         auto slab = [&](int sp) -> f32x4 {
             const f32x4* q = (const f32x4*)(pp + (size_t)sp * pd.slab_stride);
-            return (pd.flags & 4) ? __builtin_nontemporal_load(q) : *q;
+            return nt ? __builtin_nontemporal_load(q) : *q;
         };
-        f32x4 g4 = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (pd.gate) {
-            int gr = m / pd.rows_per_gate;
-            if (pd.gate_rows) gr = pd.gate_rows[gr];
-            g4 = *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
-        }
-        f32x4 y = pd.bias ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 sl[8];
-        const int nchunk = pd.nsplit <= 2 ? 2 : pd.nsplit <= 4 ? 4 : 8;     // block-uniform
-        if (nchunk == 2) {
+        nchunk = pd.nsplit <= 1 ? 1 : pd.nsplit <= 2 ? 2 : pd.nsplit <= 4 ? 4 : 8;     // block-uniform
+        if (nchunk == 1) {
+            sl[0] = slab(0);
+        } else if (nchunk == 2) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) sl[sp] = slab(sp < pd.nsplit ? sp : 0);
         } else if (nchunk == 4) {
@@ -179,6 +168,25 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
 #pragma unroll
             for (int sp = 0; sp < 8; ++sp) sl[sp] = slab(sp < pd.nsplit ? sp : 0);
         }
+    }
+    int row = 0, gr = 0;
+    if (MODE == 0) {
+        row = m / rows_per_mod;
+        if (rows && !LN_DBG(pd, 0x2000)) row = rows[row];
+    }
+    if (PEND && pd.gate) {
+        gr = m / pd.rows_per_gate;
+        if (pd.gate_rows && !LN_DBG(pd, 0x2000)) gr = pd.gate_rows[gr];
+    }
+    const float kshift = LN_DBG(pd, 0x200) ? 0.f : xr[0];   // the shift of the one-pass statistics below (same cache line as thread 0's own load)
+    if (act && !LN_DBG(pd, 0x100)) {
+        av = *(const f32x4*)((MODE == 0 ? p1 + (size_t)row * mod_stride : p0) + c);
+        bv = *(const f32x4*)((MODE == 0 ? p0 + (size_t)row * mod_stride : p1) + c);
+    }
+    if (PEND && act) {
+        f32x4 y = pd.bias && !LN_DBG(pd, 0x100) ? *(const f32x4*)(pd.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 g4 = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (pd.gate && !LN_DBG(pd, 0x100)) g4 = *(const f32x4*)(pd.gate + (size_t)gr * pd.gate_stride + c);
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp)
             if (sp < nchunk && sp < pd.nsplit) y = y + sl[sp];
@@ -199,10 +207,11 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
     const float s1 = wave_sum_dpp((a0 + a1) + (a2 + a3));
     const float s2 = wave_sum_dpp((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3));
     if (lane == 0) { red[wid] = s1; red[8 + wid] = s2; }
-    __syncthreads();   // every wave has consumed its copy of kshift = xr[0] by now
+    if (!LN_DBG(pd, 0x400)) __syncthreads();   // every wave has consumed its copy of kshift = xr[0] by now
     if (PEND && act) {
         float* xw = pd.x_out ? pd.x_out + (size_t)m * ldx + c : xr + c;   // training forward keeps every residual state
-        if (pd.flags & 1) store16_sc1(xw, v);
+        if (LN_DBG(pd, 0x800)) {}
+        else if (pd.flags & 1) store16_sc1(xw, v);
         else *(f32x4*)xw = v;
     }
     float t1 = 0.f, t2 = 0.f;
@@ -229,7 +238,8 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
         const int fr = m / pd.tperm_P, pp = m - fr * pd.tperm_P, bb = fr / pd.tperm_T, tt = fr - bb * pd.tperm_T;
         mo = ((bb * (pd.tperm_P >> 4) + (pp >> 4)) * pd.tperm_T + tt) * 16 + (pp & 15);
     }
-    store_f16x4_paired<1>(out + tiled_off(mo, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
+    if (!LN_DBG(pd, 0x1000)) store_f16x4_paired<1>(out + tiled_off(mo, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
+    else if (yv[0] == 1.2345f) out[0] = (f16)yv[1];
     sat_report(amax, pd.err_flag);
 }
 
