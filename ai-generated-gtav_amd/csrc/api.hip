@@ -485,7 +485,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
         set_pf(q, Wn, Nn, Kn, 1);
         q.splitk = gemm_choose_splitk(M, D, K);
-        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m)) {
+        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || (!h->tr.on && gemm_resid_inplace_ok(M, D, K))) {
             // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
             // read-modify-write hides under the other wave group's main loop, and without split-K slabs the next LayerNorm only
             // reads resid.  (With the one-shot kernels the same epilogue was a loss: B = 8 out-proj 0.77 -> 1.26 ms per forward;

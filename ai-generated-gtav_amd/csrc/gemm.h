@@ -115,6 +115,9 @@ int launch_gemm_tn(const GemmParams& p, hipStream_t stream);
 // True when launch_gemm would run this shape on the persistent ping-pong kernel (large M): residual GEMMs then use the in-place
 // EPI_RESID epilogue (hidden under the other wave group's main loop) instead of split-K slabs.
 bool gemm_pp_ok(int M, int N, int K, int epi);
+// True when launch_gemm runs a residual GEMM of this shape on the persistent loader-wave kernel (shape 31, large M), whose in-place gated residual epilogue
+// (EPI_RESID: the residual tile is requested at the head of the tile's K loop) replaces slab + LayerNorm reduction.
+bool gemm_resid_inplace_ok(int M, int N, int K);
 // Split-K factor used for a residual GEMM of this shape (1 = no split): fills the 256 CUs when M is small.
 int gemm_choose_splitk(int M, int N, int K);
 // Pipeline depth override for experiments (0 = heuristic, else 2 or 4 LDS stages).

@@ -2038,6 +2038,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
 //     STRAIGHT FROM REGISTERS (pairs of lanes exchange halves for 16-byte stores; no LDS staging, no barrier), whose stores drain under the next tile's K loop;
 //   * one block per CU, persistent over tiles blockIdx + i gridDim of the XCD-aware order; ONE s_barrier per K-step shared by all 12 waves.
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int LP_MAXF = 8;   // EPI_RESID: frames (gate rows) a 192-token tile may touch: tokens per gate row >= 32 (host-checked)
 __device__ __forceinline__ void lp_tile_of(const GemmParams& p, int v, int tiles_m, int tiles_n, int TNB, int TM, int& n0, int& m0) {
     const int T = tiles_m * tiles_n;
     const int xcd = v & 7, qq = T >> 3, rr = T & 7;
@@ -2131,7 +2132,49 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
         for (int i = 0; i < FI; ++i) {
             const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4;
             pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI != EPI_PARTIAL && p.bias && n < p.N) pbias[i] = *(const f32x4*)(p.bias + n);
+            if (EPI != EPI_PARTIAL && EPI != EPI_RESID && p.bias && n < p.N) pbias[i] = *(const f32x4*)(p.bias + n);   // (EPI_RESID: in the epilogue, see there)
+        }
+        // EPI_RESID (in-place gated residual update, large M): the residual tile is requested HERE, at the head of the tile's K loop — the compute waves issue
+        // no other vector-memory load and never wait on vmcnt in the loop, so the 48 registers per lane arrive under the MFMAs and the epilogue finds them
+        constexpr bool RES = EPI == EPI_RESID;
+        f32x4 xres[RES ? FI : 1][RES ? FJ : 1];
+        // ... and the bias / gate vectors of the tile (its TNB features of the <= LP_MAXF frames its tokens belong to: a few KiB) are staged in LDS behind the
+        // ring by the compute waves themselves, one 16-byte chunk per thread, requested in front of the residual tile.  The epilogue then reads them with
+        // ds_read: it issues NO vector-memory load, and a load behind its stores would wait for their write-through (vmcnt retires in order: measured
+        // twelve times per tile, +14 us per launch).  Two areas alternate by tile parity: a wave may stage tile t + 1 while a slower one still reads tile t,
+        // and the >= 1 K-step barriers of tile t + 1 lie between the last read of an area and its next write.
+        const int gfirst = RES ? m0 / p.rows_per_gate : 0;
+        float* const garea = (float*)(smem + NS * STAGE_BYTES) + (ti & 1) * (LP_MAXF + 1) * TNB;
+        if constexpr (RES) {
+            const int ct = 64 * w + lane;                                   // compute-thread index, 0 .. 511
+            if (ct < (LP_MAXF + 1) * (TNB / 4)) {
+                const int r = ct / (TNB / 4), cq = ct - r * (TNB / 4);     // staged row (frame slot, LP_MAXF = bias), 4-feature chunk
+                int n = n0 + 4 * cq;
+                n = n < p.N ? n : 0;
+                f32x4 val = r < LP_MAXF ? f32x4{1.f, 1.f, 1.f, 1.f} : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r < LP_MAXF) {
+                    if (p.gate) {
+                        const int nfr = (p.M - 1) / p.rows_per_gate;
+                        int fr = gfirst + r;
+                        fr = fr < nfr ? fr : nfr;
+                        if (p.gate_rows) fr = p.gate_rows[fr];
+                        val = *(const f32x4*)(p.gate + (size_t)fr * p.gate_stride + n);
+                    }
+                } else if (p.bias) {
+                    val = *(const f32x4*)(p.bias + n);
+                }
+                *(f32x4*)(garea + r * TNB + 4 * cq) = val;
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4;
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    const int m = m0 + 16 * FJ * wm + 16 * j + li;
+                    xres[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (n < p.N && m < p.M) xres[i][j] = *(const f32x4*)((const float*)p.out + (size_t)m * p.ldo + n);
+                }
+            }
         }
         f16x8 wa[FI], xa[FJ], wb[FI], xb[FJ];
         auto rdh = [&](const char* b, int sh, f16x8 (&wf)[FI], f16x8 (&xf)[FJ]) {
@@ -2166,6 +2209,17 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
         }
         mmh(wb, xb);
         // ---- epilogue straight from the accumulators (no LDS, no barrier): the stores drain under the next tile's K loop ----
+        int gslot[RES ? FJ : 1];   // EPI_RESID: staged gate row (frame slot) of this lane's token in each of its FJ token groups
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                int mm = m0 + 16 * FJ * wm + 16 * j + li;
+                mm = mm < p.M ? mm : p.M - 1;
+                gslot[j] = mm / p.rows_per_gate - gfirst;
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i) pbias[i] = *(const f32x4*)(garea + LP_MAXF * TNB + 16 * FI * wn + 16 * i + 4 * g4);
+        }
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
             const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4;
@@ -2174,7 +2228,15 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
                 const int m = m0 + 16 * FJ * wm + 16 * j + li;
                 const bool ok = n < p.N && m < p.M;
                 const f32x4 v = acc[i][j] + pbias[i];
-                if constexpr (EPI == EPI_PARTIAL) {
+                if constexpr (RES) {
+                    if (ok) {
+                        const f32x4 gq = *(const f32x4*)(garea + gslot[j] * TNB + 16 * FI * wn + 16 * i + 4 * g4);
+                        const f32x4 r = xres[i][j] + gq * v;
+                        float* dst = (float*)p.out + (size_t)m * p.ldo + n;
+                        if (p.out_sc1) store16_sc1(dst, r);
+                        else *(f32x4*)dst = r;
+                    }
+                } else if constexpr (EPI == EPI_PARTIAL) {
                     if (ok) {
                         float* dst = (float*)p.out + (size_t)m * p.ldo + n;
                         if (p.out_sc1) store16_sc1(dst, v);
@@ -2544,7 +2606,9 @@ void gemm_set_stamps(unsigned long long* buf, int max_blocks) { g_stamps = buf; 
 // M = 4320: out-proj 17.2 -> 13.2 us, fc2 47.1 -> 36.3 us; M = 5760: 17.5 -> 14.3, 51.0 -> 45.1; M = 8640: 27.5 -> 24.0, 78.6 -> 75.0; M = 11 520: 27.9 -> 25.1,
 // 87.6 -> 84.5; at 120 tiles (M = 2880) it loses (12.0 -> 12.8, 31.7 -> 34.0) and the split-K shapes stay.  One slab also halves what the LayerNorm behind fc2 reads.
 static int g_lp_enable = GTAV_ENV_INT("GTAV_LP", 1);   // experiments build: 0 = round-2 selection, for A/B runs
+static int g_resid_inplace = GTAV_ENV_INT("GTAV_RESID_INPLACE", 1);   // experiments build: 0 = slab + LayerNorm reduction at every M (A/B runs)
 static bool lp_takes(int M, int N, int K) { return g_lp_enable && N <= 2048 && N % 8 == 0 && K >= 512 && cdiv(M, 192) * cdiv(N, 128) >= 160; }
+bool gemm_resid_inplace_ok(int M, int N, int K) { return g_resid_inplace && lp_takes(M, N, K); }
 int gemm_choose_splitk(int M, int N, int K) {
     if (lp_takes(M, N, K)) return 1;
 #ifdef GTAV_EXPERIMENTS
@@ -2704,7 +2768,8 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
 template <int EPI, int NS, int FI = 4, int FJ = 3, int WN = 2, int WM = 4>
 static int launch_lp(const GemmParams& p, hipStream_t stream) {
     constexpr int TNB = 16 * FI * WN, TM = 16 * FJ * WM;
-    constexpr int LDS = NS * (TNB + TM) * 128;
+    constexpr int LDS = NS * (TNB + TM) * 128 + (EPI == EPI_RESID ? 2 * (LP_MAXF + 1) * TNB * 4 : 0);   // + the staged bias / gate rows, two tile parities
+    if constexpr (EPI == EPI_RESID) GTAV_REQUIRE(!p.gate || (p.rows_per_gate > 0 && (TM - 1) / p.rows_per_gate + 2 <= LP_MAXF), "gemm/resid on the persistent kernel: %d tokens per gate row are too few (a tile may touch at most %d rows)", p.rows_per_gate, LP_MAXF);
     static unsigned long long attr_devs = 0;
     int dev = 0;
     const int cus = device_cus(&dev);
@@ -2714,6 +2779,7 @@ static int launch_lp(const GemmParams& p, hipStream_t stream) {
         attr_devs |= 1ull << (dev & 63);
     }
     GemmParams q = p;
+    if (EPI == EPI_RESID && !q.gate) q.rows_per_gate = 1 << 30;   // no gate: one staged row of ones
     const int T = cdiv(p.M, TM) * cdiv(p.N, TNB);
     q.tm.gn = choose_gn(p.M, p.N, p.K, TM, TNB, 1);
     GTAV_LAUNCH((gemm_lp_kernel<EPI, NS, FI, FJ, WN, WM>), dim3(T < cus ? T : cus), dim3(768), LDS, stream, q);
@@ -2737,7 +2803,7 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if (shape == 28) return launch_l<EPI, 8, 2, 1, 2, 3, 4>(p, splitk, stream);   // ... and four loader waves
 #endif
     if (shape >= 30 && shape <= 33) {   // persistent loader-wave kernel: 30 / 31 = 128 x 192 tiles, 4- / 3-stage ring; 32 = 256 x 128, 33 = 128 x 256 (3 stages)
-        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
+        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED || EPI == EPI_RESID) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");
 #ifdef GTAV_EXPERIMENTS
             // measured against shape 31 / the two-blocks-per-CU shapes: 30 ties 31; 32 / 33 win back to back on cold operands (fc1 at
@@ -3045,7 +3111,7 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         else if (t13 > 256 && t13 <= 512 && !fold_p) wm = 13, narrow_pick = true;
         else if (fold_p && t12 > 128) wm = 12, narrow_pick = true;
     }
-    if (!g_force_wm && epi_x == EPI_PARTIAL && splitk == 1 && lp_takes(p.M, p.N, p.K)) wm = 31, narrow_pick = true;
+    if (!g_force_wm && (epi_x == EPI_PARTIAL || (epi_x == EPI_RESID && (!p.gate || p.rows_per_gate >= 32))) && splitk == 1 && lp_takes(p.M, p.N, p.K)) wm = 31, narrow_pick = true;
 #ifdef GTAV_EXPERIMENTS
     if (!g_force_wm && epi_x == EPI_GELU_TANH && (g_debug & 0x600000) && cdiv(p.M, 128) * cdiv(p.N, 256) >= 512) wm = (g_debug & 0x200000) ? 33 : 32;   // A/B of the persistent 128 x 256 / 256 x 128 tiles for fc1 (debug bits 21 / 22)
 #endif

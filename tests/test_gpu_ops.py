@@ -490,5 +490,16 @@ def test_persistent_loader_wave_kernel(shape, M, N, K):
         parts = torch.full((M, N), float("nan"), device=dev())
         L.check(lib.gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), 0, parts.data_ptr(), N, M, N, K, 6, 0, 1, 1, stream()))
         assert rel_l2(parts, pre) < 2e-5
+        # in-place gated residual epilogue (the residual tile is requested at the head of the tile's K loop): frames of 36 tokens where M allows, else one frame
+        P = 36 if M % 36 == 0 else M
+        resid, gate = _rand(M, N, seed=4), _rand(M // P, N, seed=5)
+        rs = []
+        for _ in range(2):
+            r = resid.clone().to(dev())
+            gd = gate.to(dev())
+            L.check(lib.gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), r.data_ptr(), N, M, N, K, 4, gd.data_ptr(), N, P, stream()))
+            rs.append(r.cpu())
+        assert torch.equal(rs[0], rs[1])
+        assert rel_l2(rs[0], resid + gate.repeat_interleave(P, dim=0) * (pre + b)) < 2e-5
     finally:
         lib.gtav_op_gemm_set_wm(0)
