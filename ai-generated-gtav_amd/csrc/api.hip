@@ -1847,6 +1847,7 @@ int gtav_op_rope_interleave(const float* cos_t, const float* sin_t, float* cs, i
     return launch_rope_interleave(cos_t, sin_t, cs, npos, (hipStream_t)stream);
 }
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K) { return gemm_choose_splitk(M, N, K); }
+int gtav_op_gemm_resid_inplace(int32_t M, int32_t N, int32_t K) { return gemm_resid_inplace_ok(M, N, K) ? 1 : 0; }
 void gtav_op_gemm_set_stages(int32_t ns) { gemm_set_stages(ns); }
 #ifdef GTAV_EXPERIMENTS
 void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }   // libgtav_amd_exp.so only (csrc/experiments.h)

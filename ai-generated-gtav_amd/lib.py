@@ -121,6 +121,7 @@ SIGNATURES = {
     "gtav_op_gemm_fold_producer": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p],
     "gtav_op_gemm_fold_consumer": [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],
+    "gtav_op_gemm_resid_inplace": [_i, _i, _i],
     "gtav_op_gemm_set_stages": [_i],
     "gtav_op_gemm_set_wm": [_i],
 }

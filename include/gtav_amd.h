@@ -333,6 +333,9 @@ int gtav_op_gemm_fold_producer(const void* x_f16_dev, const void* w_f16_dev, con
 int gtav_op_gemm_fold_consumer(const void* a_f16_dev, const void* w_f16_dev, int32_t M, int32_t N, int32_t K, int32_t epi, const float* stats_dev,
                                const float* c1_dev, const float* c2_dev, int32_t ldc, int32_t tokens_per_frame, void* out_dev, int32_t ldo, void* stream);
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K);
+/* 1 when the model runs a residual GEMM of this shape (out-proj, fc2) with the in-place gated residual epilogue (epilogue 4) instead of split-K slabs
+ * reduced by the following LayerNorm: large M on the persistent loader-wave kernel (csrc/gemm.h gemm_resid_inplace_ok). */
+int gtav_op_gemm_resid_inplace(int32_t M, int32_t N, int32_t K);
 /* (The per-thread hooks the parity tests use to force a GEMM block shape / pipeline depth are declared in gtav_amd_testing.h: they are
  * not part of the product interface.) */
 /* fp32 [R][C] -> fp16 [Rp][Cp] zero padded; tiled != 0 writes the GEMM's tile-major operand layout (128 x 64 tiles,

@@ -43,13 +43,22 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&hb, (size_t)Mp * H * 2));
         CK(hipMalloc(&parts, (size_t)8 * Mp * D * 4));
         const int sk_out = gtav_op_gemm_choose_splitk(M, D, D), sk_fc2 = gtav_op_gemm_choose_splitk(M, D, H);
+        const bool ip_out = gtav_op_gemm_resid_inplace(M, D, D), ip_fc2 = gtav_op_gemm_resid_inplace(M, D, H);   // large M: in-place gated residual epilogue
+        float* gate;
+        CK(hipMalloc((void**)&gate, (size_t)(M / 144 + 1) * D * 4));
+        CK(hipMemset(gate, 0, (size_t)(M / 144 + 1) * D * 4));
         for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_qkv(x, D, w[it % copies], nullptr, M, D, 0, q, k, v, 144, 0, 0, 0, cs, nullptr));
-        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(x, D, w[it % copies], nullptr, parts, D, M, D, D, 6, nullptr, sk_out, 1, nullptr));
+        for (int it = 0; it < iters; ++it)
+            GK(ip_out ? gtav_op_gemm_f16(x, D, w[it % copies], bias, parts, D, M, D, D, 4, gate, D, 144, nullptr)
+                      : gtav_op_gemm_f16(x, D, w[it % copies], nullptr, parts, D, M, D, D, 6, nullptr, sk_out, 1, nullptr));
         for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(x, D, w[it % copies], bias, hb, H, M, H, D, 2, nullptr, 0, 1, nullptr));
-        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(xh, H, w[it % copies], nullptr, parts, D, M, D, H, 6, nullptr, sk_fc2, 1, nullptr));
+        for (int it = 0; it < iters; ++it)
+            GK(ip_fc2 ? gtav_op_gemm_f16(xh, H, w[it % copies], bias, parts, D, M, D, H, 4, gate, D, 144, nullptr)
+                      : gtav_op_gemm_f16(xh, H, w[it % copies], nullptr, parts, D, M, D, H, 6, nullptr, sk_fc2, 1, nullptr));
         CK(hipDeviceSynchronize());
         printf("M=%d: %d launches each of qkv (N=3072 K=1024), out (N=1024 K=1024, %d K slices), fc1 (N=4096 K=1024), fc2 (N=1024 K=4096, %d K slices)\n", M, iters,
-               sk_out, sk_fc2);
+               ip_out ? 0 : sk_out, ip_fc2 ? 0 : sk_fc2);
+        CK(hipFree(gate));
         CK(hipFree(x)); CK(hipFree(xh)); CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(v)); CK(hipFree(hb)); CK(hipFree(parts));
     }
     return 0;

@@ -61,7 +61,8 @@ def main():
             out_bytes = M * N * (2 if name in ("qkv", "fc1") else 4)
             res[f"{name}_M{M}"] = {"hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "fetch_size_kb": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
                                    "launches": ITERS, "kernel": kern, "grid_threads": grid,
-                                   "algorithmic_bytes": N * K * 2 + M * K * 2 + out_bytes,
+                                   # (the in-place residual epilogue of the large-M out-proj / fc2 — EPI_RESID, gemm_lp_kernel<4, ..> — also READS its fp32 output tile)
+                                   "algorithmic_bytes": N * K * 2 + M * K * 2 + out_bytes * (2 if name in ("out", "fc2") and "gemm_lp_kernel<4" in kern else 1),
                                    "mfma_busy_cycles": round(mfma[(name, M)][0]), "sq_busy_cycles": round(sqb[(name, M)][0]),
                                    "shader_cycles": round(cyc), "mfma_busy": round(mfma[(name, M)][0] / (1024.0 * cyc), 4) if cyc > 0 else None}
     json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
