@@ -1208,6 +1208,53 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
             }
         }
     }
+    if constexpr (EPI == EPI_RESID && !FOLD) {
+        // Read-modify-write of the fp32 output, software-pipelined over the feature groups: the loads of group i + 1 (output tile, gate vector) are issued BEFORE
+        // the stores of group i.  vmcnt retires in order, so a load issued behind a store waits for that store's round trip — the straightforward load / add /
+        // store loop paid that FI x FJ times per wave (32 times on the 256 x 256 tile of the grouped weight-gradient launch).
+        int grow[FJ];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            int mm = m0 + 16 * FJ * wm + 16 * j + li;
+            mm = mm < p.M ? mm : p.M - 1;
+            grow[j] = 0;
+            if (p.gate) {
+                grow[j] = mm / p.rows_per_gate;
+                if (p.gate_rows) grow[j] = p.gate_rows[grow[j]];
+            }
+        }
+        f32x4 xo[2][FJ], gt[2][FJ];
+        auto loads = [&](int i, f32x4 (&xv)[FJ], f32x4 (&gv)[FJ]) {
+            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int m = m0 + 16 * FJ * wm + 16 * j + li;
+                xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                gv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (n < p.N && m < p.M) {
+                    xv[j] = *(const f32x4*)((const float*)p.out + (size_t)m * p.ldo + n);
+                    if (p.gate) gv[j] = *(const f32x4*)(p.gate + (size_t)grow[j] * p.gate_stride + n);
+                }
+            }
+        };
+        loads(0, xo[0], gt[0]);
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            if (i + 1 < FI) loads(i + 1, xo[(i + 1) & 1], gt[(i + 1) & 1]);
+            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int m = m0 + 16 * FJ * wm + 16 * j + li;
+                if (n < p.N && m < p.M) {
+                    const f32x4 x = xo[i & 1][j] + gt[i & 1][j] * (acc[i][j] + pbias[i]);
+                    float* dst = (float*)p.out + (size_t)m * p.ldo + n;
+                    if (p.out_sc1) store16_sc1(dst, x);
+                    else *(f32x4*)dst = x;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
         const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;  // 4 consecutive features n..n+3
@@ -1241,19 +1288,6 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                 *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
             } else if constexpr (EPI == EPI_F16) {
                 *(uint2*)((f16*)p.out + (size_t)m * p.ldo + n) = pack4(amax, v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == EPI_RESID) {
-                float* dst = (float*)p.out + (size_t)m * p.ldo + n;
-                f32x4 x = *(const f32x4*)dst;
-                if (p.gate) {
-                    int row = m / p.rows_per_gate;
-                    if (p.gate_rows) row = p.gate_rows[row];
-                    const f32x4 gt = *(const f32x4*)(p.gate + (size_t)row * p.gate_stride + n);
-                    x = x + gt * v;
-                } else {
-                    x = x + v;
-                }
-                if (p.out_sc1) store16_sc1(dst, x);
-                else *(f32x4*)dst = x;
             } else if constexpr (EPI == EPI_QKV) {
                 if (which < 2) {
                     // interleaved table: (cos, sin) of pair d/2 and of pair d/2+1 in one 16-byte load
