@@ -2650,7 +2650,13 @@ int gemm_choose_splitk(int M, int N, int K) {
 #endif
     const int tiles = cdiv(M, 128) * cdiv(N, TN);
     int s = 1;
-    while (tiles * s < 192 && s < 8 && (K / TK) % (s * 2) == 0 && K / (s * 2) >= 256) s *= 2;
+    // Every slab is one more 16-byte load per thread in the LayerNorm behind the GEMM (~0.4 us per slab and launch at M = 720) and 3 MB more through the L2s that
+    // hold the next GEMM's prefetched weight: from 48 tiles on (the batch-1 window step) a K slice is at least 512 deep — out-proj in two slices instead of four:
+    // GEMM unchanged (6.7-7.0 us), LayerNorm 5.45 -> 4.7 us, forward -1.3 ... -3 % (profiles/round3/forward_ab_B1_splitk_slices.txt); fc2 keeps four slices of 1024
+    // (two: +1.6 us).  Below 48 tiles (the 144-token cached step) the CUs matter more: 256 as before.
+    static const int old_rule = GTAV_ENV_INT("GTAV_SPLITK_OLD", 0);   // experiments build: A/B
+    const int min_slice = (tiles >= 48 && !old_rule) ? 512 : 256;
+    while (tiles * s < 192 && s < 8 && (K / TK) % (s * 2) == 0 && K / (s * 2) >= min_slice) s *= 2;
     // long-K GEMMs whose 128 x 192 grid would fill the 512 block slots unevenly (160-320 tiles): two K slices make it
     // 320-640 blocks of half the length — fc2 at M = 5760: 69.5 -> 57.6 us, for one more slab (+5 us) in the next LayerNorm
     if (s == 1 && K >= 4096 && (K / TK) % 2 == 0) {
