@@ -21,10 +21,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--cached", action="store_true")
     ap.add_argument("--actions", action="store_true")
+    ap.add_argument("--product", action="store_true", help="the product library (no debug bits: one variant) instead of the experiments build")
     ap.add_argument("--fused-ab", action="store_true", help="every variant also with the fused temporal QKV + attention kernel")
     ap.add_argument("--graph-ab", action="store_true", help="every variant also with eager (stream-ordered) launches instead of the captured graph")
     a = ap.parse_args()
-    lib = L.load_experiments()
+    lib = L.load() if a.product else L.load_experiments()
+    if a.product:
+        a.variants = [0]
+        lib.gtav_op_gemm_set_debug = lambda v: None
     import gtav_amd.weights as W
     from gtav_amd.generate import generate_latents
     from gtav_amd.model.dit import DiT_models
