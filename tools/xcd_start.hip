@@ -7,6 +7,15 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
+__global__ void probe_busy(int* out, int slot, int spin) {   // the same with work in every block: consecutive launches now overlap at their tails
+    if (threadIdx.x == 0 && blockIdx.x < 16) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        out[slot * 16 + blockIdx.x] = (int)(x & 15);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin * (1 + (blockIdx.x & 3))) __builtin_amdgcn_s_sleep(8);   // 100 MHz ticks; uneven block lengths
+}
 __global__ void probe(int* out, int slot) {
     if (threadIdx.x == 0 && blockIdx.x < 16) {
         unsigned x;
@@ -39,6 +48,20 @@ int main() {
     CK(hipGraphLaunch(ge, s));
     CK(hipStreamSynchronize(s));
     CK(hipMemcpy(h.data() + 2 * n * 16, d + n * 16, n * 16 * sizeof(int), hipMemcpyDeviceToHost));
+    {   // busy kernels back to back (5-20 us per block), stream-ordered: does block 0 still start on XCC 0?
+        CK(hipMemset(d, 0xFF, n * 16 * sizeof(int)));
+        for (int rep = 0; rep < 3; ++rep)
+            for (int i = 0; i < n; ++i) hipLaunchKernelGGL(probe_busy, dim3(grids[i]), dim3(256), 0, s, d, i, 500);
+        CK(hipStreamSynchronize(s));
+        std::vector<int> hb(n * 16);
+        CK(hipMemcpy(hb.data(), d, n * 16 * sizeof(int), hipMemcpyDeviceToHost));
+        printf("busy kernels back to back (third pass):\n");
+        for (int i = 0; i < n; ++i) {
+            printf("  grid %4d: xcc of blocks 0..7:", grids[i]);
+            for (int b = 0; b < 8 && b < grids[i]; ++b) printf(" %d", hb[i * 16 + b]);
+            printf("\n");
+        }
+    }
     const char* names[3] = {"stream launches", "graph replay 1", "graph replay 2"};
     for (int m = 0; m < 3; ++m) {
         printf("%s\n", names[m]);
