@@ -131,8 +131,9 @@ def test_gemm_qkv_temporal_layout():
     assert kv[:, :t0].abs().max().item() == 0  # untouched cache slots
 
 
-@pytest.mark.parametrize("M,N,K,act", [(5, 1024, 256, 1), (16, 6144, 1056, 0), (37, 192, 1024, 1)])
+@pytest.mark.parametrize("M,N,K,act", [(5, 1024, 256, 1), (16, 6144, 1056, 0), (37, 192, 1024, 1), (808, 6144, 1024, 0), (131, 320, 1024, 1)])
 def test_skinny_f32(M, N, K, act):
+    """(808 = the adaLN table rows of a batch-8 frame, 131 = a ragged last slab)"""
     x, w, b = _rand(M, K, seed=1), _rand(N, K, scale=1 / math.sqrt(K), seed=2), _rand(N, seed=3)
     y = torch.full((M, N), float("nan"), device=dev())
     xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())

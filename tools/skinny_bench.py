@@ -1,0 +1,20 @@
+"""The adaLN table launch of a generated frame (csrc/skinny.hip, fp32 MFMA; N = 198 656 modulation features, K = 1024) at 101 rows (batch 1: all noise steps of a frame)
+and 808 rows (batch 8).  Round 3: 32-row X slabs (half the re-streaming of W_ada) bought 3 % at 808 rows (11.3 -> 11.0 ms) — the launch is bound by the one
+LDS operand read per four MFMAs, not by the weight stream; not kept.  Usage (GPU box): python tools/skinny_bench.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gtav_amd import lib as L
+lib = L.load_experiments()
+dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
+N, K = 198656, 1024
+w = torch.randn(N, K, device=dev) * 0.03; b = torch.randn(N, device=dev)
+for M in (101, 808):
+    x = torch.randn(M, K, device=dev); y = torch.empty(M, N, device=dev)
+    run = lambda: L.check(lib.gtav_op_skinny_f32(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, N, K, 0, st))
+    for _ in range(2): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"adaLN table M={M}: {e0.elapsed_time(e1)/5:.3f} ms", flush=True)
