@@ -10,21 +10,25 @@ namespace gtav {
 
 namespace {
 
-// One block = 4 waves = 64 output features x one 16-row slab of X.
-template <int ACT>
+// One block = 4 waves x FT feature tiles of 16 = 64 FT output features x one slab of 16 RT rows of X.  A wave reads each X fragment from LDS once per 32 k and uses it
+// for its FT feature tiles; each W fragment comes straight from memory once and is used for the RT row tiles.  At tens of rows (FT = RT = 1) the launch is a weight
+// stream; at hundreds — the adaLN table of a batch-8 frame, 808 rows x 198 656 features — FT = RT = 1 was bound by the LDS read per four MFMAs (11.3 ms = 30 TFLOP/s),
+// FT = 4 by re-streaming W_ada once per 16 rows (7.2 ms = 5.9 TB/s out of L2 / Infinity Cache), hence 32-row slabs on top (tools/skinny_bench.py).  Per output the
+// same fp32 fma chain in the same order for every FT / RT.
+template <int ACT, int FT, int RT>
 __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                         int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [16][K + 8]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [16 RT][K + 8]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.y * 16;
-    const int n0 = blockIdx.x * 64 + w * 16;
+    const int m0 = blockIdx.y * 16 * RT;
+    const int n0 = (blockIdx.x * 4 + w) * 16 * FT;
     const int ldk = K + 8;
 
     // stage the X slab (rows beyond M are zero)
     const int kq = K >> 2;
-    for (int idx = tid; idx < 16 * kq; idx += 256) {
+    for (int idx = tid; idx < 16 * RT * kq; idx += 256) {
         const int r = idx / kq, c = idx - r * kq;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (m0 + r < M) v = *(const f32x4*)(X + (size_t)(m0 + r) * ldx + 4 * c);
@@ -33,45 +37,75 @@ __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict
     __syncthreads();
     if (n0 >= N) return;
 
-    int nrow = n0 + li;
-    nrow = nrow < N ? nrow : N - 1;
-    const float* wp = W + (size_t)nrow * K + 4 * g;
+    const float* wp[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        int nrow = n0 + 16 * f + li;
+        nrow = nrow < N ? nrow : N - 1;
+        wp[f] = W + (size_t)nrow * K + 4 * g;
+    }
     const float* xp = xs + li * ldk + 4 * g;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[FT][RT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // K % 32 == 0; each step covers 32 k: lane group g holds k = kb + 16 i + 4 g + e
-#pragma unroll 4
+#pragma unroll 2
     for (int kb = 0; kb < K; kb += 32) {
-        const f32x4 w0 = *(const f32x4*)(wp + kb);
-        const f32x4 w1 = *(const f32x4*)(wp + kb + 16);
-        const f32x4 x0 = *(const f32x4*)(xp + kb);
-        const f32x4 x1 = *(const f32x4*)(xp + kb + 16);
+        f32x4 x0[RT], x1[RT], w0[FT], w1[FT];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[e], x0[e], acc, 0, 0, 0);
+        for (int t = 0; t < RT; ++t) {
+            x0[t] = *(const f32x4*)(xp + (size_t)t * 16 * ldk + kb);
+            x1[t] = *(const f32x4*)(xp + (size_t)t * 16 * ldk + kb + 16);
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[e], x1[e], acc, 0, 0, 0);
+        for (int f = 0; f < FT; ++f) {
+            w0[f] = *(const f32x4*)(wp[f] + kb);
+            w1[f] = *(const f32x4*)(wp[f] + kb + 16);
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[f][e], x0[t][e], acc[f][t], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[f][e], x1[t][e], acc[f][t], 0, 0, 0);
+            }
     }
     // D[row = feature 4g + r][col = X row li]
-    const int m = m0 + li, n = n0 + 4 * g;
-    if (m < M && n < N) {
-        f32x4 v = acc;
-        if (bias) v = v + *(const f32x4*)(bias + n);
-        if (ACT == 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+    for (int t = 0; t < RT; ++t) {
+        const int m = m0 + 16 * t + li;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int n = n0 + 16 * f + 4 * g;
+            if (m < M && n < N) {
+                f32x4 v = acc[f][t];
+                if (bias) v = v + *(const f32x4*)(bias + n);
+                if (ACT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+                }
+                *(f32x4*)(Y + (size_t)m * ldy + n) = v;
+            }
         }
-        *(f32x4*)(Y + (size_t)m * ldy + n) = v;
     }
 }
 
 }  // namespace
 
+// (FT, RT) variants: (1, 1) small projections; (4, 1) many features, tens of rows (the adaLN table at batch 1); (4, 2) / (8, 2) hundreds of rows
+#define GTAV_SKINNY_VARIANTS(X) X(0, 1, 1) X(1, 1, 1) X(0, 4, 1) X(1, 4, 1) X(0, 4, 2) X(1, 4, 2) X(0, 8, 2)
 int skinny_init() {
     static unsigned long long done_devs = 0;   // the attribute is per device (see attention.hip)
     int devid = 0;
     GTAV_CHECK_HIP(hipGetDevice(&devid));
     if (done_devs >> (devid & 63) & 1) return 0;
-    GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define GTAV_SKINNY_ATTR(A, F, R) GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<A, F, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GTAV_SKINNY_VARIANTS(GTAV_SKINNY_ATTR)
+#undef GTAV_SKINNY_ATTR
     done_devs |= 1ull << (devid & 63);
     return 0;
 }
@@ -81,12 +115,28 @@ int launch_skinny_f32(const float* X, int ldx, const float* W, const float* bias
     GTAV_REQUIRE(M > 0 && N > 0 && N % 4 == 0, "skinny: bad M=%d N=%d", M, N);
     GTAV_REQUIRE(K > 0 && K % 32 == 0 && K <= 2048, "skinny: K=%d must be a multiple of 32 and <= 2048", K);
     GTAV_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= K && ldy >= N, "skinny: bad leading dims");
-    dim3 grid(cdiv(N, 64), cdiv(M, 16)), block(256);
-    const size_t lds = (size_t)16 * (K + 8) * sizeof(float);
-    if (act_silu)
-        hipLaunchKernelGGL(skinny_f32_kernel<1>, grid, block, lds, stream, X, ldx, W, bias, Y, ldy, M, N, K);
-    else
-        hipLaunchKernelGGL(skinny_f32_kernel<0>, grid, block, lds, stream, X, ldx, W, bias, Y, ldy, M, N, K);
+    // four (eight) feature tiles per wave where that still leaves the chip full, 32-row slabs as soon as there are two of them: the adaLN table of a frame
+    // 1.52 -> 0.92 ms at 101 rows (batch 1), 11.3 -> 5.0 ms at 808 rows (batch 8)
+    static const int ft_min_blocks = GTAV_ENV_INT("GTAV_SKINNY_FT_MIN_BLOCKS", 1024);   // experiments build: a huge value = one tile per wave everywhere (A/B)
+    static const int variant = GTAV_ENV_INT("GTAV_SKINNY_VARIANT", 0);                  // experiments build: 41 / 42 / 82 force (FT, RT)
+    int ft = 1, rt = 1;
+    if ((long long)cdiv(N, 256) * cdiv(M, 16) >= ft_min_blocks) {
+        ft = 4;
+        if (M > 32 && (size_t)32 * (K + 8) * sizeof(float) <= 150 * 1024) {
+            rt = 2;
+            if (!act_silu && (long long)cdiv(N, 512) * cdiv(M, 32) >= ft_min_blocks) ft = 8;
+        }
+    }
+    if (variant == 41) ft = 4, rt = 1;
+    if (variant == 42) ft = 4, rt = 2;
+    if (variant == 82 && !act_silu) ft = 8, rt = 2;
+    dim3 grid(cdiv(N, 64 * ft), cdiv(M, 16 * rt)), block(256);
+    const size_t lds = (size_t)16 * rt * (K + 8) * sizeof(float);
+#define GTAV_SKINNY_LAUNCH(A, F, R)                                                                                               \
+    if (act_silu == A && ft == F && rt == R) hipLaunchKernelGGL((skinny_f32_kernel<A, F, R>), grid, block, lds, stream, X, ldx, W, bias, Y, ldy, M, N, K);
+    act_silu = act_silu ? 1 : 0;
+    GTAV_SKINNY_VARIANTS(GTAV_SKINNY_LAUNCH)
+#undef GTAV_SKINNY_LAUNCH
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

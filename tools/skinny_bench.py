@@ -1,6 +1,6 @@
 """The adaLN table launch of a generated frame (csrc/skinny.hip, fp32 MFMA; N = 198 656 modulation features, K = 1024) at 101 rows (batch 1: all noise steps of a frame)
-and 808 rows (batch 8).  Round 3: 32-row X slabs (half the re-streaming of W_ada) bought 3 % at 808 rows (11.3 -> 11.0 ms) — the launch is bound by the one
-LDS operand read per four MFMAs, not by the weight stream; not kept.  Usage (GPU box): python tools/skinny_bench.py"""
+and 808 rows (batch 8).  Experiments build: GTAV_SKINNY_VARIANT=41 / 42 / 82 forces (feature tiles per wave, 16-row tiles per slab), GTAV_SKINNY_FT_MIN_BLOCKS=100000000 the
+round-2 kernel (1, 1).  Usage (GPU box): python tools/skinny_bench.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gtav_amd import lib as L
