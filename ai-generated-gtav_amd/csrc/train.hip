@@ -27,7 +27,8 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[16]*/) {
 // Tile-major transpose: src logical [R][C] (C % 64 == 0, rows padded to 128) -> dst logical [C][Rp], Rp = round_up(R, 64), rows of
 // dst padded to 128 by the caller's allocation; dst columns [R, Rp) are written as zeros (they are the K padding of the dW GEMM:
 // both operands must be zero there).  One block = one 64 x 64 sub-tile through LDS, 16-byte accesses on both sides.  (Four sub-tiles per block with every load
-// before the first store: 17.2 -> 18.7 us per launch, round 3 — the launch is bound by its sixteen 2-byte LDS reads per thread, not by latency.)
+// before the first store: 17.2 -> 18.7 us per launch; columns by the transposing LDS read ds_read_b64_tr_b16, which leaves a 16-lane group with 16 different
+// destination rows = scattered 16-byte stores: 22.6 us — round 3; the eight-lanes-per-128-byte-row store pattern of this form is what matters.)
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_tiled_kernel(const f16* __restrict__ src, int R, int C, f16* __restrict__ dst, int Rp) {
     __shared__ f16 t[64][72];              // [r][c], 144-byte pitch
