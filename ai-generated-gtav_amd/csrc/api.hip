@@ -472,7 +472,8 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // (Prefetching for to_qkv / fc1 from the LayerNorm launch right in front of them instead — 64 extra blocks beside its row blocks — gained nothing
     // for the consumers and made every LayerNorm 1.6 us longer: profiles/round3/*prefetch_from_layernorm_vs_from_gemm.txt.  The issuing GEMM pays
     // 0.6-0.9 us for its prefetch, the consumer gains 1.5-2 us.)
-    const bool pf_on = h->w_prefetch && M >= 512 && M <= pf_max_m;
+    static const int pf_min_m = GTAV_ENV_INT("GTAV_PF_MIN_M", 256);   // 320 tokens (window step of the 256 x 256-frame preset): -2.1 %; 144 (cached step): +1.5 %; experiments build: A/B
+    const bool pf_on = h->w_prefetch && M >= pf_min_m && M <= pf_max_m;
     auto set_pf = [&](GemmParams& q, const f16* Wn, int Nn, int Kn, int skn) {
         if (!pf_on || !Wn) return;
         const int nkt = Kn / 64;

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--cached", action="store_true")
     ap.add_argument("--actions", action="store_true")
+    ap.add_argument("--g256", action="store_true", help="the 256x256-frame preset: 16x16 latents, 64 tokens per frame (M = 320 per window step)")
     ap.add_argument("--product", action="store_true", help="the product library (no debug bits: one variant) instead of the experiments build")
     ap.add_argument("--fused-ab", action="store_true", help="every variant also with the fused temporal QKV + attention kernel")
     ap.add_argument("--graph-ab", action="store_true", help="every variant also with eager (stream-ordered) launches instead of the captured graph")
@@ -31,14 +32,16 @@ def main():
         lib.gtav_op_gemm_set_debug = lambda v: None
     import gtav_amd.weights as W
     from gtav_amd.generate import generate_latents
-    from gtav_amd.model.dit import DiT_models
+    from gtav_amd.model.dit import DiT, DiT_models
     dev = torch.device("cuda", 0)
     B = a.batch
-    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    gkw = dict(input_h=16, input_w=16, patch_size=2, in_channels=16, hidden_size=1024, depth=16, num_heads=16, external_cond_dim=25)
+    sd = W.synth_state_dict(W.dit_param_shapes(**gkw) if a.g256 else W.dit_param_shapes(depth=16), seed=0)
+    lat = (16, 16) if a.g256 else (18, 32)
     g = torch.Generator().manual_seed(3)
     n_prompt, total = 4, 4 + a.frames
-    x0 = torch.randn(B, n_prompt, 16, 18, 32, generator=g) * 0.5
-    nz = torch.randn(B, total - n_prompt, 16, 18, 32, generator=g)
+    x0 = torch.randn(B, n_prompt, 16, *lat, generator=g) * 0.5
+    nz = torch.randn(B, total - n_prompt, 16, *lat, generator=g)
     act = None
     if a.actions:
         act = torch.zeros(B, total, 25)
@@ -47,7 +50,7 @@ def main():
     for v in a.variants:
         for graph in ((True, False) if a.graph_ab else ((True, "fused") if a.fused_ab else (True,))):
             lib.gtav_op_gemm_set_debug(v)
-            m = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+            m = DiT(**gkw, init_weights=False, max_batch=B) if a.g256 else DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
             m.load_state_dict(sd)
             if graph == "fused":
                 m.set_fused_temporal(True)
