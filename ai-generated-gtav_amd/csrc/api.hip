@@ -486,7 +486,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
         set_pf(q, Wn, Nn, Kn, 1);
         q.splitk = gemm_choose_splitk(M, D, K);
-        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || (!h->tr.on && gemm_resid_inplace_ok(M, D, K))) {
+        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || (!h->tr.on && gemm_resid_inplace_ok(M, D, K, P))) {
             // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
             // read-modify-write hides under the other wave group's main loop, and without split-K slabs the next LayerNorm only
             // reads resid.  (With the one-shot kernels the same epilogue was a loss: B = 8 out-proj 0.77 -> 1.26 ms per forward;
@@ -1099,7 +1099,10 @@ int gtav_dit_set_grad_divisor(gtav_dit* h, float divisor) {
 int gtav_dit_zero_grad(gtav_dit* h, void* stream) {
     GTAV_REQUIRE(h && h->tr.on, "zero_grad: training is not enabled");
     // (hipMemsetAsync splits 2.4 GB into ~600 fill launches of 4 MB: 3.8 ms per step in the rocprofv3 trace; one grid-stride kernel: 0.5 ms)
-    return launch_fill_f32(h->tr.grad_arena, h->tr.grad_count, 0.f, (hipStream_t)stream);
+    RET_IF(launch_fill_f32(h->tr.grad_arena, h->tr.grad_count, 0.f, (hipStream_t)stream));
+    // a training step starts here: saturation / non-finite bits raised by an earlier forward on this handle (validation, predict) are not this step's
+    // overflow — clear them so that only the step's own stores can make the optimizer skip (gtav_dit_check reports inference saturation before that)
+    return launch_err_clear(h->err_flag, ERR_F16_SAT | ERR_NONFINITE, (hipStream_t)stream);
 }
 
 // raw (loss-scaled) gradient of one parameter, torch layout; the caller divides by the loss scale
@@ -1352,6 +1355,9 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     RET_IF(launch_silu_bwd(tr.dh0, D, tr.z0, D, tr.dz0, D, rows, D, s));
     RET_IF(launch_colsum_f32(tr.dz0, D, rows, D, slot("t_embedder.mlp.0.bias").grad, tr.red_ws, s));
     RET_IF(launch_gemm_tn_f32(tr.dz0, D, h->E, 256, rows, D, 256, slot("t_embedder.mlp.0.weight").grad, 256, s));
+    // Last kernel of the backward pass: a saturated / non-finite fp16 store on THIS rank becomes +inf in the embedder bucket (the one the data-parallel
+    // harness all-reduces last, train.gradient_buckets), so the skip decision of the optimizer step is the same on every rank (ops.h)
+    RET_IF(launch_overflow_publish(h->err_flag, slot("x_embedder.proj.bias").grad, s));
     return 0;
 }
 
@@ -1848,7 +1854,7 @@ int gtav_op_rope_interleave(const float* cos_t, const float* sin_t, float* cs, i
     return launch_rope_interleave(cos_t, sin_t, cs, npos, (hipStream_t)stream);
 }
 int gtav_op_gemm_choose_splitk(int32_t M, int32_t N, int32_t K) { return gemm_choose_splitk(M, N, K); }
-int gtav_op_gemm_resid_inplace(int32_t M, int32_t N, int32_t K) { return gemm_resid_inplace_ok(M, N, K) ? 1 : 0; }
+int gtav_op_gemm_resid_inplace(int32_t M, int32_t N, int32_t K) { return gemm_resid_inplace_ok(M, N, K, 0) ? 1 : 0; }
 void gtav_op_gemm_set_stages(int32_t ns) { gemm_set_stages(ns); }
 #ifdef GTAV_EXPERIMENTS
 void gtav_op_gemm_set_debug(int32_t bits) { gemm_set_debug(bits); }   // libgtav_amd_exp.so only (csrc/experiments.h)

@@ -20,7 +20,7 @@ enum GemmEpi : int {
     // ---- LayerNorm fold: the LayerNorm + adaLN modulate between a residual GEMM and the GEMM that consumes its
     // output is split over the two epilogues instead of being a launch of its own (model/dit.py:19-27,200-225) ----
     EPI_RESID_FOLD = 8,      // producer (out-proj, fc2; full K): x = resid[m][n] += gate (acc + bias) in place, AND the next GEMM's operand
-                             // A[m][n] = fp16(x (1 + scale_next + 1e-6)) tile-major, AND per-row partial sums (sum x, sum x^2) per 32-feature slot
+                             // A[m][n] = fp16(x (1 + scale_next + 1e-6)) tile-major, AND per-row partial sums (sum x, sum x^2) per 64-feature slot
     EPI_QKV_FOLD = 9,        // consumers: X = A; y = (acc - mean c1[frame][n]) rstd + c2[frame][n], then as EPI_QKV / EPI_GELU_TANH / EPI_F32
     EPI_GELU_TANH_FOLD = 10, //   with mean / rstd from the producer's partial sums and c1 = sum_k (1 + scale_k) W[n][k],
     EPI_F32_FOLD = 11,       //   c2 = sum_k shift_k W[n][k] + bias[n] from the per-frame tables (gemm_grouped: one launch per forward)
@@ -74,13 +74,13 @@ struct GemmParams {
     int f_P;
     const int* f_rows;
     // consumer (EPI_*_FOLD)
-    const float* f_stats;   // [M][f_nslot][2]: (sum x, sum x^2) over features 32 s .. 32 s + 31 of row m, written by the producer
-    int f_nslot;            // K / 32 (a multiple of 8)
+    const float* f_stats;   // [M][f_nslot][2]: (sum x, sum x^2) over features 64 s .. 64 s + 63 of row m, written by the producer
+    int f_nslot;            // K / 64 (a multiple of 4)
     const float* f_c1;      // row r at f_c1 + r * f_ldc: [N]
     const float* f_c2;
     int f_ldc;
     // producer (EPI_RESID_FOLD): out = resid, gate / gate_stride as EPI_RESID (rows by f_P / f_rows)
-    float* f_stats_out;     // [M][N / 32][2]
+    float* f_stats_out;     // [M][N / 64][2]
     const float* f_scale;   // scale vectors of the NEXT LayerNorm: row r at f_scale + r * gate_stride
     f16* f_a;               // tile-major [round_up(M, 128)][N]
     // ---- L2 prefetch of the NEXT GEMM's weight by the compute waves of the loader-wave kernels at small M (common.h PrefetchDesc) ----
@@ -117,7 +117,7 @@ int launch_gemm_tn(const GemmParams& p, hipStream_t stream);
 bool gemm_pp_ok(int M, int N, int K, int epi);
 // True when launch_gemm runs a residual GEMM of this shape on the persistent loader-wave kernel (shape 31, large M), whose in-place gated residual epilogue
 // (EPI_RESID: the residual tile is requested at the head of the tile's K loop) replaces slab + LayerNorm reduction.
-bool gemm_resid_inplace_ok(int M, int N, int K);
+bool gemm_resid_inplace_ok(int M, int N, int K, int rows_per_gate);
 // Split-K factor used for a residual GEMM of this shape (1 = no split): fills the 256 CUs when M is small.
 int gemm_choose_splitk(int M, int N, int K);
 // Pipeline depth override for experiments (0 = heuristic, else 2 or 4 LDS stages).

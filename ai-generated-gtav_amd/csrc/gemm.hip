@@ -677,7 +677,7 @@ __device__ __forceinline__ void tile_map_fast(const GemmParams& p, int& n0, int&
 // the LayerNorm would have normalised (f = frame of token m), so with mean / rstd of the row and the per-frame tables
 //   c1[f][n] = sum_k (1 + scale[f][k]) W[n][k],   c2[f][n] = sum_k shift[f][k] W[n][k] + bias[n]
 // the GEMM of the modulated LayerNorm output is   y[m][n] = (acc[m][n] - mean_m c1[f][n]) rstd_m + c2[f][n]   (model/dit.py:19-27).
-// mean / rstd come from the producer's partial sums (sum x, sum x^2) per 32-feature slot: lane (li, g) adds quarter g of its token's
+// mean / rstd come from the producer's partial sums (sum x, sum x^2) per 64-feature slot: lane (li, g) adds quarter g of its token's
 // slots in slot order, two xor-shuffles combine the quarters — ONE fixed order for every consumer block of that row.
 // A wave's 16-token groups never straddle a frame (f_P % 16 == 0, tiles start on multiples of 16).  The c1 / c2 slices of the block tile
 // — TNB features of the (at most FOLD_NFR) frames its tokens belong to — are staged in LDS once per block (fold_stage_tables, behind the
@@ -1889,7 +1889,7 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
             fold_prefetch<TNB, TM, FJ>(p, n0, m0, (int)threadIdx.x - 64 * NL, __builtin_amdgcn_readfirstlane(m0 + 16 * FJ * (cw / WN)), cw >= 0, ft);
         }
     };
-    if constexpr (EPI == EPI_QKV && FI * FJ <= 6) {   // small wave tiles: the RoPE values of the epilogue are fetched before the main loop (24 registers)
+    if constexpr (EPI == EPI_QKV && FI * FJ <= 6 && WN * WM + NL <= 12) {   // small wave tiles: the RoPE values of the epilogue are fetched before the main loop (24 registers; not at the 128-register budget of the 16-wave block)
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
         f32x4 prope[FI][FJ];
         auto pfq = [&]() {
@@ -2642,7 +2642,11 @@ void gemm_set_stamps(unsigned long long* buf, int max_blocks) { g_stamps = buf; 
 static int g_lp_enable = GTAV_ENV_INT("GTAV_LP", 1);   // experiments build: 0 = round-2 selection, for A/B runs
 static int g_resid_inplace = GTAV_ENV_INT("GTAV_RESID_INPLACE", 1);   // experiments build: 0 = slab + LayerNorm reduction at every M (A/B runs)
 static bool lp_takes(int M, int N, int K) { return g_lp_enable && N <= 2048 && N % 8 == 0 && K >= 512 && cdiv(M, 192) * cdiv(N, 128) >= 160; }
-bool gemm_resid_inplace_ok(int M, int N, int K) { return g_resid_inplace && lp_takes(M, N, K); }
+// (rows_per_gate: tokens per gate vector — the persistent kernel stages at most LP_MAXF gate rows per 192-token tile; 0 = no gate.  A forced block shape
+// other than 31 (tests) runs the one-shot kernels, where the in-place epilogue was measured slower than slab + LayerNorm: keep the slabs then.)
+bool gemm_resid_inplace_ok(int M, int N, int K, int rows_per_gate) {
+    return g_resid_inplace && lp_takes(M, N, K) && (rows_per_gate == 0 || rows_per_gate >= 32) && (g_force_wm == 0 || g_force_wm == 31);
+}
 int gemm_choose_splitk(int M, int N, int K) {
     if (lp_takes(M, N, K)) return 1;
 #ifdef GTAV_EXPERIMENTS
@@ -2860,6 +2864,9 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
         }
     }
     if constexpr (!FOLDISH) {
+    // 128 x 144 (nine 16-token groups: one 144-token frame per row tile), 12 compute waves of 32 x 48 + 4 loader waves (round 4): M = 1152, the context-cached
+    // step at batch 8, is 8 x 32 = 256 tiles for fc1 / 4-slice fc2 where the 128 x 128 grid has 288 (1.1 rounds)
+    if (shape == 29) return launch_l<EPI, 4, 2, 3, 4, 3, 4>(p, splitk, stream);
 #ifdef GTAV_EXPERIMENTS
     // measured slower than the shapes the heuristic picks: kept for A/B runs in the experiments build only
     if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
@@ -3133,6 +3140,14 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         if (wm == 11) wm = 24;
         else if (wm == 14 && !(epi_x == EPI_PARTIAL && splitk >= 8)) wm = 26;
     }
+    // Round 4: a little over a thousand tokens (M = 1152: the context-cached step at batch 8) sits between the small-M tiles (128 x 96: 12 row tiles, 1.1-1.5
+    // rounds of one-block-per-CU tiles) and the large-M ones (128 x 128, two blocks per CU: 216-288 blocks on 512 slots).  128 x 144 tiles on the loader-wave
+    // kernel (shape 29) are one round there: to_qkv 192, fc1 256, four-slice fc2 256 tiles (profiles/round4/step_B8_cached_*.json: to_qkv 14.9, fc1 18.5, fc2 19.7 us before).
+    bool frame_tile = false;
+    if (!g_force_wm && !foldish && !(g_debug & 64)) {
+        const int t29 = cdiv(p.M, 144) * cdiv(p.N, 128) * splitk, t20 = cdiv(p.M, 96) * cdiv(p.N, 128) * splitk;
+        if (t29 > 128 && t29 <= 256 && t20 > 256 && blocks128 <= 320) wm = 29, frame_tile = true;
+    }
     if (!g_force_wm && wm == 2 && cdiv(p.M, 192) * cdiv(p.N, 128) * splitk >= 320) {
         // large M: 128 x 192 tiles (4 waves of 64 x 96, still two blocks per CU) move 17 % fewer fill bytes per FLOP than
         // 128 x 128: QKV 62.6 -> 55.5 us, fc1 63.8 -> 61.1 us at M = 5760 (profiles/round1/v17_gemm_128x192_microbench.txt);
@@ -3145,13 +3160,13 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     // M = 2880 out-proj 13.7 -> 11.4 us, fc2 34.6 -> 27.9 us (shape 13, two K slices) — profiles/round3/gemm_shapes_*.txt.  The LayerNorm-fold
     // producer takes the larger tile whenever its grid is more than half full (27.2 us against 33.5 us at M = 5760).
     bool narrow_pick = false;
-    if (!g_force_wm && blocks128 > 256 && p.N <= 2048 && epi != EPI_QKV) {
+    if (!g_force_wm && !frame_tile && blocks128 > 256 && p.N <= 2048 && epi != EPI_QKV) {
         const int t12 = cdiv(p.M, 192) * cdiv(p.N, 128) * splitk, t13 = cdiv(p.M, 96) * cdiv(p.N, 128) * splitk;
         if (t12 > 256 && t12 <= 512) wm = 12, narrow_pick = true;
         else if (t13 > 256 && t13 <= 512 && !fold_p) wm = 13, narrow_pick = true;
         else if (fold_p && t12 > 128) wm = 12, narrow_pick = true;
     }
-    if (!g_force_wm && (epi_x == EPI_PARTIAL || (epi_x == EPI_RESID && (!p.gate || p.rows_per_gate >= 32))) && splitk == 1 && lp_takes(p.M, p.N, p.K)) wm = 31, narrow_pick = true;
+    if (!g_force_wm && splitk == 1 && ((epi_x == EPI_PARTIAL && lp_takes(p.M, p.N, p.K)) || (epi_x == EPI_RESID && gemm_resid_inplace_ok(p.M, p.N, p.K, p.gate ? p.rows_per_gate : 0)))) wm = 31, narrow_pick = true;
 #ifdef GTAV_EXPERIMENTS
     if (!g_force_wm && epi_x == EPI_GELU_TANH && (g_debug & 0x600000) && cdiv(p.M, 128) * cdiv(p.N, 256) >= 512) wm = (g_debug & 0x200000) ? 33 : 32;   // A/B of the persistent 128 x 256 / 256 x 128 tiles for fc1 (debug bits 21 / 22)
 #endif

@@ -188,6 +188,12 @@ int sumsq_parts(size_t n);                                                      
 int launch_sumsq(const float* g, size_t n, float* part, hipStream_t stream);
 // adds the partial sums in order (ctl[0]); err_flag (optional): ERR_F16_SAT / ERR_NONFINITE in the handle's error word count as overflow
 // (step skipped) and are cleared
+// Data-parallel training: the overflow decision of the optimizer step must be the SAME on every rank.  A rank whose fp16 gradient stores saturated
+// (ERR_F16_SAT / ERR_NONFINITE in its error word) writes +inf into one element `g` of its gradient arena at the end of its backward pass, before the
+// gradient all-reduce (SUM): every rank then sees a non-finite norm and skips the step (train.hip clip_coef_kernel).
+int launch_overflow_publish(const int* err_flag, float* g, hipStream_t stream);
+// clears `bits` of the device error word (stream-ordered)
+int launch_err_clear(int* err_flag, int bits, hipStream_t stream);
 int launch_clip_coef(float* ctl, const float* part, int nparts, float inv_scale, float max_norm, float beta1, float beta2, int* err_flag, hipStream_t stream);
 int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, float* v, const float* ctl, float lr, float beta1, float beta2, float eps,
                  float wd, hipStream_t stream);

@@ -844,10 +844,11 @@ __global__ void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const
 }
 // The adaLN projection mod = SiLU(c) W_ada^T + b_ada with W_ada [MODW][D] (MODW ~ 2 x 10^5): dSc[r][n] = sum_k dmod[r][k] W_ada[k][n].
 // Block = (256 features n) x (a chunk of KC rows k of W_ada), up to ADA_RB conditioning rows per pass in registers; W_ada is read once
-// per pass (0.8 GB at full size), partial sums leave by atomics into the zeroed dSc.
+// per pass (0.8 GB at full size); the partial sums of chunk c are STORED to part[c][r][n] and ada_reduce_kernel adds the chunks in a fixed order
+// (round 4: this fallback added them with float atomics — the one place left where the step was not bit-reproducible).
 constexpr int ADA_RB = 40;   // conditioning rows per pass (registers): the training batch of 16 x 5 rows takes two passes over W_ada
 __global__ __launch_bounds__(256) void ada_bwd_dx_kernel(const float* __restrict__ dmod, int MODW, const float* __restrict__ W, int D, int R, int KC,
-                                                         float* __restrict__ dSc) {
+                                                         float* __restrict__ part) {
     __shared__ float sd[ADA_RB][256];
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int k0 = blockIdx.y * KC, k1 = min(MODW, k0 + KC);
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(256) void ada_bwd_dx_kernel(const float* __restrict
         if (n < D)
 #pragma unroll
             for (int i = 0; i < ADA_RB; ++i)
-                if (rb + i < R) atomicAdd(dSc + (size_t)(rb + i) * D + n, acc[i]);
+                if (rb + i < R) part[((size_t)blockIdx.y * R + rb + i) * D + n] = acc[i];
     }
 }
 // dSc on the fp32 matrix cores.  One block of D / 64 waves per chunk of 1024 rows k of W_ada: W_ada is read ONCE (the VALU kernel
@@ -943,6 +944,9 @@ __global__ void ada_reduce_kernel(const float* __restrict__ part, int nchunk, si
 //   the step is skipped and ctl[2] counts it).  Overflow = a non-finite norm OR the handle's error word carrying ERR_F16_SAT /
 //   ERR_NONFINITE: every fp16 gradient / activation store saturates to +-65504 and raises that bit, so at a too-large loss scale the
 //   norm itself stays finite — the bit is what says the gradients are clipped garbage.  The bits are cleared here (consumed).
+//   Data-parallel: the bit is per rank, so the backward pass ends by turning it into +inf in one element of the rank's gradient arena
+//   (overflow_publish_kernel, in the bucket that is all-reduced last): after the all-reduce EVERY rank's norm is non-finite and every rank skips —
+//   weights, moments and the Adam step count cannot drift apart between replicas (round 3 tested the bit locally only: ADVICE r3).
 //   ctl[4] = number of APPLIED steps (the Adam step count t: a skipped step does not advance it), ctl[5] / ctl[6] = the bias
 //   corrections 1 - beta1^t / 1 - beta2^t of the step being applied, computed here on the device so that m / v and t stay in step.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1264,9 +1268,13 @@ int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R,
         const size_t n = (size_t)R * D;
         hipLaunchKernelGGL(ada_reduce_kernel, dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, stream, part, nchunk, n, dSc);
     } else {
-        GTAV_CHECK_HIP(hipMemsetAsync(dSc, 0, (size_t)R * D * sizeof(float), stream));
-        const int KC = 2048;
-        hipLaunchKernelGGL(ada_bwd_dx_kernel, dim3(cdiv(D, 256), cdiv(MODW, KC)), dim3(256), 0, stream, dmod, MODW, W, D, R, KC, dSc);
+        // shapes the matrix-core kernel does not take (hidden % 64 != 0, more than 80 conditioning rows): the VALU kernel, same fixed-order reduction
+        GTAV_REQUIRE(part, "ada_bwd_dx: needs its partial-sum workspace (ada_bwd_dx_workspace)");
+        const int KC = 2048, nchunk = cdiv(MODW, KC);    // (<= cdiv(MODW, ADA_KC) chunks: the workspace covers it)
+        hipLaunchKernelGGL(ada_bwd_dx_kernel, dim3(cdiv(D, 256), nchunk), dim3(256), 0, stream, dmod, MODW, W, D, R, KC, part);
+        GTAV_CHECK_HIP(hipGetLastError());
+        const size_t n = (size_t)R * D;
+        hipLaunchKernelGGL(ada_reduce_kernel, dim3((unsigned)cdiv((long long)n, 256)), dim3(256), 0, stream, part, nchunk, n, dSc);
     }
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1274,6 +1282,22 @@ int launch_ada_bwd_dx(const float* dmod, int MODW, const float* W, int D, int R,
 int sumsq_parts(size_t n) { return grid_for(n, 256 * 8); }
 int launch_sumsq(const float* g, size_t n, float* part, hipStream_t stream) {
     hipLaunchKernelGGL(sumsq_kernel, dim3(sumsq_parts(n)), dim3(256), 0, stream, g, n, part);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void overflow_publish_kernel(const int* __restrict__ err_flag, float* __restrict__ g) {
+    if (*err_flag & (ERR_F16_SAT | ERR_NONFINITE)) *g = __builtin_inff();
+}
+__global__ void err_clear_kernel(int* err_flag, int bits) { atomicAnd(err_flag, ~bits); }
+int launch_err_clear(int* err_flag, int bits, hipStream_t stream) {
+    if (!err_flag) return 0;
+    hipLaunchKernelGGL(err_clear_kernel, dim3(1), dim3(1), 0, stream, err_flag, bits);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_overflow_publish(const int* err_flag, float* g, hipStream_t stream) {
+    if (!err_flag || !g) return 0;
+    hipLaunchKernelGGL(overflow_publish_kernel, dim3(1), dim3(1), 0, stream, err_flag, g);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -298,7 +298,12 @@ class LossScaler:
         self.min_scale, self.max_scale = float(min_scale), float(max_scale)
         self._calls = 0
         self._clean = 0
-        self._skipped_seen = None
+        # the counter's value when this scaler starts watching (a resumed run restores it from the checkpoint); a handle that is not built yet
+        # gives it on the first update instead
+        try:
+            self._skipped_seen = int(dit.train_stats()[1]) if getattr(dit, "_handle", None) else None
+        except Exception:
+            self._skipped_seen = None
 
     def update(self) -> float:
         """Call once per optimisation step (after adamw_step).  Returns the loss scale the NEXT step will use."""
@@ -307,7 +312,10 @@ class LossScaler:
             return self.dit.loss_scale
         _, skipped, _ = self.dit.train_stats()
         if self._skipped_seen is None:
-            self._skipped_seen = 0
+            # first look at the counter: a resumed run restores it from the checkpoint (set_opt_step) — steps skipped BEFORE this scaler existed
+            # say nothing about the restored loss scale
+            self._skipped_seen = skipped
+            return self.dit.loss_scale
         if skipped > self._skipped_seen:
             self.dit.loss_scale = max(self.min_scale, self.dit.loss_scale * 0.5)
             self._clean = 0

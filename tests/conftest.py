@@ -17,8 +17,7 @@ def pytest_configure(config):
 def _built_library():
     """The HIP library is built in-tree (hipcc cross-compiles gfx950 without a GPU); tests never run on a fallback."""
     from gtav_amd import lib as L
-    if not os.path.exists(L.LIB_PATH):
-        L.build()
+    L.build()          # mtime-aware (lib.build): a stale in-tree .so — they are git-ignored but travel to the GPU box — is rebuilt, a current one is kept
     L.load()
 
 

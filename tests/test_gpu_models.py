@@ -19,7 +19,7 @@ from gtav_amd.model.vae import AutoencoderKL, VAE_models  # noqa: E402
 
 TOL_FULL = 1e-3      # north-star bound: full-size DiT / VAE forwards vs the fp32 CPU reference
 TOL_SMALL = 2e-3     # toy widths (hidden 128-256): fewer terms per dot product average the fp16 operand rounding less
-TOL_ROLLOUT = 3e-3   # tens of chained forwards (toy and full-size models; measured <= 7e-4, pytest -s prints every margin)
+TOL_ROLLOUT = 1.5e-3   # tens of chained forwards (toy and full-size models; measured <= 7e-4, pytest -s prints every margin)
 
 
 def rel_l2(a, b):
@@ -528,6 +528,21 @@ def test_full_dit_batch8_production_shapes():
     print("full DiT B=8 T=5 (M=5760) rel-L2", e)
     assert e < 1e-3
     m.check()
+    # the context-cached sampler step of the same batch (M = 8 x 144 = 1152 tokens: the 128 x 144 frame tiles of round 4) reproduces the
+    # window step on the frame being denoised; generate.py:200-220 is the loop both run
+    from gtav_amd.utils import alphas_cumprod
+    m.set_schedule(alphas_cumprod(1e-4))
+    ad = a.to(dev())
+    xd = x.to(dev()).contiguous()
+    m.denoise_step_(xd, 0, 4, 15, 500, 490, False, ad)
+    xc = x.to(dev()).contiguous()
+    m.denoise_step_(xc, 0, 4, 15, 500, 490, False, ad)
+    xc[:, -1] = x[:, -1].to(dev())
+    m.denoise_step_(xc, 0, 4, 15, 500, 490, False, ad, cached=True)
+    ec = rel_l2(xc[:, -1], xd[:, -1])
+    print("full DiT B=8 cached step (M=1152) vs window step rel-L2", ec)
+    assert ec < 1e-4      # (same kernels; the K slices of the residual GEMMs differ between the two token counts: fp32 summation order, measured 1.4e-5)
+    m.check()
 
 
 def test_full_dit_batch16_train_forward_loss():
@@ -715,8 +730,9 @@ def test_config0_production_size_vs_reference_golden(full_dit, full_vae):
     print(f"config0 full size: encode {e_enc:.2e} latents {e_lat:.2e} (cached vs window {rel_l2(lat_c, lat):.1e}) frames {e_img:.2e} "
           f"(max |err| {dmax:.3f} of 255); {int((diff > 0).sum())} of {diff.numel()} bytes differ, max {int(diff.max())}")
     # 33 chained full-size forwards: per-forward error 6-9e-4 (TOL_FULL), accumulated over the rollout
-    assert e_enc < TOL_FULL and e_lat < 5e-3 and e_img < 5e-3 and rel_l2(lat_c, lat) < 1e-4
-    assert diff.max().item() <= 2 and int((diff > 0).sum()) < 0.3 * diff.numel()
+    # (measured: latents 3.7e-4, frames 4.5e-4, byte differences of at most 1 — profiles/round3/test_margins_pytest_s.txt)
+    assert e_enc < TOL_FULL and e_lat < 1.5e-3 and e_img < 1.5e-3 and rel_l2(lat_c, lat) < 1e-4
+    assert diff.max().item() <= 1 and int((diff > 0).sum()) < 0.3 * diff.numel()
 
 
 def test_full_size_checkpoint_in_the_reference_writers_convention(tmp_path, full_dit):

@@ -437,7 +437,7 @@ def test_gemm_8wave_tile_matches(M, N, K):
         lib.gtav_op_gemm_set_stages(0)
 
 
-@pytest.mark.parametrize("shape", [7, 11, 12, 13, 14, 20, 24, 26])
+@pytest.mark.parametrize("shape", [7, 11, 12, 13, 14, 20, 24, 26, 29])
 def test_gemm_other_tiles_all_epilogues(shape):
     """Block shapes 7 (256 x 256, phased K-tile, mainloop256), 11 / 14 (64 x 48, 64 x 96), 12 (128 x 192; piece-granular mainloop_g) and
     20 (128 x 96 loader-wave kernel) through every epilogue they support, incl. ragged token and feature edges, K of one and two tiles
@@ -447,7 +447,7 @@ def test_gemm_other_tiles_all_epilogues(shape):
     try:
         lib.gtav_op_gemm_set_wm(shape)
         for (M, N, K) in ((5760, 1024, 1024), (700, 384, 192), (256, 128, 64), (1300, 256, 4096), (513, 512, 128), (100, 768, 320),
-                          (720, 3072, 1024), (96, 96, 64), (97, 100, 128)):
+                          (720, 3072, 1024), (96, 96, 64), (97, 100, 128), (1152, 4096, 1024), (1000, 384, 256)):
             x = _rand(M, K, seed=1).half()
             w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
             b = _rand(N, seed=3)

@@ -438,7 +438,9 @@ def test_fp16_saturation_skips_the_step_and_loss_scaler_backs_off():
     m.loss_scale = 2.0 ** 40
     training_step(m, lat, a5, tgt, ctx, cn, nz, lr=1e-3)
     applied, skipped, gnorm = m.train_stats()
-    assert not applied and skipped == 1 and math.isfinite(gnorm)
+    # (round 4: the backward pass turns the saturation bit into +inf in one gradient element — the form every data-parallel rank sees after the
+    # all-reduce — so the reported norm of an overflowed step is inf)
+    assert not applied and skipped == 1 and math.isinf(gnorm)
     assert int(m.opt_state_dict()["step"][0]) == 0                      # the Adam step count did not advance
     m.pull_weights()
     assert torch.equal(m._sd["blocks.0.s_mlp.fc1.weight"], sd["blocks.0.s_mlp.fc1.weight"])
@@ -451,6 +453,52 @@ def test_fp16_saturation_skips_the_step_and_loss_scaler_backs_off():
             break
     assert m.train_stats()[0] and m.loss_scale < 2.0 ** 40
     assert int(m.opt_state_dict()["step"][0]) >= 1
+
+
+def test_overflow_on_one_rank_skips_the_step_on_every_rank():
+    """the skip decision of the optimizer step must be global.  Two data-parallel replicas emulated in one process (two handles,
+    identical weights, the all-reduce SUM done by hand on the two gradient arenas): only replica A's inputs saturate its fp16 gradient stores.
+    Its backward pass publishes the overflow as +inf in its arena, so after the "all-reduce" BOTH replicas see a non-finite norm and skip: weights
+    bit-equal afterwards, Adam step counts equal, both skip counters 1.  (Round 3 tested the saturation bit per rank: A skipped, B stepped.)"""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT
+    from gtav_amd.train import forward_loss
+    lat, a5, tgt, ctx, cn, nz = _step_inputs()
+    sd = W.synth_state_dict(W.dit_param_shapes(**KW), seed=1)
+    reps = []
+    for _ in range(2):
+        m = DiT(**KW, max_batch=2, max_frames=5, init_weights=False, trainable=True)
+        m.load_state_dict(sd)
+        reps.append(m)
+    lats = [lat * 3e4, lat]            # replica A: latents far outside the fp16 range of the activation gradients at the default loss scale
+    for m, l in zip(reps, lats):
+        m.zero_grad()
+        forward_loss(m, l, a5, tgt, ctx, cn, nz, keep_activations=True, on_frame=lambda k, vp, vt, m=m: m.backward_(vp, vt))
+    total = reps[0].grad_arena + reps[1].grad_arena          # what ncclAllReduce(SUM) leaves on every rank
+    assert not torch.isfinite(total).all() and torch.isfinite(reps[1].grad_arena).all()
+    for m in reps:
+        m.grad_arena.copy_(total)
+        m.grad_divisor = 2.0
+        m.adamw_step(1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    stats = [m.train_stats() for m in reps]
+    assert [bool(s[0]) for s in stats] == [False, False] and [s[1] for s in stats] == [1, 1]
+    for m in reps:
+        m.pull_weights()
+    for k in reps[0]._sd:
+        assert torch.equal(reps[0]._sd[k], reps[1]._sd[k]), k
+    assert int(reps[0].opt_state_dict()["step"][0]) == int(reps[1].opt_state_dict()["step"][0]) == 0
+    # and a clean step afterwards applies on both, identically
+    for m in reps:
+        m.zero_grad()
+        forward_loss(m, lat, a5, tgt, ctx, cn, nz, keep_activations=True, on_frame=lambda k, vp, vt, m=m: m.backward_(vp, vt))
+    total = reps[0].grad_arena + reps[1].grad_arena
+    for m in reps:
+        m.grad_arena.copy_(total)
+        m.adamw_step(1e-3, weight_decay=0.01, max_grad_norm=1.0)
+        m.pull_weights()
+    assert all(m.train_stats()[0] for m in reps)
+    for k in reps[0]._sd:
+        assert torch.equal(reps[0]._sd[k], reps[1]._sd[k]), k
 
 
 def test_frame_loop_three_target_frames_vs_reference_fixture_g10():
