@@ -917,6 +917,17 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable) {
     return 0;
 }
 
+int gtav_dit_set_weight_prefetch(gtav_dit* h, int32_t enable) {
+    GTAV_REQUIRE(h, "dit_set_weight_prefetch: null handle");
+    if (h->w_prefetch != (enable != 0)) {   // captured sampler steps carry the other kernel parameters
+        for (auto& kv : h->graphs)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+    }
+    h->w_prefetch = enable != 0;
+    return 0;
+}
+
 int gtav_dit_set_fold(gtav_dit* h, int32_t mode, int32_t min_tokens_a, int32_t min_tokens_b) {
     GTAV_REQUIRE(h && mode >= 0 && mode <= 2, "dit_set_fold: mode %d", mode);
     if (min_tokens_a >= 0) h->fold.min_m_a = min_tokens_a;
@@ -1749,11 +1760,29 @@ int gtav_latents_to_tokens(const float* lat, float* z, int32_t N, int32_t hw, in
 // ------------------------------------------------------------------------------------------------
 // kernel-level entry points
 // ------------------------------------------------------------------------------------------------
+// split workspace of the persistent 256-token-tile kernel for the kernel-level entry points (a handle owns its own): allocated on first use per device —
+// these test / tool entry points are never called under stream capture
+static int op_sk_workspace(GemmParams& g) {
+    static float* ws[64] = {nullptr};
+    static int* flags[64] = {nullptr};
+    int dev = 0;
+    GTAV_CHECK_HIP(hipGetDevice(&dev));
+    dev &= 63;
+    if (!ws[dev]) {
+        GTAV_CHECK_HIP(hipMalloc((void**)&ws[dev], gemm_sk_ws_bytes()));
+        GTAV_CHECK_HIP(hipMalloc((void**)&flags[dev], gemm_sk_flag_bytes()));
+        GTAV_CHECK_HIP(hipMemset(flags[dev], 0, gemm_sk_flag_bytes()));
+    }
+    g.sk_ws = ws[dev];
+    g.sk_flags = flags[dev];
+    return 0;
+}
 int gtav_op_gemm_f16(const void* x, int32_t ldx, const void* w, const float* bias, void* out, int32_t ldo, int32_t M, int32_t N,
                      int32_t K, int32_t epilogue, const float* gate, int32_t gate_stride, int32_t rows_per_gate, void* stream) {
     GTAV_REQUIRE((epilogue >= 0 && epilogue <= 4) || epilogue == EPI_PARTIAL, "op_gemm_f16: epilogue %d", epilogue);
     GemmParams g;
     memset(&g, 0, sizeof(g));
+    RET_IF(op_sk_workspace(g));
     if (epilogue == EPI_PARTIAL) g.splitk = gate_stride > 0 ? gate_stride : 1;  // split-K factor travels in gate_stride
     g.X = (const f16*)x; g.ldx = ldx; g.W = (const f16*)w; g.M = M; g.N = N; g.K = K; g.bias = bias; g.out = out; g.ldo = ldo;
     g.gate = gate; g.gate_stride = gate_stride; g.rows_per_gate = rows_per_gate;

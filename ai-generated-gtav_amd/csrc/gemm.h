@@ -85,7 +85,17 @@ struct GemmParams {
     f16* f_a;               // tile-major [round_up(M, 128)][N]
     // ---- L2 prefetch of the NEXT GEMM's weight by the compute waves of the loader-wave kernels at small M (common.h PrefetchDesc) ----
     PrefetchDesc pf;
+    // ---- persistent 256-token-tile kernel (gemm_p256_kernel, shape 40).  sk_ws / sk_flags: the caller's split workspace — fp32 partial
+    // tiles (GEMM_SK_MAX_SPLIT tiles of 256 x 256 floats) and one int per split tile, ZERO between launches (the kernel resets what it sets); null = whole
+    // tiles only.  sk_dp / sk_r are filled by the launcher: tiles [0, sk_dp) run whole (tile t on block t % grid), each of the sk_r remainder tiles is split
+    // in two K halves — block 2 i + 1 runs the K tail FIRST in its sequence and hands its partial sums over, block 2 i runs the K head LAST and owns the epilogue ----
+    float* sk_ws;
+    int* sk_flags;
+    int sk_dp, sk_r;
 };
+constexpr int GEMM_SK_MAX_SPLIT = 128;   // split tiles per launch (half the CUs)
+constexpr size_t gemm_sk_ws_bytes() { return (size_t)GEMM_SK_MAX_SPLIT * 256 * 256 * 4; }
+constexpr size_t gemm_sk_flag_bytes() { return (size_t)GEMM_SK_MAX_SPLIT * 4; }
 
 // One group of a grouped launch (launch_gemm_grouped): out[m][n] = sum_k X[m][k] W[n][k] + bias[n], m < M (common), n < N.
 struct GemmGroup { const f16* X; const f16* W; float* out; const float* bias; int N; int ldo; };

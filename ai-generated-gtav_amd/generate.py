@@ -6,6 +6,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import time
+
 import torch
 
 from . import lib as _lib
@@ -83,6 +85,44 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
                                 noise_idx <= 0, act, cached=cached, cond_step=step if hoist_cond else -1)
     model.check()
     return x
+
+
+@torch.inference_mode()
+def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps: int = 24, rounds: int = 2, use_actions: bool = False,
+                         latent_hw=None) -> dict:
+    """Times the captured full-window sampler step of batch B with the next-weight L2 prefetch on and off — the results are
+    bit-identical, only the speed differs, and the gain is box-dependent (-7 % on some MI355X boxes, nothing on others) — and leaves the model on
+    the faster setting.  Alternates the two settings `rounds` times in this process (a fresh capture per switch), `steps` replays each; synthetic
+    latents; about 0.2 s at batch 1.  Returns {"on_ms", "off_ms", "chosen"} (milliseconds per step, best round of each)."""
+    dev = model.device
+    T = int(window or model.max_frames)
+    h, w = latent_hw or (model.input_h, model.input_w)
+    F = T
+    x0 = (torch.randn(B, F, model.in_channels, h, w, generator=torch.Generator().manual_seed(11)) * 0.5).to(dev)
+    act = None
+    if use_actions:
+        act = torch.zeros(B, F, 25, device=dev)
+        act[:, :, 3] = 1
+    model.set_schedule(_alphas_cumprod(1e-4))
+    ts = [999 - 7 * k for k in range(steps + 3)]
+    best = {True: float("inf"), False: float("inf")}
+    for _ in range(rounds):
+        for on in (True, False):
+            model.set_weight_prefetch(on)
+            x = x0.clone()
+            model.prepare_frame_(B, F, 0, T - 1, 15, ts, act)
+            for k in range(3):                                  # eager warm-up, capture, first replay
+                model.denoise_step_(x, 0, T - 1, 15, ts[k], ts[k + 1], False, act, cond_step=k)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for k in range(3, steps + 3):
+                model.denoise_step_(x, 0, T - 1, 15, ts[k], ts[min(k + 1, steps + 2)], False, act, cond_step=k)
+            torch.cuda.synchronize(dev)
+            best[on] = min(best[on], (time.perf_counter() - t0) / steps * 1e3)
+    chosen = best[True] <= best[False]
+    model.set_weight_prefetch(chosen)
+    model.check()
+    return {"on_ms": round(best[True], 4), "off_ms": round(best[False], 4), "chosen": "on" if chosen else "off"}
 
 
 def sample_inputs(gid: int, n_prompt: int, total_frames: int, frame_hw, latent_hw, latent_ch: int = 16, seed: int = 1000):

@@ -76,6 +76,7 @@ SIGNATURES = {
     "gtav_dit_set_opt_step": [_p, _l, _l, _p],
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_set_fused_temporal": [_p, _i],
+    "gtav_dit_set_weight_prefetch": [_p, _i],
     "gtav_dit_set_fold": [_p, _i, _i, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

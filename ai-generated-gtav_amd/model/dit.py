@@ -235,6 +235,8 @@ class DiT(_HipModule):
                     _lib.check(L.gtav_dit_set_fused_temporal(self._handle, 1))
                 if getattr(self, "_fold", None) is not None:
                     _lib.check(L.gtav_dit_set_fold(self._handle, *self._fold))
+                if getattr(self, "_weight_prefetch", None) is not None:
+                    _lib.check(L.gtav_dit_set_weight_prefetch(self._handle, int(self._weight_prefetch)))
                 if self._trainable:
                     n = C.c_int64(0)
                     _lib.check(L.gtav_dit_train_param_count(self._handle, C.byref(n)))
@@ -479,6 +481,12 @@ class DiT(_HipModule):
         self._fused_temporal = bool(enable)
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fused_temporal(self._handle, int(self._fused_temporal)))
+
+    def set_weight_prefetch(self, enable: bool):
+        """L2 prefetch of the next GEMM's weight at small token counts (gtav_dit_set_weight_prefetch; on by default, bit-identical results)."""
+        self._weight_prefetch = bool(enable)
+        if self._handle:
+            _lib.check(_lib.load().gtav_dit_set_weight_prefetch(self._handle, int(self._weight_prefetch)))
 
     def set_fold(self, mode: int, min_tokens_a: int = -1, min_tokens_b: int = -1):
         """LayerNorm fold (gtav_dit_set_fold): 0 = separate LayerNorm launches everywhere, 1 = folded into the GEMM epilogues where that is

@@ -145,6 +145,9 @@ def parse_args(argv=None):
     ap.add_argument("--train-leg-steps", type=int, default=3,
                     help="timed optimisation steps of the bounded training leg of the default run (SURVEY.md 8(f)1: batch 16, forward + backward "
                          "+ AdamW on latents resident in HBM; N = 1 only); 0 disables it")
+    ap.add_argument("--g256-clips", type=int, default=2,
+                    help="timed clips of the bounded g256 leg of the default (native-geometry, N = 1) run: BASELINE.json's literal 256x256 frames through "
+                         "the SURVEY.md 8(d) preset, batch 1, window algorithm; 0 disables it")
     ap.add_argument("--mode", choices=["generate", "train", "train_step"], default="generate",
                     help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
                          "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline); "
@@ -404,6 +407,71 @@ def bench_generate(args, world, rank, dev, dist, torch):
                     "kernel_classes": classes}
         return roofline, dit_step, (xw, tw)
 
+    def profile_cached_step(b, actions):
+        """in-situ per-class kernel times of the CONTEXT-CACHED sampler step of batch b (M = b x P tokens: the frame being denoised only, context K / V
+        from the temporal caches; generate.py:200-220 with the exact caching of DESIGN.md 5) + the captured-graph time of that step.  The roofline
+        object follows SURVEY.md 8(d)'s accounting rule: FLOPs actually executed by this algorithm's step."""
+        from gtav_amd.utils import alphas_cumprod
+        nst = 24
+        g = torch.Generator().manual_seed(5)
+        F = 6
+        xb = (torch.randn(b, F, 16, LH, LW, generator=g) * 0.5).to(dev)
+        ab = actions[:, :F].contiguous() if actions is not None else None
+        dit.set_schedule(alphas_cumprod(1e-4))
+        ts = [999 - 9 * k for k in range(nst + 1)]
+
+        xx = torch.empty_like(xb)         # ONE buffer: the captured graph is keyed by it
+
+        def frame(profile):
+            xx.copy_(xb)
+            dit.prepare_frame_(b, F, 1, 5, 15, ts, ab)
+            dit.denoise_step_(xx, 1, 5, 15, ts[0], ts[1], False, ab, cached=False, cond_step=0)
+            torch.cuda.synchronize()
+            if profile:
+                dit.profile(True)
+            t0 = time.perf_counter()
+            for k in range(1, nst + 1):
+                dit.denoise_step_(xx, 1, 5, 15, ts[k], ts[min(k + 1, nst)], False, ab, cached=True, cond_step=k)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / nst * 1e3
+
+        frame(False)                      # eager warm-up + capture of this key
+        graph_ms = min(frame(False), frame(False))
+        frame(True)
+        prof = dit.profile_read()
+        dit.profile(False)
+        M = b * P_TOK
+        ev_ms, ev_n = prof.pop("empty_event_pair")
+        classes = {k: {"ms_per_step": round(v[0] / nst, 4), "launches_per_step": v[1] // nst} for k, v in prof.items()}
+        gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": 2.0 * M * HM * D_MODEL,
+                 "gemm_fc2": 2.0 * M * HM * D_MODEL}
+        tot_fl = tot_ms = 0.0
+        for k, fl in gflop.items():
+            ms, n = prof[k]
+            if n:
+                classes[k]["us_per_launch"] = round(ms / n * 1e3, 2)
+                classes[k]["frac_of_mfma_peak"] = round(fl / (ms / n * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+                tot_fl += fl * n
+                tot_ms += ms
+        step_fl = dit_forward_flops(M, b, 5, b)
+        w_bytes = 2.0 * (DEPTH * 2 * 12 * D_MODEL * D_MODEL)          # fp16 GEMM weights streamed once per step (DESIGN.md 3: 0.40 GB at DiT-S/2) ...
+        w_bytes_all = 1.216e9                                          # ... SURVEY.md 8(d)'s per-forward figure (all 607.9 M parameters as 2-byte values)
+        mfma = step_fl / (graph_ms * 1e-3) / 1e12
+        hbm = w_bytes_all / (graph_ms * 1e-3) / 1e9
+        bound = "hbm" if b * P_TOK < 310 else "mfma"                   # SURVEY.md 8(d): ridge at ~310 FLOP/B = ~310 tokens per weight byte pair
+        roof = {"kernel": "context-cached sampler step (one hipGraph replay: %d launches), M=%d tokens" % (sum(v[1] for v in prof.values()) // nst, M),
+                "bound": bound,
+                "achieved": round(hbm if bound == "hbm" else mfma, 2), "peak": 8000.0 if bound == "hbm" else MFMA_PEAK_TFLOPS,
+                "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                "frac": round((hbm / 8000.0) if bound == "hbm" else (mfma / MFMA_PEAK_TFLOPS), 4), "traffic": None,
+                "algorithmic_bytes_per_step": w_bytes_all, "fp16_gemm_weight_bytes_per_step": w_bytes, "executed_tflop_per_step": round(step_fl / 1e12, 4),
+                "mfma_tflops": round(mfma, 1), "weight_stream_gbps": round(hbm, 1),
+                "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,
+                "note": "whole-step figure (executed FLOPs / weight bytes of ONE cached step over the captured step's time), not one kernel: at this size "
+                        "the step is a chain of ~230 short launches"}
+        return roof, {"graph_ms_per_step": round(graph_ms, 4), "tokens": M, "kernel_classes": classes,
+                      "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2)}
+
     def algo_report(b, results, nclips):
         out = {}
         for algo, e in results.items():
@@ -413,6 +481,11 @@ def bench_generate(args, world, rank, dev, dist, torch):
                                    "achieved_tflops_per_gpu": round(fl / world * nclips / e / 1e12, 1)}
         return out
 
+    # ---- the next-weight L2 prefetch pays on some boxes and not on others (bit-identical results either way): time both on this box, keep the faster ----
+    prefetch_choice = None
+    if 256 <= B * 5 * P_TOK <= 1536:
+        from gtav_amd.generate import tune_weight_prefetch
+        prefetch_choice = tune_weight_prefetch(dit, B, use_actions=args.use_actions, latent_hw=(LH, LW))
     # ---- headline leg: batch B per GPU (configs[1] by default) ----
     inp = leg_inputs(B, args.use_actions, seed=1000)
     algos = ["window", "cached"] if args.algo == "both" else [args.algo]
@@ -422,6 +495,9 @@ def bench_generate(args, world, rank, dev, dist, torch):
     gen_frames = world * B * (total - n_prompt)
     value = gen_frames * args.steps / el
     roofline, dit_step, (xw, tw) = profile_forward(B, inp[2])
+    roofline_cached = dit_step_cached = None
+    if "cached" in results:
+        roofline_cached, dit_step_cached = profile_cached_step(B, inp[2])
 
     # ---- batched leg: batch 8 per GPU, action-conditioned (configs[2] at N = 1, configs[3]-shaped at N > 1), bounded ----
     batched = None
@@ -429,12 +505,13 @@ def bench_generate(args, world, rank, dev, dist, torch):
         binp = leg_inputs(Bb, True, seed=5000)
         bres = {algo: timed(binp, algo == "cached", args.batched_clips, 1, short_warm=True) for algo in algos}
         broof, bstep, _ = profile_forward(Bb, binp[2])
+        broof_c, bstep_c = profile_cached_step(Bb, binp[2]) if "cached" in bres else (None, None)
         bel = bres["window" if "window" in bres else algos[0]]
         batched = {"workload": "BASELINE configs[%d]: batch %d per GPU x %d GPU(s) = %d sequences, action-conditioned, %d frames (%d prompt), "
                                "%d noise steps, VAE inside the timed region" % (2 if world == 1 else 3, Bb, world, world * Bb, total, n_prompt, steps),
                    "clips_timed": args.batched_clips, "warmup": "1 clip with 2 noise steps (same shapes and hipGraph keys)",
                    "value": round(world * Bb * (total - n_prompt) * args.batched_clips / bel, 4), "unit": "generated frames/s",
-                   "roofline": broof, "dit_step": bstep}
+                   "roofline": broof, "dit_step": bstep, "roofline_cached": broof_c, "dit_step_cached": bstep_c}
         batched.update(algo_report(Bb, bres, args.batched_clips))
         del binp
 
@@ -518,6 +595,41 @@ def bench_generate(args, world, rank, dev, dist, torch):
         del tdit, lat, cn, nz
         torch.cuda.empty_cache()
 
+    # ---- bounded g256 leg (N = 1, native default run only): BASELINE.json's literal "[B, 32 frames, 256x256]" through the SURVEY.md 8(d) preset
+    # (VAE patch 16 -> 16x16x16 latents, 64 DiT tokens per frame, DiT-S / ViT-L widths), batch 1, no actions, window algorithm, VAE in the timed region ----
+    g256_leg = None
+    if world == 1 and args.geometry == "native" and args.g256_clips > 0 and vae is not None:
+        g2 = GEOM["g256"]
+        dit2 = DiT(**g2["dit"], init_weights=False, max_batch=1)
+        dit2.load_state_dict(W.synth_state_dict(W.dit_param_shapes(**g2["dit"]), seed=0))
+        dit2.reserve(1, 5, steps)
+        vae2 = AutoencoderKL(**g2["vae"], init_weights=False, max_frames_per_call=4)
+        vae2.load_state_dict(W.synth_state_dict(W.vae_param_shapes(**g2["vae"]), seed=1))
+        _, fr2, nz2 = shard_inputs(1, 0, 1, n_prompt, total, g2["frame"], g2["lat"], seed=1000)
+        fr2, nz2 = fr2.to(dev), nz2.to(dev)
+        pf2 = None
+        if 256 <= 5 * 64 <= 1536:
+            from gtav_amd.generate import tune_weight_prefetch
+            pf2 = tune_weight_prefetch(dit2, 1, latent_hw=g2["lat"])
+        generate_clip(dit2, vae2, fr2, nz2, total, 2, None, ctx_cache=False)          # short warm-up: same shapes / graph keys
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.g256_clips):
+            generate_clip(dit2, vae2, fr2, nz2, total, steps, None, ctx_cache=False)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        p_save, P_TOK = P_TOK, 64
+        fl2 = clip_flops(1, n_prompt, total, steps, 5, False)
+        P_TOK = p_save
+        g256_leg = {"workload": "BASELINE.json's literal 256x256 frames: SURVEY.md 8(d) g256 preset (VAE patch 16 -> 16x16x16 latents, 64 DiT tokens per frame, "
+                                "DiT-S/2 widths depth 16 + ViT-L/16 VAE), %d frames (%d prompt), %d noise steps, batch 1, no actions, window algorithm, VAE in the "
+                                "timed region" % (total, n_prompt, steps),
+                    "clips_timed": args.g256_clips, "value": round((total - n_prompt) * args.g256_clips / e2, 4), "unit": "generated frames/s",
+                    "ms_per_clip": round(e2 / args.g256_clips * 1e3, 1), "executed_pflop_per_clip": round(fl2 / 1e15, 4),
+                    "achieved_tflops_per_gpu": round(fl2 * args.g256_clips / e2 / 1e12, 1), "weight_prefetch": pf2}
+        del dit2, vae2, fr2, nz2
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -572,12 +684,15 @@ def bench_generate(args, world, rank, dev, dist, torch):
             "all_frames_per_s": round(world * B * total * args.steps / el, 4),          # B * 32 / wall
             "dit_forwards_per_s": round(world * (total - n_prompt) * (steps + 1) * args.steps / el, 2),   # batched forwards of B samples
             "roofline": roofline, "cpu_baseline": cpu, "dit_step": dit_step,
+            "roofline_cached": roofline_cached, "dit_step_cached": dit_step_cached, "weight_prefetch": prefetch_choice,
         }
         line.update(algo_report(B, results, args.steps))
         if batched is not None:
             line["config2" if world == 1 else "config3"] = batched
         if train_leg is not None:
             line["train_step"] = train_leg
+        if g256_leg is not None:
+            line["g256"] = g256_leg
         if shard_check is not None:
             line["shard_self_check"] = shard_check
         print(json.dumps(line))

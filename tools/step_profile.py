@@ -48,9 +48,12 @@ def main():
     order = list(reversed(range(a.steps + 1)))
     i, start = 5, 1
 
+    xbuf = torch.empty_like(x)          # ONE buffer: the captured graph is keyed by it
+
     def frame(count_from=1):
         """one generated frame: the first step always runs the whole window; returns (seconds, steps) of the steps from `count_from` on"""
-        xx = x.clone()
+        xx = xbuf
+        xx.copy_(x)
         dit.prepare_frame_(B, F, start, i, 15, [t_of[k] for k in order], act)
         t0 = None
         for step, ni in enumerate(order):
