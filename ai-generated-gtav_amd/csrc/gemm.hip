@@ -2331,9 +2331,10 @@ __device__ __forceinline__ P256Unit p256_unit(const GemmParams& p, int u, int ti
     P256Unit r;
     r.kt0 = 0; r.nkt = nktot; r.kind = 0; r.slot = 0;
     int v;
-    if (helper && u == 0) { v = p.sk_dp + (b >> 1); r.kind = 1; r.slot = b >> 1; r.kt0 = nktot >> 1; r.nkt = nktot - r.kt0; }
+    const int kh = (nktot >> 1) & ~1;   // split point: both halves hold an even number of K-tiles (the K loop advances by pairs)
+    if (helper && u == 0) { v = p.sk_dp + (b >> 1); r.kind = 1; r.slot = b >> 1; r.kt0 = kh; r.nkt = nktot - kh; }
     else if (d < n_dp) v = b + d * G;
-    else { v = p.sk_dp + (b >> 1); r.kind = 2; r.slot = b >> 1; r.nkt = nktot >> 1; }
+    else { v = p.sk_dp + (b >> 1); r.kind = 2; r.slot = b >> 1; r.nkt = kh; }
     lp_tile_of(p, v, tiles_m, tiles_n, 32 * FI, 256, r.n0, r.m0);
     return r;
 }
@@ -2355,7 +2356,14 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
     const int n_dp = b < p.sk_dp ? (p.sk_dp - b + G - 1) / G : 0;
     const int nunits = n_dp + (split ? 1 : 0);
     if (nunits == 0) return;
-    const int S = n_dp * nktot + (split ? ((b & 1) ? nktot - (nktot >> 1) : (nktot >> 1)) : 0);   // K-tiles of this block
+#ifdef GTAV_EXPERIMENTS   // per-block timeline of the FIRST unit (tools/gemm_stamps.py): entry, first K-tile landed, main loop done, epilogue done; slot 7 = block end
+#define P256_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    if (p.stamps && tid == 0) { p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime(); }
+#else
+#define P256_STAMP(i) do { } while (0)
+#endif
+    P256_STAMP(0);
+    const int S = n_dp * nktot + (split ? ((b & 1) ? nktot - ((nktot >> 1) & ~1) : ((nktot >> 1) & ~1)) : 0);   // K-tiles of this block (even)
     const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
     const unsigned voff = (unsigned)lane * 16u, smem0 = lds_offset(smem);
     // ---- the block's unit list, decoded ONCE (one unit per thread: the tile map's integer divisions stay out of the K loop) into LDS ----
@@ -2427,29 +2435,26 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
     constexpr std::false_type SECOND{};
     setW(0);
     setX(0);
+    // K-tiles 0 and 1 are issued completely (X before W: the K loop's counted waits rely on that order), K-tile 0 is awaited with K-tile 1 in flight
     issueX(FIRST); issueX(SECOND); advX();
     issueW(FIRST); issueW(SECOND); advW();
     if (S > 1) {
         issueX(FIRST); issueX(SECOND); advX();
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        issueW(FIRST); issueW(SECOND); advW();
+        if constexpr (NWQ == 3) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
+    P256_STAMP(1);
     const int li = lane & 15, g4 = lane >> 4;
-    int woff[2], xoff[2];
-#pragma unroll
-    for (int sh = 0; sh < 2; ++sh) {
-        const int ch = ((4 * sh + g4) ^ (li & 7)) << 4;
-        woff[sh] = (16 * FI * wn + li) * 128 + ch;
-        xoff[sh] = C::WREG + (64 * wm + li) * 128 + ch;
-    }
     f32x4 acc[FI][4];
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0); };
+    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) { if (!GTAV_DBG(p, 2)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0); };   // (debug bit 1: no MFMAs)
 
     // the unit being computed; its bias slice (TNB floats, one 16-byte chunk per thread) is requested at its head and goes through LDS in the epilogue
     int cu = 0, ck = 0, cnk = unit_field(0, 3);
@@ -2462,64 +2467,129 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
     f32x4 bias4 = bias_chunk(0);
     float amax = 0.f;
 
-    for (int g = 0; g < S; ++g) {
-        const char* bb = smem + (g & 1) * C::PAR;
-        const bool n1 = g + 1 < S, n2 = g + 2 < S;
-        f16x8 wa[2][FIH], wb[2][FIH], xa[2][2], xb[2][2];
-        // ---- phase 1 ----
-        if (n1) issueW(FIRST);
+    // Fragment offsets from an opaque copy of the lane number (see the loop): used by the prologue read here
+    auto frag_offsets = [&](int lo, int (&woff)[2], int (&xoff)[2]) {
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+            const int l15 = lo & 15, ch = ((4 * sh + (lo >> 4)) ^ (l15 & 7)) << 4;
+            woff[sh] = (16 * FI * wn + l15) * 128 + ch;
+            xoff[sh] = C::WREG + (64 * wm + l15) * 128 + ch;
+        }
+    };
+    // K-tile schedule (round 4, second form).  Every MFMA phase finds its fragments in registers, read ONE PHASE EARLIER — the first form read them at the head
+    // of the phase that used them and its K-tile was the SUM of the LDS round trips (0.82 us of reads + barriers) and the MFMAs (0.64 us), tools/gemm_stamps.py:
+    //   phase 1: MFMA W[0:h] x X[0:2]   | read X[2:4] and the first half of W[h:2h] of this K-tile
+    //   phase 2: MFMA W[0:h] x X[2:4]   | read the rest of W[h:2h]
+    //   -- lgkmcnt(0), barrier (b): every wave has read this parity -> it is free --
+    //   phase 3: MFMA W[h:2h] x X[2:4]  | issue X(g + 2) into this parity
+    //   -- vmcnt(4): everything older than X(g + 2) has landed = K-tile g + 1 complete; barrier (a) --
+    //   phase 4: MFMA W[h:2h] x X[0:2]  | read W[0:h], X[0:2] of K-tile g + 1 (other parity) for the next phase 1; issue W(g + 2) into this parity
+    // Fill order per K-tile is X then W, so the four youngest operations at (a) are exactly X(g + 2); K-tile g + 1 was issued during phases 3 / 4 of K-tile
+    // g - 1: one whole K-tile of latency budget for every piece (the first form gave W half of that).
+    // Two named fragment sets (A, B) alternate between consecutive K-tiles — no register copies, no conditional reads (the last K-tile of a block reads
+    // its "next" fragments from whatever the other parity holds and nobody uses them) — so the K loop advances by PAIRS of K-tiles: every unit has an even
+    // number of K-tiles (host-checked: K / 64 even, the split point is even).
+    f16x8 wA[2][FIH], xA[2][2], wB[2][FIH], xB[2][2];
+    {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        int woff[2], xoff[2];
+        frag_offsets(lo, woff, xoff);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh) {
 #pragma unroll
-            for (int i = 0; i < FIH; ++i) wa[sh][i] = *(const f16x8*)(bb + woff[sh] + i * 16 * 128);
+            for (int i = 0; i < FIH; ++i) wA[sh][i] = *(const f16x8*)(smem + woff[sh] + i * 16 * 128);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xa[sh][j] = *(const f16x8*)(bb + xoff[sh] + j * 16 * 128);
+            for (int j = 0; j < 2; ++j) xA[sh][j] = *(const f16x8*)(smem + xoff[sh] + j * 16 * 128);
         }
+    }
+    const bool late = w >= 4;
+    auto ktile = [&](int g, const f16x8 (&wa)[2][FIH], const f16x8 (&xa)[2][2], f16x8 (&wnx)[2][FIH], f16x8 (&xnx)[2][2]) {
+        const char* bb = smem + (g & 1) * C::PAR;
+        const char* bn = smem + ((g + 1) & 1) * C::PAR;
+        const bool n2 = g + 2 < S && !GTAV_DBG(p, 1);   // (experiments build, debug bit 0: no refills — timing only)
+        f16x8 wb[2][FIH], xb[2][2];
+        // The per-lane fragment offsets are RECOMPUTED every K-tile from the lane number (a dozen VALU operations beside 48-64 MFMAs): kept in registers across
+        // the loop they were spilled around the epilogue and reloaded in front of the loop's back edge — and hipcc's wait-count pass, which does not see the
+        // inline-asm fills, then put an `s_waitcnt vmcnt(0)` at the head of EVERY K-tile (the fills in flight drained each step).  The empty asm makes the lane
+        // number opaque so that the computation is not hoisted out of the loop again.
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
+        int woff[2], xoff[2];
+        frag_offsets(lo, woff, xoff);
+        // ---- phase 1 ----
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
             for (int j = 0; j < 2; ++j) xb[sh][j] = *(const f16x8*)(bb + xoff[sh] + (2 + j) * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < FIH; ++i) wb[0][i] = *(const f16x8*)(bb + woff[0] + (FIH + i) * 16 * 128);
+        // (sched_barrier: the reads of a phase are ISSUED in front of its MFMAs and not sunk next to their first use — at the register limit hipcc's scheduler
+        // otherwise moves every read down to the MFMA that consumes it, which puts the LDS round trip back on the critical path)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
             for (int i = 0; i < FIH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma(wa[sh][i], xa[sh][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- phase 2 ----
-        if (n1) { issueW(SECOND); advW(); }
-        // (the W rows of phases 3 / 4: the first 32-deep half is fetched here, the second one behind barrier (b) into the registers phase 2 frees — the W slots
-        // of this parity are not refilled before the NEXT K-tile, only the X slots are, and the kernel sits at the 256-register limit)
 #pragma unroll
-        for (int i = 0; i < FIH; ++i) wb[0][i] = *(const f16x8*)(bb + woff[0] + (FIH + i) * 16 * 128);
+        for (int i = 0; i < FIH; ++i) wb[1][i] = *(const f16x8*)(bb + woff[1] + (FIH + i) * 16 * 128);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
             for (int i = 0; i < FIH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma(wa[sh][i], xb[sh][j], acc[i][2 + j]);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (b): every wave has read this parity's X fragments
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (b): every wave has read this parity's fragments
         // ---- phase 3 ----
-#pragma unroll
-        for (int i = 0; i < FIH; ++i) wb[1][i] = *(const f16x8*)(bb + woff[1] + (FIH + i) * 16 * 128);
-        if (n2) issueX(FIRST);
+        // A fill instruction holds its wave until the CU's address pipe has taken it (64 B/clk: the 32 + 24 pieces of a K-tile are ~900 cycles of that pipe), and
+        // with all eight waves issuing in the same phase every wave sat in that queue IN FRONT of its MFMAs (tools/gemm_stamps.py, debug bits: fills 0.41 us of a
+        // 1.46 us K-tile).  Waves 4-7 — the SIMD partners of waves 0-3 — issue their pieces BEHIND their MFMAs instead: while one wave of a SIMD queues, the
+        // other one feeds the matrix pipe.  Every wave's own order of fills and waits is unchanged.
+        if (n2 && !late) { issueX(FIRST); issueX(SECOND); advX(); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
             for (int i = 0; i < FIH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma(wb[sh][i], xb[sh][j], acc[FIH + i][2 + j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (n2 && late) { issueX(FIRST); issueX(SECOND); advX(); }
+        if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a): everything but X(g + 2) has landed = K-tile g + 1 complete
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         // ---- phase 4 ----
-        if (n2) { issueX(SECOND); advX(); }
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+#pragma unroll
+            for (int i = 0; i < FIH; ++i) wnx[sh][i] = *(const f16x8*)(bn + woff[sh] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xnx[sh][j] = *(const f16x8*)(bn + xoff[sh] + j * 16 * 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n2 && !late) { issueW(FIRST); issueW(SECOND); advW(); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
             for (int i = 0; i < FIH; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma(wb[sh][i], xa[sh][j], acc[FIH + i][j]);
-        if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a): everything but X(g + 2) has landed = K-tile g + 1 complete
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (++ck < cnk) continue;
+        __builtin_amdgcn_sched_barrier(0);
+        if (n2 && late) { issueW(FIRST); issueW(SECOND); advW(); }
+    };
+    for (int g = 0; g < S; g += 2) {
+        ktile(g, wA, xA, wB, xB);
+        ktile(g + 1, wB, xB, wA, xA);
+        ck += 2;
+        if (ck < cnk) continue;
 
+        if (cu == 0) P256_STAMP(2);
         // ================= the unit is complete: epilogue straight from the accumulators =================
         const int kind = unit_field(cu, 4), slot = unit_field(cu, 5);
         const size_t slot_off = (size_t)slot * (TNB * 256);
@@ -2590,8 +2660,8 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
                         const unsigned o0 = __shfl_xor(mine.x, 16, 64), o1 = __shfl_xor(mine.y, 16, 64);
                         if (ok && !(lane & 16)) *(uint4*)((f16*)p.out + tiled_off(m, n, p.ldo)) = uint4{mine.x, mine.y, o0, o1};
                     }
-                    if (j & 1) __builtin_amdgcn_sched_barrier(0);   // two token groups per scheduling region: all 128 accumulators are live here
                 }
+                __builtin_amdgcn_sched_barrier(0);   // one feature group (four token groups) per scheduling region: every accumulator is live here
             }
         }
 #pragma unroll
@@ -2599,11 +2669,36 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         ck = 0;
+#ifdef GTAV_EXPERIMENTS
+        if (cu == 0 && p.stamps && tid == 0) {
+            p.stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            p.stamps[(size_t)blockIdx.x * 8 + 6] = xcc & 0xF;
+        }
+#endif
         if (++cu < nunits) {
             cnk = unit_field(cu, 3);
             bias4 = bias_chunk(cu);
+            // the next unit's first fragments are read (again) HERE, not carried through the epilogue from phase 4 of the K-tile before it: 40 registers
+            // that the epilogue needs (all accumulators are live there) for one exposed LDS round trip per unit
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+            int woff[2], xoff[2];
+            frag_offsets(lo, woff, xoff);
+            const char* bn = smem + (g & 1) * C::PAR;        // K-tile g + 2: landed and visible since barrier (a) of K-tile g + 1
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+#pragma unroll
+                for (int i = 0; i < FIH; ++i) wA[sh][i] = *(const f16x8*)(bn + woff[sh] + i * 16 * 128);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xA[sh][j] = *(const f16x8*)(bn + xoff[sh] + j * 16 * 128);
+            }
         }
     }
+    P256_STAMP(7);
+#undef P256_STAMP
     if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_F16_TILED) sat_report(amax, p.err_flag);
 }
 
@@ -3158,6 +3253,7 @@ static int launch_p256(const GemmParams& p, hipStream_t stream) {
     GTAV_REQUIRE((size_t)round_up(p.M, 128) * p.K * 2 < (1ull << 32) && (size_t)round_up(p.N, 128) * p.K * 2 < (1ull << 32),
                  "gemm: the persistent 256-token-tile kernel addresses its operands with 32-bit offsets (M=%d N=%d K=%d)", p.M, p.N, p.K);
     const int T = cdiv(p.M, 256) * cdiv(p.N, C::TNB), nkt = p.K / TK;
+    GTAV_REQUIRE(nkt % 2 == 0, "gemm: the persistent 256-token-tile kernel walks K in pairs of K-tiles (K = %d is not a multiple of 128)", p.K);
     GTAV_REQUIRE(cdiv(T, cus) + 1 <= P256_MAXU, "gemm: %d tiles are more than %d rounds of the persistent 256-token-tile kernel", T, P256_MAXU - 1);
     const int full = T / cus, rem = T - full * cus;
     int grid = T < cus ? T : cus;
@@ -3192,7 +3288,12 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if (shape == 40 || shape == 41) {   // persistent 256-token tiles (round 4): 40 = 256 x 256, 41 = 192 x 256 (N x M)
         if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent 256-token-tile kernel splits K itself (one slab, N %% 8 == 0)");
-            return shape == 40 ? launch_p256<EPI, 8>(p, stream) : launch_p256<EPI, 6>(p, stream);
+#ifdef GTAV_EXPERIMENTS
+            if (shape == 40) return launch_p256<EPI, 8>(p, stream);   // 256 x 256: 128 accumulator registers — hipcc spills inside the K loop at the 256-register cap (117 us for fc1 at M = 5760)
+#else
+            GTAV_REQUIRE(shape == 41, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
+#endif
+            return launch_p256<EPI, 6>(p, stream);
         } else {
             GTAV_REQUIRE(false, "gemm: the persistent 256-token-tile kernel (shape %d) has no epilogue %d", shape, (int)EPI);
         }
