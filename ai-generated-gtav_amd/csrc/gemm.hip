@@ -2702,327 +2702,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
     if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_F16_TILED) sat_report(amax, p.err_flag);
 }
 
-#ifdef GTAV_EXPERIMENTS   // measured slower than shape 12 (profiles/round2/pp_stamps_v1.txt): not in the product library
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent ping-pong GEMM for large M (shape 16): one 1024-thread block per CU, two groups of 8 waves.
-//
-// What the stamps of round 2 showed for the two-blocks-per-CU shape at M = 5760 (profiles/round2/stamps_*.txt): the 512
-// resident blocks run in LOCKSTEP — every block is in its prologue (2 us), main loop (21.6 us at half the CU's fill rate
-// each) and epilogue (6.1 us: GELU / RoPE VALU + staging + stores) at the same time, so the co-resident block never hides
-// anything: 8 of every 30 us the MFMA pipe and the L2->LDS path of the whole chip idle.  Here the overlap is built in:
-//   * the block is persistent and walks its tiles (blockIdx + i * gridDim of an XCD-aware order) — 128 features x 192 tokens
-//     each, the per-wave 64 x 48 sub-tile and fragment reads of shape 12;
-//   * group (i & 1) runs the MAIN loop of tile i (all the LDS-DMA fills, fragment reads and MFMAs) while the other group runs
-//     the EPILOGUE of tile i - 1 out of its accumulators: one 16 x 16 accumulator tile per K-step slot, straight from registers
-//     to memory (pairs of lanes exchange halves for 16-byte stores; no LDS staging, so no LDS or barrier of its own), and in
-//     its last NS - 1 slots issues the first fills of tile i + 1, which it will compute next: the LDS ring never drains
-//     between tiles, a tile's prologue latency and its epilogue are both under the other group's MFMAs;
-//   * one s_barrier per K-step, shared by all 16 waves: MAIN waves arrive after their counted vmcnt / lgkmcnt(0) (tile data
-//     landed, previous stage no longer read), EPILOGUE waves arrive bare.  Ring slot of K-step k of tile i = (i P + k) % NS.
-// 16 waves per CU = 4 per SIMD = 128 VGPRs per lane: 48 accumulator + 56 fragment registers fit (shape 12's budget).
-// Because the epilogue is free, the residual GEMMs use the in-place gated residual epilogue here (EPI_RESID: x += gate (acc +
-// bias), a read-modify-write whose loads are issued one slot ahead) instead of split-K slabs: the LayerNorm that follows
-// reads and writes 35 MB instead of 83-106 MB at M = 5760.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int PP_FI = 4, PP_FJ = 3, PP_WM = 4, PP_G = 5, PP_NT = PP_FI * PP_FJ;
-constexpr int PP_WPC = 16, PP_NP = 40, PP_STAGE = PP_NP * 1024, PP_TN = 128, PP_TM = 192;
-
-__device__ __forceinline__ void pp_tile_of(const GemmParams& p, int v, int tiles_m, int tiles_n, int& n0, int& m0) {
-    const int T = tiles_m * tiles_n;
-    const int xcd = v & 7, qq = T >> 3, rr = T & 7;
-    const int tile_id = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (v >> 3);
-    int gn = p.tm.gn;                                      // host: choose_gn() (every launcher fills it)
-    const int group = tiles_m * gn;
-    const int ng = tile_id / group, rem = tile_id - ng * group;
-    const int n_first = ng * gn;
-    if (n_first + gn > tiles_n) gn = tiles_n - n_first;
-    const int tile_m = rem / gn, tile_n = n_first + (rem - tile_m * gn);
-    n0 = tile_n * PP_TN;
-    m0 = tile_m * PP_TM;
-}
-
-// 16-byte store of the fp16x4 of lanes (l, l ^ 16): the MFMA tile's lane groups g and g ^ 1 hold adjacent 4-element runs
-__device__ __forceinline__ void pp_store_pair(f16* dst, uint2 mine, int lane, bool sc1, bool ok) {
-    const unsigned o0 = __shfl_xor(mine.x, 16, 64), o1 = __shfl_xor(mine.y, 16, 64);
-    if (ok && !(lane & 16)) {
-        if (sc1) store16_sc1(dst, u32x4{mine.x, mine.y, o0, o1});
-        else *(uint4*)dst = uint4{mine.x, mine.y, o0, o1};
-    }
-}
-
-template <int EPI, int NS>
-__global__ __launch_bounds__(1024, 1) void gemm_pp_kernel(GemmParams p) {
-    constexpr int FI = PP_FI, FJ = PP_FJ, G = PP_G, NT = PP_NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 3, wg = w & 7, wn = wg & 1, wm = wg >> 1;
-    const int li = lane & 15, g = lane >> 4;
-    const int P = p.K / TK;
-    const int tiles_m = (p.M + PP_TM - 1) / PP_TM, tiles_n = (p.N + PP_TN - 1) / PP_TN;
-    const int T = tiles_m * tiles_n;
-    const int nt = (T - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this block (grid <= T)
-    const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
-    const bool late = wg >= 4;
-
-    // ---- fills: 40 one-KiB pieces per K-step (16 of W, 24 of X), 5 per MAIN wave; sources located per piece (mainloop_g).
-    // Address of a piece = operand base + k * 16 KiB (SGPRs) + a 32-bit per-lane offset set once per tile (glds16_s) ----
-    unsigned soff[G];
-    const unsigned smem0 = lds_offset(smem);
-    auto setup = [&](int n0, int m0) {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int q = wg * G + i;
-            const bool isw = q < PP_WPC;
-            const int row = isw ? n0 + 8 * q : m0 + 8 * (q - PP_WPC);
-            int rt = row >> 7;
-            const int lim = isw ? last_wt : last_rt;
-            rt = rt < lim ? rt : lim;                    // ragged edges re-read a valid tile (results are masked)
-            soff[i] = (unsigned)rt * (unsigned)(P * TILE_BYTES) + (unsigned)(((row & 127) >> 3) * 1024 + lane * 16);
-        }
-    };
-    auto stage = [&](int slot, int k) {
-        const unsigned base = smem0 + slot * PP_STAGE + wg * (G * 1024);
-        const char* wk = (const char*)p.W + (size_t)k * TILE_BYTES;
-        const char* xk = (const char*)p.X + (size_t)k * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < G; ++i) glds16_s(wg * G + i < PP_WPC ? wk : xk, soff[i], base + i * 1024);
-    };
-    int woff[2], xoff[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
-        woff[s] = (16 * FI * wn + li) * 128 + ch;
-        xoff[s] = PP_WPC * 1024 + (16 * FJ * wm + li) * 128 + ch;
-    }
-
-    f32x4 acc[FI][FJ];
-    float amax = 0.f;
-    int en0 = 0, em0 = 0;          // tile whose accumulators this group holds
-    bool etr = false;
-
-#ifdef GTAV_EXPERIMENTS
-    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (grp == 0) {                // prologue of the first tile
-        int n0, m0;
-        pp_tile_of(p, blockIdx.x, tiles_m, tiles_n, n0, m0);
-        setup(n0, m0);
-        const int npro = P < NS - 1 ? P : NS - 1;
-        for (int k = 0; k < npro; ++k) stage(k % NS, k);
-    }
-
-    for (int i = 0; i <= nt; ++i) {
-        const bool has_main = i < nt;
-        const int base_slot = (int)(((long long)i * P) % NS);
-        if ((i & 1) == grp) {
-            if (!has_main) continue;
-            // =========================================== MAIN loop of tile i ===========================================
-            int n0, m0;
-            pp_tile_of(p, blockIdx.x + i * gridDim.x, tiles_m, tiles_n, n0, m0);
-            bool tr = false;
-            if constexpr (EPI == EPI_QKV) tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-            en0 = n0; em0 = m0; etr = tr;
-#pragma unroll
-            for (int a = 0; a < FI; ++a)
-#pragma unroll
-                for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // two copies of the K loop (operands swapped for the transposed V tiles) instead of a per-MFMA select
-            auto main_loop = [&](auto trc) {
-                constexpr bool TR = decltype(trc)::value;
-                int slot = base_slot;
-                for (int k = 0; k < P; ++k) {
-                    const int rem = P - 1 - k;
-                    // this wave's share of K-step k has landed (younger fills of this wave: min(NS - 2, rem) K-steps of G)
-                    kstep_sync_ring<(NS < 4 ? NS : 4), G>(rem);
-                    const bool refill = k + NS - 1 < P;      // the last NS - 1 slots belong to the next tile (filled by the other group)
-                    int fslot = slot + NS - 1;
-                    fslot = fslot >= NS ? fslot - NS : fslot;
-                    if (refill && !late) stage(fslot, k + NS - 1);
-                    const char* b = smem + slot * PP_STAGE;
-                    // all 14 fragment reads of the K-step go out before its first MFMA (one LDS round trip per K-step instead of the
-                    // eight read / wait / 3-MFMA groups hipcc forms at this register budget)
-                    f16x8 wf[2][FI], xf[2][FJ];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                        for (int a = 0; a < FI; ++a) wf[s][a] = *(const f16x8*)(b + woff[s] + a * 16 * 128);
-#pragma unroll
-                        for (int c = 0; c < FJ; ++c) xf[s][c] = *(const f16x8*)(b + xoff[s] + c * 16 * 128);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int a = 0; a < FI; ++a)
-#pragma unroll
-                            for (int c = 0; c < FJ; ++c) {
-                                if (TR) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][c], wf[s][a], acc[a][c], 0, 0, 0);
-                                else acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][a], xf[s][c], acc[a][c], 0, 0, 0);
-                            }
-                    if (refill && late) {
-                        asm volatile("" ::: "memory");
-                        stage(fslot, k + NS - 1);
-                    }
-                    slot = slot + 1 == NS ? 0 : slot + 1;
-                }
-            };
-            if (tr) main_loop(std::true_type{});
-            else main_loop(std::false_type{});
-#ifdef GTAV_EXPERIMENTS
-            if (p.stamps && wg == 0 && lane == 0 && i < 5) p.stamps[(size_t)blockIdx.x * 8 + 2 + i] = __builtin_amdgcn_s_memrealtime();   // end of MAIN(i)
-#endif
-        } else {
-            // ================= EPILOGUE of tile i - 1 (this group's accumulators) + first fills of tile i + 1 =================
-            const bool do_epi = i >= 1, do_pref = i + 1 < nt;
-            // (the fill pointers of tile i + 1 are set up at its first prefetch slot, not here: ten VGPRs less through the epilogue)
-            auto prefetch = [&](int e, int pbase_, int pfirst_) {
-                if (e == pfirst_) {
-                    int pn0, pm0;
-                    pp_tile_of(p, blockIdx.x + (i + 1) * gridDim.x, tiles_m, tiles_n, pn0, pm0);
-                    setup(pn0, pm0);
-                }
-                int ps = pbase_ + (e - pfirst_);
-                ps = ps >= NS ? ps - NS : ps;
-                stage(ps, e - pfirst_);
-            };
-            const int pbase = (int)(((long long)(i + 1) * P) % NS);      // ring slot of K-step 0 of tile i + 1
-            const int pfirst = P - (NS - 1);                              // slot index in this phase at which tile i + 1's step 0 may be issued
-            const int n0 = en0, m0 = em0;
-            // ---- per-token destination coordinates of this wave's FJ token columns (integer divisions: once per tile) ----
-            int tok_a[FJ], tok_b[FJ];          // tok_b: token inside its frame (spatial, = RoPE position) / window frame (temporal RoPE position)
-            bool tok_ok[FJ];
-#pragma unroll
-            for (int c = 0; c < FJ; ++c) {
-                const int m = m0 + 16 * FJ * wm + 16 * c + (etr ? 4 * g : li);
-                tok_ok[c] = m < p.M;
-                const int mm = tok_ok[c] ? m : p.M - 1;
-                tok_a[c] = 0; tok_b[c] = 0;
-                if constexpr (EPI == EPI_QKV) {
-                    const int fr = mm / p.S;
-                    if (p.qkv_mode == QKV_SPATIAL) {
-                        tok_a[c] = fr; tok_b[c] = mm - fr * p.S;
-                    } else {
-                        const int bb = fr / p.Tq, tfr = p.t0 + (fr - bb * p.Tq);
-                        tok_a[c] = (bb * p.Tmax + tfr) * p.S + (mm - fr * p.S); tok_b[c] = tfr;
-                    }
-                } else if constexpr (EPI == EPI_RESID) {
-                    int row = p.gate ? mm / p.rows_per_gate : 0;
-                    if (p.gate && p.gate_rows) row = p.gate_rows[row];
-                    tok_a[c] = row;
-                }
-            }
-            // one accumulator tile per slot; the loads a tile needs (residual row, gate, bias, RoPE) are issued one slot ahead
-            f32x4 ld0 = f32x4{0.f, 0.f, 0.f, 0.f}, ld1 = ld0, ld2 = ld0;      // for the tile processed in THIS slot
-            f32x4 nx0 = ld0, nx1 = ld0, nx2 = ld0;                            // for the next one
-            auto issue_loads = [&](int e, f32x4& r0, f32x4& r1, f32x4& r2) {
-                const int a = e / FJ, c = e - a * FJ;
-                const int m = m0 + 16 * FJ * wm + 16 * c + li;
-                const int n = n0 + 16 * FI * wn + 16 * a + 4 * g;
-                r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; r2 = r0;
-                if (etr) {
-                    if (p.bias) { const int nf = n0 + 16 * FI * wn + 16 * a + li; r0[0] = nf < p.N ? p.bias[nf] : 0.f; }
-                    return;
-                }
-                if (n >= p.N || !tok_ok[c]) return;
-                if (p.bias) r0 = *(const f32x4*)(p.bias + n);
-                if constexpr (EPI == EPI_RESID) {
-                    r1 = *(const f32x4*)((const float*)p.out + (size_t)m * p.ldo + n);
-                    if (p.gate) r2 = *(const f32x4*)(p.gate + (size_t)tok_a[c] * p.gate_stride + n);
-                } else if constexpr (EPI == EPI_QKV) {
-                    if (n < 2 * p.D) r1 = *(const f32x4*)(p.rope_cs + tok_b[c] * 64 + (n & 63));
-                }
-            };
-            auto epi_tile = [&](int e, const f32x4& r0, const f32x4& r1, const f32x4& r2) {
-                const int a = e / FJ, c = e - a * FJ;
-                const f32x4 av = acc[a][c];
-                // every lane runs the pair exchange of pp_store_pair (cross-lane reads need both lanes active); only the store is
-                // predicated.  A pair (g, g ^ 1) shares its token(s) / feature group, so `ok` is the same in both lanes.
-                if (etr) {
-                    // D[row = token][col = feature] (spatial V): the lane owns tokens m .. m + 3 of feature n -> V^T [feature][token]
-                    const int n = n0 + 16 * FI * wn + 16 * a + li;
-                    const int heads = p.D >> 6, nn = n - 2 * p.D;
-                    const uint2 pk = pack4(amax, av[0] + r0[0], av[1] + r0[0], av[2] + r0[0], av[3] + r0[0]);
-                    const bool ok = tok_ok[c] && n < p.N;
-                    f16* dst = p.v + ((size_t)(tok_a[c] * heads + (nn >> 6)) * 64 + (nn & 63)) * p.S + tok_b[c];
-                    pp_store_pair(dst, pk, lane, p.out_sc1, ok);
-                    return;
-                }
-                const int m = m0 + 16 * FJ * wm + 16 * c + li;
-                const int n = n0 + 16 * FI * wn + 16 * a + 4 * g;
-                const bool ok = n < p.N && tok_ok[c];         // a pair covers 8 consecutive features: N % 8 == 0
-                f32x4 v = av + r0;
-                if constexpr (EPI == EPI_RESID) {
-                    if (ok) {
-                        float* dst = (float*)p.out + (size_t)m * p.ldo + n;
-                        const f32x4 x = p.gate ? r1 + r2 * v : r1 + v;
-                        if (p.out_sc1) store16_sc1(dst, x);
-                        else *(f32x4*)dst = x;
-                    }
-                } else if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF) {
-                    uint2 pk;
-                    if constexpr (EPI == EPI_GELU_TANH) pk = pack4(amax, gelu_tanh_f(v[0]), gelu_tanh_f(v[1]), gelu_tanh_f(v[2]), gelu_tanh_f(v[3]));
-                    else pk = pack4(amax, gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
-                    pp_store_pair((f16*)p.out + (ok ? tiled_off(m, n, p.ldo) : 0), pk, lane, p.out_sc1, ok);
-                } else if constexpr (EPI == EPI_QKV) {
-                    const int which = n >= 2 * p.D ? 2 : (n >= p.D ? 1 : 0);
-                    const int nn = n - which * p.D;
-                    if (which < 2) {
-                        v = rope4(v, r1);
-                    }
-                    const uint2 pk = pack4(amax, v[0], v[1], v[2], v[3]);
-                    f16* dst;
-                    if (p.qkv_mode == QKV_SPATIAL) {
-                        const int heads = p.D >> 6;
-                        dst = (which == 0 ? p.q : p.k) + ((size_t)(tok_a[c] * heads + (nn >> 6)) * p.S + tok_b[c]) * 64 + (nn & 63);
-                    } else if (which == 0) {
-                        dst = p.q + (size_t)(tok_ok[c] ? m : 0) * p.D + nn;
-                    } else {
-                        dst = p.k + (size_t)tok_a[c] * 2 * p.D + (which == 2 ? p.D : 0) + nn;
-                    }
-                    pp_store_pair(dst, pk, lane, p.out_sc1, ok);
-                }
-            };
-            // the residual epilogue's read-modify-write loads are issued one slot ahead; the others (bias / RoPE rows: L2 hits) are
-            // loaded in their own slot — the epilogue has slack (12 tiles in >= 14 slots) and the QKV variant has no registers to spare
-            constexpr bool AHEAD = EPI == EPI_RESID;
-            if (do_epi && AHEAD) issue_loads(0, ld0, ld1, ld2);
-#pragma unroll
-            for (int e = 0; e < NT; ++e) {
-                if (has_main) asm volatile("s_barrier" ::: "memory");
-                if (do_epi) {
-                    if constexpr (AHEAD) {
-                        if (e + 1 < NT) issue_loads(e + 1, nx0, nx1, nx2);
-                        epi_tile(e, ld0, ld1, ld2);
-                        ld0 = nx0; ld1 = nx1; ld2 = nx2;
-                    } else {
-                        issue_loads(e, ld0, ld1, ld2);
-                        epi_tile(e, ld0, ld1, ld2);
-                    }
-                }
-                if (has_main && do_pref && e >= pfirst) prefetch(e, pbase, pfirst);
-            }
-            if (has_main) {
-                for (int e = NT; e < P; ++e) {
-                    asm volatile("s_barrier" ::: "memory");
-                    if (do_pref && e >= pfirst) prefetch(e, pbase, pfirst);
-                }
-            }
-        }
-    }
-    if constexpr (EPI != EPI_RESID) sat_report(amax, p.err_flag);
-#ifdef GTAV_EXPERIMENTS
-    // timeline (tools/gemm_stamps.py --pp): [0] entry, [2 + i] end of the MAIN loop of this block's i-th tile (i < 5), [7] end of the
-    // last epilogue (written by the group that ran it), [1] = number of tiles
-    if (p.stamps && wg == 0 && lane == 0 && grp == ((nt - 1) & 1)) {
-        p.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
-        p.stamps[(size_t)blockIdx.x * 8 + 1] = nt;
-    }
-#endif
-}
-
-
-#endif   // GTAV_EXPERIMENTS (ping-pong kernel)
+// (the persistent ping-pong kernel of round 2, shape 16 — measured slower than shape 12 — lives in gemm_experiments.inc: experiments build only)
 
 }  // namespace
 
@@ -3103,37 +2783,8 @@ static int device_cus(int* dev_out) {
 // forced shape 16 run it); the de-phased shape 12 above gets the same overlap with 16 computing waves.
 static int g_l_for_8 = GTAV_ENV_INT("GTAV_L_FOR_8", 1);   // experiments build: 0 keeps the 96 x 96 tile (shape 8) where the cost model picks it
 #ifndef GTAV_EXPERIMENTS
-bool gemm_pp_ok(int, int, int, int) { return false; }   // the ping-pong kernel (shape 16) is compiled into the experiments build only
-#else
-static int g_pp_enable = GTAV_ENV_INT("GTAV_PP", 0);
-bool gemm_pp_ok(int M, int N, int K, int epi) {
-    if (!(epi == EPI_GELU_TANH || epi == EPI_GELU_ERF || epi == EPI_QKV || epi == EPI_RESID)) return false;
-    if (K % TK != 0 || K / TK < 14 || M % 8 != 0 || N % 8 != 0) return false;
-    // worth it when most CUs get a tile and, beyond one tile per CU, the epilogue of one tile hides under the next tile's main
-    // loop (otherwise the one-shot kernels with smaller tiles cover the chip better)
-    return g_pp_enable && cdiv(M, PP_TM) * cdiv(N, PP_TN) >= 224;
-}
-template <int EPI>
-static int launch_pp(const GemmParams& p, hipStream_t stream) {
-    constexpr int NS = 3;
-    static unsigned long long attr_devs = 0;   // per instantiation, per device (hipFuncSetAttribute is a per-device setting)
-    int dev = 0;
-    const int cus = device_cus(&dev);
-    GTAV_REQUIRE(cus > 0, "gemm: no current device");
-    if (!(attr_devs >> (dev & 63) & 1)) {
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * PP_STAGE));
-        attr_devs |= 1ull << (dev & 63);
-    }
-    const int T = cdiv(p.M, PP_TM) * cdiv(p.N, PP_TN);
-    const dim3 grid(T < cus ? T : cus);
-    GemmParams q = p;
-    const int tiles_n = cdiv(p.N, PP_TN);
-    q.tm.gn = tiles_n >= 8 ? tiles_n >> 3 : 1;   // pp_tile_of: an eighth of the n-panels per group (the persistent walk strides over XCD runs)
-    GTAV_LAUNCH((gemm_pp_kernel<EPI, NS>), grid, dim3(1024), NS * PP_STAGE, stream, q);
-    GTAV_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-#endif   // GTAV_EXPERIMENTS (ping-pong launcher)
+bool gemm_pp_ok(int, int, int, int) { return false; }   // the ping-pong kernel (shape 16) is compiled into the experiments build only (gemm_experiments.inc)
+#endif
 
 // loader-wave kernels: dynamic LDS above 64 KiB needs the per-device opt-in once per instantiation
 // block -> tile map constants of the loader-wave kernels (tile_map_fast)
@@ -3270,6 +2921,10 @@ static int launch_p256(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
+#ifdef GTAV_EXPERIMENTS
+#include "gemm_experiments.inc"   // laboratory: kernels, launchers and block shapes that measured slower than what the heuristic picks (tools/ only)
+#endif
+
 template <int EPI>
 static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hipStream_t stream) {
     GemmParams p = p_in;
@@ -3282,35 +2937,27 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if (shape == 24) return launch_l<EPI, 4, 2, 1, 2, 3, 2>(p, splitk, stream);   // 64 x 48, 6 compute + 2 loader waves (the skinny shape 11 on the loader-wave kernel)
     if (shape == 26) return launch_l<EPI, 4, 2, 2, 2, 3, 2>(p, splitk, stream);   // 64 x 96, 6 compute + 2 loader waves (shape 14 likewise)
 #ifdef GTAV_EXPERIMENTS
-    if (shape == 27) return launch_l<EPI, 8, 2, 1, 2, 3, 2>(p, splitk, stream);   // shape 24 with an 8-stage ring (112 KiB): seven K-steps of W in flight per CU
-    if (shape == 28) return launch_l<EPI, 8, 2, 1, 2, 3, 4>(p, splitk, stream);   // ... and four loader waves
+    {   // shapes that exist only in the experiments build (8, 9, 16, 21, 23, 25, 27, 28, 30, 32, 33, 40): gemm_experiments.inc
+        bool handled = false;
+        const int rc_ = launch_experiment_shape<EPI>(p, ns, shape, splitk, stream, handled);
+        if (handled) return rc_;
+    }
+#else
+    GTAV_REQUIRE(shape != 8 && shape != 9 && shape != 16 && shape != 21 && shape != 23 && shape != 25 && shape != 27 && shape != 28 && shape != 30 && shape != 32 &&
+                 shape != 33 && shape != 40, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
 #endif
-    if (shape == 40 || shape == 41) {   // persistent 256-token tiles (round 4): 40 = 256 x 256, 41 = 192 x 256 (N x M)
+    if (shape == 41) {   // persistent 256-token tiles (round 4): 192 x 256 (N x M)
         if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent 256-token-tile kernel splits K itself (one slab, N %% 8 == 0)");
-#ifdef GTAV_EXPERIMENTS
-            if (shape == 40) return launch_p256<EPI, 8>(p, stream);   // 256 x 256: 128 accumulator registers — hipcc spills inside the K loop at the 256-register cap (117 us for fc1 at M = 5760)
-#else
-            GTAV_REQUIRE(shape == 41, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
-#endif
-            return launch_p256<EPI, 6>(p, stream);
+            return launch_p256<EPI, 6>(p, stream);   // (40, the 256 x 256 form, spills inside the K loop at the 256-register cap: experiments build)
         } else {
             GTAV_REQUIRE(false, "gemm: the persistent 256-token-tile kernel (shape %d) has no epilogue %d", shape, (int)EPI);
         }
     }
-    if (shape >= 30 && shape <= 33) {   // persistent loader-wave kernel: 30 / 31 = 128 x 192 tiles, 4- / 3-stage ring; 32 = 256 x 128, 33 = 128 x 256 (3 stages)
+    if (shape == 31) {   // persistent loader-wave kernel: 128 x 192 tiles, 3-stage ring
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED || EPI == EPI_RESID) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");
-#ifdef GTAV_EXPERIMENTS
-            // measured against shape 31 / the two-blocks-per-CU shapes: 30 ties 31; 32 / 33 win back to back on cold operands (fc1 at
-            // M = 5760 67 -> 57 us) and LOSE inside the forward (54 -> 59-60 us), profiles/round3/*persistent*256x128*
-            if (shape == 30) return launch_lp<EPI, 4>(p, stream);
-            if (shape == 32) return launch_lp<EPI, 3, 4, 4, 4, 2>(p, stream);
-            if (shape == 33) return launch_lp<EPI, 3, 4, 4, 2, 4>(p, stream);
-#else
-            GTAV_REQUIRE(shape == 31, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
-#endif
-            return launch_lp<EPI, 3>(p, stream);
+            return launch_lp<EPI, 3>(p, stream);   // (30 / 32 / 33 — 4-stage ring, 256 x 128 / 128 x 256 tiles — were handled above in the experiments build)
         } else {
             GTAV_REQUIRE(false, "gemm: the persistent loader-wave kernel (shape %d) has no epilogue %d", shape, (int)EPI);
         }
@@ -3319,15 +2966,6 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     // 128 x 144 (nine 16-token groups: one 144-token frame per row tile), 12 compute waves of 32 x 48 + 4 loader waves (round 4): M = 1152, the context-cached
     // step at batch 8, is 8 x 32 = 256 tiles for fc1 / 4-slice fc2 where the 128 x 128 grid has 288 (1.1 rounds)
     if (shape == 29) return launch_l<EPI, 4, 2, 3, 4, 3, 4>(p, splitk, stream);
-#ifdef GTAV_EXPERIMENTS
-    // measured slower than the shapes the heuristic picks: kept for A/B runs in the experiments build only
-    if (shape == 21) return launch_l<EPI, 3, 4, 4, 4, 2, 4>(p, splitk, stream);   // 256 x 128, 8 compute + 4 loader waves
-    if (shape == 23) return launch_l<EPI, 4, 4, 3, 2, 2, 4>(p, splitk, stream);   // 128 x 96, 4 compute waves of 64 x 48 + 4 loader waves
-    if (shape == 25) return launch_l<EPI, 5, 2, 3, 4, 2, 4>(p, splitk, stream);   // shape 20 with a 5-stage ring (140 KiB)
-#else
-    GTAV_REQUIRE(shape != 8 && shape != 9 && shape != 16 && shape != 21 && shape != 23 && shape != 25,
-                 "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
-#endif
     }
     // (a 128 x 128 loader-wave tile — 8 compute waves of 32 x 64 — was 12 % faster than shape 3 back to back and equal in the training step's
     // weight-gradient GEMMs, which are bound by the fabric traffic of their 118 MB of operands: not kept)
@@ -3335,17 +2973,6 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     // 256 x 144 with 8 / 6 waves of 128 x 48 / 96 x 48 — and the 256 x 128 loader-wave tile, shape 21: all correct, all 5-30 %
     // SLOWER than the two-blocks-per-CU 128 x 192 tile at M = 5760 / 11 520, profiles/round2/gemm_large_tile_*.txt: without a
     // co-resident block the prologue and epilogue of every tile are exposed.  The 1-block shapes 30-32 were removed again.)
-#ifdef GTAV_EXPERIMENTS
-    if (shape == 16 && !FOLDISH) {
-        if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_QKV || EPI == EPI_RESID) {
-            GTAV_REQUIRE(gemm_pp_ok(p.M, p.N, p.K, EPI) || (p.K / TK >= 12 && p.M % 8 == 0 && p.N % 8 == 0),
-                         "gemm: the ping-pong kernel needs K >= 768, M %% 8 == 0, N %% 8 == 0 (M=%d N=%d K=%d)", p.M, p.N, p.K);
-            return launch_pp<EPI>(p, stream);
-        } else {
-            GTAV_REQUIRE(false, "gemm: the ping-pong kernel (shape 16) has no epilogue %d", (int)EPI);
-        }
-    }
-#endif
     if (shape == 14) {         // 64 features x 96 tokens, 6 waves: a few hundred tokens (M = 288-320)
         set_gn(96, 64);
         const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 64) * splitk);
@@ -3363,22 +2990,6 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
         set_gn(48, 64);
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384));   // 6 stages measured 6-8 % slower
-#ifdef GTAV_EXPERIMENTS
-    } else if (shape == 9) {   // 128 features x 96 tokens, 6 waves
-        if constexpr (!FOLDISH) {
-            set_gn(96, 128);
-            const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 128) * splitk);
-            GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 4, 2, 3>), grid, dim3(384));   // 3 stages 1-3 % and 5 stages 4-5 % slower
-        }
-    } else if (shape == 8) {   // 96 x 96, 6 waves
-        if constexpr (FOLDISH || EPI == EPI_GELU_TANH || EPI == EPI_GELU_ERF || EPI == EPI_F16_TILED) {
-            GTAV_REQUIRE(false, "gemm: the 96-feature tile has no tile-major (GELU) epilogue");
-        } else {
-            set_gn(96, 96);
-            const dim3 grid(cdiv(p.M, 96) * cdiv(p.N, 96) * splitk);
-            GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 3, 2, 3>), grid, dim3(384));
-        }
-#endif
     } else if (shape == 7) {
 #ifndef GTAV_EXPERIMENTS
         if constexpr (EPI == EPI_QKV) {   // 15 spilled registers and never selected by the heuristic
