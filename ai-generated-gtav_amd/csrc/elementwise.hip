@@ -663,7 +663,7 @@ static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
 // forward_ab_B1_ln_wave_row.txt: the 16 dependent DPP reductions of one wave cost more than the barriers they replace.  Removed.)
 
 #define LN_LAUNCH_(MODE, PEND, NV, P0, P1, STRIDE, ROWS, RPM) \
-    hipLaunchKernelGGL((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)
+    GTAV_LAUNCH((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)   /* (GTAV_LAUNCH: the profiler's events ride on the dispatch) */
 #define LN_DISPATCH(MODE, P0, P1, STRIDE, ROWS, RPM)                                                     \
     do {                                                                                                  \
         LnPending pd_;                                                                                    \

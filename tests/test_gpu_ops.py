@@ -397,6 +397,59 @@ def test_gemm_splitk_partials_reduced_by_layernorm(M, N, K, splitk):
     assert rel_l2(untile(out, M, N).float(), ref) < 5e-4
 
 
+@pytest.mark.parametrize("M,K,splitk", [(720, 4096, 4), (1152, 4096, 4), (720, 1024, 2)])
+def test_inplace_pending_layernorm_is_bit_reproducible(M, K, splitk):
+    """VERDICT r3 #6 / ADVICE r3: the LayerNorm that applies a pending split-K update IN PLACE — `resid += gate (sum of slabs + bias)` written back to the
+    row it then normalises (ln_row_block_kernel<*, true>: every thread stores its chunk of the row behind the statistics' barrier) — 50 runs from the same
+    inputs must agree bit for bit in both outputs (the updated residual and the fp16 operand); a store that overtakes another thread's read of the row, or a
+    slab read before its GEMM's store, shows up as run-to-run differences.  Shapes: fc2 / out-proj of the batch-1 window step and of the batch-8 cached step."""
+    N, P = 1024, 144
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    resid = _rand(M, N, seed=4)
+    mod = _rand(M // P, 3 * N, seed=5)
+    w16, xd, bd, md = pad_weight_f16(w), to_tiled_f16(x), b.to(dev()), mod.to(dev())
+    first = None
+    for r in range(50):
+        rd = resid.clone().to(dev())
+        parts = torch.full((splitk, M, N), float("nan"), device=dev())
+        out = torch.zeros((M + 127) // 128 * 128, N, device=dev(), dtype=torch.float16)
+        L.check(L.load().gtav_op_gemm_splitk_ln(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), M, N, K, splitk, parts.data_ptr(),
+                                                rd.data_ptr(), md.data_ptr(), 3 * N, P, out.data_ptr(), md[:, N:].data_ptr(),
+                                                md[:, 2 * N:].data_ptr(), 3 * N, stream()))
+        if first is None:
+            first = (rd.clone(), out.clone())
+            y = x.float() @ w.half().float().t() + b
+            assert rel_l2(rd, resid + mod[:, :N].repeat_interleave(P, 0) * y) < 2e-5
+        else:
+            assert torch.equal(rd, first[0]) and torch.equal(out, first[1]), r
+
+
+@pytest.mark.parametrize("M,K", [(5760, 1024), (5760, 4096)])
+def test_inplace_residual_persistent_epilogue_is_bit_reproducible(M, K):
+    """the in-place gated residual epilogue of the persistent loader-wave kernel (shape 31, EPI_RESID: the residual tile is requested at the head of
+    the tile's K loop, bias / gate rows staged in LDS by tile parity) as the batch-8 forward runs it (out-proj K = 1024, fc2 K = 4096, 144-token frames): 50 runs
+    from the same residual must agree bit for bit."""
+    lib = L.load()
+    N, P = 1024, 144
+    x = _rand(M, K, seed=1).half()
+    w = _rand(N, K, scale=1 / math.sqrt(K), seed=2)
+    b = _rand(N, seed=3)
+    resid, gate = _rand(M, N, seed=4), _rand(M // P, N, seed=5)
+    w16, xd, bd, gd = pad_weight_f16(w), to_tiled_f16(x), b.to(dev()), gate.to(dev())
+    assert lib.gtav_op_gemm_resid_inplace(M, N, K) == 1          # the heuristic's own choice at this size
+    first = None
+    for r in range(50):
+        rd = resid.clone().to(dev())
+        L.check(lib.gtav_op_gemm_f16(xd.data_ptr(), K, w16.data_ptr(), bd.data_ptr(), rd.data_ptr(), N, M, N, K, 4, gd.data_ptr(), N, P, stream()))
+        if first is None:
+            first = rd.clone()
+            assert rel_l2(rd, resid + gate.repeat_interleave(P, dim=0) * (x.float() @ w.half().float().t() + b)) < 2e-5
+        else:
+            assert torch.equal(rd, first), r
+
+
 @pytest.mark.parametrize("ns", [2, 4])
 def test_gemm_pipeline_depths_agree(ns):
     """Both LDS ring depths (2 and 4 stages) of the GEMM give the same result, incl. K as short as one tile."""

@@ -1,7 +1,7 @@
 // Torch-free driver for rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on the four GEMM classes of a DiT half-block, through the
 // C-ABI exactly as the model launches them: to_qkv (spatial layout + RoPE epilogue), out-proj and fc2 (split-K slabs, the model's K-slice
-// heuristic), fc1 (GELU epilogue); M = 720 (batch-1 window step) and M = 5760 (batch 8); rotating weight buffers.  Dispatch order is fixed —
-// for M in {720, 5760}: qkv, out, fc1, fc2, `iters` launches each — and tools/gemm_traffic.py segments the counter rows by that order.
+// heuristic), fc1 (GELU epilogue); M = 720 (batch-1 window step), M = 1152 (batch-8 context-cached step) and M = 5760 (batch-8 window step); rotating weight
+// buffers.  Dispatch order is fixed — for M in {720, 1152, 5760}: qkv, out, fc1, fc2, `iters` launches each — and tools/gemm_traffic.py segments the counter rows by that order.
 //   hipcc -O2 tools/gemm_pmc.cpp -Iinclude -L ai-generated-gtav_amd -lgtav_amd -Wl,-rpath,'$ORIGIN/../ai-generated-gtav_amd' -o tools/gemm_pmc
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- ./tools/gemm_pmc 16
 #include <hip/hip_runtime.h>
@@ -15,7 +15,7 @@
 
 int main(int argc, char** argv) {
     const int D = 1024, H = 4096, copies = 8, iters = argc > 1 ? atoi(argv[1]) : 16;
-    const int Ms[2] = {720, 5760};
+    const int Ms[3] = {720, 1152, 5760};
     std::vector<unsigned short> host((size_t)H * D);
     for (size_t i = 0; i < host.size(); ++i) host[i] = 0x2000 + (unsigned short)((i * 2654435761u) >> 20 & 0x3ff);  // small fp16 values
     std::vector<void*> w(copies);
@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < one.size(); ++i) one[i] = (i & 1) ? 0.f : 1.f;     // (cos, sin) = (1, 0): identity rotation
         CK(hipMemcpy(cs, one.data(), one.size() * 4, hipMemcpyHostToDevice));
     }
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 3; ++mi) {
         const int M = Ms[mi], Mp = (M + 127) / 128 * 128;
         void *x, *xh, *q, *k, *v, *hb, *parts;
         CK(hipMalloc(&x, (size_t)Mp * D * 2));

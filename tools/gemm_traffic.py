@@ -1,5 +1,5 @@
 """Second half of tools/gemm_traffic.sh: rocprofv3 counter_collection csv files -> profiles/traffic.json.
-tools/gemm_pmc dispatches, for M in (720, 5760): qkv, out, fc1, fc2 — ITERS launches each; the rows are segmented by dispatch order."""
+tools/gemm_pmc dispatches, for M in (720, 1152, 5760): qkv, out, fc1, fc2 — ITERS launches each; the rows are segmented by dispatch order."""
 import csv
 import glob
 import hashlib
@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ITERS = 16
 CLASSES = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
-MS = (720, 5760)
+MS = (720, 1152, 5760)
 
 
 def rows_by_dispatch(outdir, sub, counters):
