@@ -673,11 +673,9 @@ static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
         pd_.err_flag = err_flag;                                                                          \
         const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
         GTAV_REQUIRE(pd_.tperm_T == 0 || (M <= g_ln_rowblock_max && pd_.tperm_P % 16 == 0 && M % (pd_.tperm_T * pd_.tperm_P) == 0), "ln: bad output row permutation"); \
-        /* Round 4: WITHOUT a pending slab update (the large-M steps whose residual GEMMs update the residual in place) a few thousand rows run faster */ \
-        /* on the wave-per-row kernel — no LDS, no block barrier, four rows per block, every row of M = 5760 resident at once: 10.2 -> 4.6 us per launch */ \
-        /* in the batch-8 forward (profiles/round4/layernorm_wave_per_row_large_M.txt).  With slabs, or at ~1000 rows, the row-block kernel stays.      */ \
-        const bool wave_rows_ = !pend && M >= 2048 && g_ln_rowblock_max == (1 << 30);                                 \
-        if (M <= g_ln_rowblock_max && !wave_rows_) { /* one block per row */                                          \
+        /* (Round 4 re-measured the wave-per-row kernel for the large-M steps without pending slabs: 10.1 us against 10.2 us per launch at M = 5760 — a tie;   */ \
+        /* a first reading of "4.6 us" was the profiler's empty event pair: that kernel's launch did not carry the events.  profiles/round4/layernorm_*.txt)   */ \
+        if (M <= g_ln_rowblock_max) { /* one block per row */                                                         \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
             if (pend) GTAV_LAUNCH((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
             else GTAV_LAUNCH((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
