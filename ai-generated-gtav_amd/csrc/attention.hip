@@ -200,6 +200,158 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __rest
     }
 }
 
+// The same attention for SHORT sequences (S_pad = 16 NK <= 160 keys: the DiT's 144 patch tokens per frame; round 4) in ONE pass per query tile: the scores of
+// all NK key tiles live in registers (4 NK floats per lane), one row maximum, one exponential per score, then the PV products — no online-softmax rescale
+// and no dependency between key blocks.  The online kernel above walks a query tile as three serial (QK^T -> max -> exp -> rescale -> PV) rounds of ~1 800 cycles
+// each, and with 2.5 four-wave blocks per CU at batch 8 nothing hides that chain: 17.7 us per launch against a 9.4 us traffic floor.  Same staging, same MFMA
+// operand maps; softmax(QK^T / 8) V is computed with one fp32 rounding order for every batch size and both sampling algorithms (the kernel is chosen by S alone).
+template <int NW, int NK>
+__global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
+                                                              const f16* __restrict__ Vt, f16* __restrict__ O, int heads, int S,
+                                                              int qsplit, int sc1) {
+    constexpr int S_pad = 16 * NK;
+    static_assert(NK % 2 == 0 && NK <= 10, "an even number of 16-key tiles, at most 160 keys");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                              // [S_pad][128 B], 16-B chunk c of row r stored at c ^ (r & 7)
+    constexpr int vstride = (S_pad + 8) * 2;      // bytes per Vt row
+    char* Vs = smem + (size_t)S_pad * 128;        // [64][S_pad + 8] halves
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x;                    // nb * heads + head
+    const int nb = bh / heads, head = bh - nb * heads;
+    const f16* Kg = K + (size_t)bh * S * 64;
+    const f16* Vg = Vt + (size_t)bh * 64 * S;
+    const f16* Qg = Q + (size_t)bh * S * 64;
+    const int nqt = (S + 15) >> 4;
+    constexpr int NT = 64 * NW;
+    const int qt_first = blockIdx.y * NW + w;
+    f16x8 qpre[2] = {};
+    if (qt_first < nqt) {
+        int qr = qt_first * 16 + li;
+        qr = qr < S ? qr : S - 1;
+        qpre[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
+        qpre[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+    }
+    {   // stage K (swizzled) and Vt (padded), zero the padding: every load of a batch before the first LDS write (one memory round trip)
+        constexpr int nk = S_pad * 8, vchunks = (S_pad + 8) / 8, nv = 64 * vchunks, nmax = nk > nv ? nk : nv;
+        for (int base = tid; base < nmax; base += NT * 6) {
+            uint4 kv[6], vv[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * NT;
+                kv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nk && (idx >> 3) < S) kv[u] = *(const uint4*)(Kg + (size_t)(idx >> 3) * 64 + (idx & 7) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * NT;
+                vv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < nv) {
+                    const int d = idx / vchunks, c = idx - d * vchunks;
+                    if (c * 8 < S) vv[u] = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * NT;
+                if (idx < nk) {
+                    const int r = idx >> 3, c = idx & 7;
+                    *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = kv[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const int idx = base + u * NT;
+                if (idx < nv) {
+                    const int d = idx / vchunks, c = idx - d * vchunks;
+                    *(uint4*)(Vs + d * vstride + c * 16) = vv[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int Dm = heads * 64;
+    for (int qt = qt_first; qt < nqt; qt += NW * qsplit) {
+        const int q0 = qt * 16;
+        f16x8 qf[2];
+        if (qt == qt_first) {
+            qf[0] = qpre[0];
+            qf[1] = qpre[1];
+        } else {
+            int qr = q0 + li;
+            qr = qr < S ? qr : S - 1;
+            qf[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
+            qf[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+        }
+        // S^T = K Q^T for every key tile: NK independent accumulators
+        f32x4 sc[NK];
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            const int key = kt * 16 + li;
+            const char* kr = Ks + key * 128;
+            const f16x8 k0 = *(const f16x8*)(kr + (((0 + g) ^ (key & 7)) << 4));
+            const f16x8 k1 = *(const f16x8*)(kr + (((4 + g) ^ (key & 7)) << 4));
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], sc[kt], 0, 0, 0);
+        }
+        // padded keys (only the last tiles can hold any) never win the maximum and contribute exp2(-inf) = 0
+        float bmax = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 15 >= S && kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
+                bmax = fmaxf(bmax, sc[kt][r]);
+            }
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f((sc[kt][r] - bmax) * kScaleLog2e);   // raw v_exp_f32: argument <= 0
+                sc[kt][r] = pv;
+                psum += pv;
+            }
+        // O^T = Vt P^T, 32 keys per step; P^T straight from the score registers (k-slot j of the B operand <-> key 32 s + 16 (j >> 2) + 4 g + (j & 3))
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < NK / 2; ++s2) {
+            f16x8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (f16)sc[2 * s2][r];
+                pf[4 + r] = (f16)sc[2 * s2 + 1][r];
+            }
+            const int kcol = (32 * s2 + 4 * g) * 2;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char* vr = Vs + (dt * 16 + li) * vstride + kcol;
+                union { f16x8 v8; f16x4 v4[2]; } vf;
+                vf.v4[0] = *(const f16x4*)(vr);
+                vf.v4[1] = *(const f16x4*)(vr + 32);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v8, pf, o[dt], 0, 0, 0);
+            }
+        }
+        float lt = psum + __shfl_xor(psum, 16, 64);
+        lt = lt + __shfl_xor(lt, 32, 64);
+        const float inv = 1.0f / lt;
+        if (q0 + li < S) {
+            const int mrow = nb * S + q0 + li;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (f16)(o[dt][r] * inv);
+                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1);
+            }
+        }
+    }
+}
+
 // One thread per 8 consecutive features (16-byte loads / stores; 8 lanes per head), D/8 threads per (b, p) column and as many
 // columns per block as fit in 256 threads; grid = (column groups, query-frame group): with `split` every query frame of a column
 // gets its own block, which loads only the K / V frames its causal mask admits — five times as many independent blocks for the
@@ -300,6 +452,26 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
     // many frames: 9 tiles in one round instead of 4 + 4 + 1) — each wave is a serial QK^T -> softmax -> PV chain
     static const int wide = GTAV_ENV_INT("GTAV_ATTN_S_WIDE", 0);   // measured neutral at B = 8 (0.41 vs 0.42 ms per forward): off
     dim3 grid(NB * heads, qsplit);
+    if (S_pad <= 160) {   // short sequences (the DiT's frames): one pass per query tile, scores in registers
+        const int nk = S_pad / 16;
+#define GTAV_ATTN_1P(NK_)                                                                                                               \
+        do {                                                                                                                          \
+            static unsigned long long devs_ = 0;                                                                                      \
+            if (!(devs_ >> (devid & 63) & 1)) {                                                                                       \
+                GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_1p_kernel<4, NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                devs_ |= 1ull << (devid & 63);                                                                                        \
+            }                                                                                                                         \
+            GTAV_LAUNCH((attn_spatial_1p_kernel<4, NK_>), grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, qsplit, g_attn_sc1);   \
+        } while (0)
+        if (nk == 2) GTAV_ATTN_1P(2);
+        else if (nk == 4) GTAV_ATTN_1P(4);
+        else if (nk == 6) GTAV_ATTN_1P(6);
+        else if (nk == 8) GTAV_ATTN_1P(8);
+        else GTAV_ATTN_1P(10);
+#undef GTAV_ATTN_1P
+        GTAV_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (wide && cdiv(nqt, qsplit) > 4)
         GTAV_LAUNCH(attn_spatial_kernel<9>, grid, dim3(576), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
     else
