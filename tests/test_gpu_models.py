@@ -136,6 +136,32 @@ def test_fused_temporal_qkv_attention_is_bit_identical(full_dit):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
+    """gtav_dit_set_weight_prefetch (round 4): the next-weight L2 prefetch of the small-M GEMMs changes no arithmetic — a captured batch-1 window step with it on
+    and off gives EQUAL latents — and generate.tune_weight_prefetch times both settings, leaves the model on the faster one and reports the choice."""
+    from gtav_amd.generate import tune_weight_prefetch
+    from gtav_amd.utils import alphas_cumprod
+    m, _, _ = full_dit
+    g = torch.Generator().manual_seed(17)
+    x0 = (torch.randn(1, 5, 16, 18, 32, generator=g) * 0.5).to(dev())
+    m.set_schedule(alphas_cumprod(1e-4))
+    outs = []
+    try:
+        for on in (True, False):
+            m.set_weight_prefetch(on)
+            x = x0.clone()
+            for k in range(4):                       # eager warm-up, capture, two replays
+                m.denoise_step_(x, 0, 4, 15, 900 - 10 * k, 890 - 10 * k, False, None)
+            outs.append(x.clone())
+        assert torch.equal(outs[0], outs[1])
+        r = tune_weight_prefetch(m, 1, steps=6, rounds=1)
+        assert r["chosen"] in ("on", "off") and r["on_ms"] > 0 and r["off_ms"] > 0
+        print("weight prefetch on / off (ms per step):", r)
+    finally:
+        m.set_weight_prefetch(True)
+    m.check()
+
+
 def test_denoise_step_mirror_and_fused_and_cached():
     from gtav_amd.sampler import denoise_step
     from gtav_amd.utils import alphas_cumprod
