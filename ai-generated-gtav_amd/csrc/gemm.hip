@@ -9,7 +9,11 @@
 //   gemm_g_kernel   piece-granular tiles that may start on any 8-row boundary: 128 x 96, 96 x 96, 64 x 48 (small M),
 //                   128 x 192 (large M, two blocks per CU)                                     mainloop_g
 //   gemm256_kernel  256 x 256 tile, K-tile in four quadrant phases                             mainloop256
-// launch_gemm() picks the shape per launch from a cost model / measured thresholds (bottom of this file).
+//   gemm_l_kernel   loader-wave tiles (small and medium M: 128 x 96, 64 x 48 / 96, 128 x 144)   mainloop_l
+//   gemm_lp_kernel  persistent loader-wave kernel, 128 x 192 tiles (large-M residual GEMMs, in-place residual epilogue)
+//   gemm_p256_kernel persistent 192 x 256 tiles with a K split of the remainder (round 4: a tested alternative, not selected)
+// launch_gemm() picks the shape per launch from a cost model / measured thresholds (bottom of this file).  Kernels, launchers and block shapes that only
+// ever measured slower live in gemm_experiments.inc, which only `build.sh exp` compiles.
 //
 // Orientation: the MFMA "A" operand is the W tile and "B" the X tile, so D[row = feature][col = token]:
 // every lane owns 4 CONSECUTIVE FEATURES of one token -> RoPE pairs, float4 bias/gate/residual and
