@@ -50,6 +50,16 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
+// 16-byte store at a wave-uniform base + a 32-bit per-lane offset (no 64-bit per-lane address in VGPRs)
+__device__ __forceinline__ void store16_soff(const void* sbase, unsigned voff, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+// one dword per lane (64 separate lines if the lanes say so) into 256 bytes of LDS: an L2 "touch" that writes no VGPR
+__device__ __forceinline__ void glds4_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
 
 __device__ __forceinline__ void store16q_sc1(void* dst, uint4 v) { store16_sc1(dst, u32x4{v.x, v.y, v.z, v.w}); }
@@ -2458,7 +2468,7 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
     for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) { if (!GTAV_DBG(p, 2)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0); };   // (debug bit 1: no MFMAs)
+    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0); };
 
     // the unit being computed; its bias slice (TNB floats, one 16-byte chunk per thread) is requested at its head and goes through LDS in the epilogue
     int cu = 0, ck = 0, cnk = unit_field(0, 3);
@@ -2521,71 +2531,66 @@ __global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
         asm volatile("" : "+v"(lo));
         int woff[2], xoff[2];
         frag_offsets(lo, woff, xoff);
+        // Third form: NOTHING is issued in a clump.  The second form put a phase's fragment reads (up to 10 per wave) and its fills (3-4 per wave) in front of
+        // its MFMAs: eight waves then queue at the LDS (4 cycles per read) and at the address pipe (16 cycles per 1 KiB piece) at the same moment and none of
+        // them feeds the matrix pipe meanwhile.  Here every MFMA of a phase carries at most one read in its issue shadow, and a wave's pieces are spread
+        // over the phase, one per three or four MFMAs (waves 0-3 in front of the group, their SIMD partners 4-7 behind it).
+        auto mm1 = [&](const f16x8 (&wf)[2][FIH], const f16x8 (&xf)[2][2], int m, int io, int jo) {   // the m-th of a phase's 4 FIH MFMAs
+            const int sh = m / (2 * FIH), i = (m >> 1) % FIH, j = m & 1;
+            mma(wf[sh][i], xf[sh][j], acc[io + i][jo + j]);
+        };
+        constexpr int NM = 4 * FIH;
         // ---- phase 1 ----
 #pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) xb[sh][j] = *(const f16x8*)(bb + xoff[sh] + (2 + j) * 16 * 128);
-#pragma unroll
-        for (int i = 0; i < FIH; ++i) wb[0][i] = *(const f16x8*)(bb + woff[0] + (FIH + i) * 16 * 128);
-        // (sched_barrier: the reads of a phase are ISSUED in front of its MFMAs and not sunk next to their first use — at the register limit hipcc's scheduler
-        // otherwise moves every read down to the MFMA that consumes it, which puts the LDS round trip back on the critical path)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-            for (int i = 0; i < FIH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(wa[sh][i], xa[sh][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < NM; ++m) {
+            mm1(wa, xa, m, 0, 0);
+            if (m < 4) xb[m >> 1][m & 1] = *(const f16x8*)(bb + xoff[m >> 1] + (2 + (m & 1)) * 16 * 128);
+            else if (m < 4 + FIH) wb[0][m - 4] = *(const f16x8*)(bb + woff[0] + (FIH + m - 4) * 16 * 128);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- phase 2 ----
 #pragma unroll
-        for (int i = 0; i < FIH; ++i) wb[1][i] = *(const f16x8*)(bb + woff[1] + (FIH + i) * 16 * 128);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-            for (int i = 0; i < FIH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(wa[sh][i], xb[sh][j], acc[i][2 + j]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int m = 0; m < NM; ++m) {
+            mm1(wa, xb, m, 0, 2);
+            if (m < FIH) wb[1][m] = *(const f16x8*)(bb + woff[1] + (FIH + m) * 16 * 128);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (b): every wave has read this parity's fragments
-        // ---- phase 3 ----
-        // A fill instruction holds its wave until the CU's address pipe has taken it (64 B/clk: the 32 + 24 pieces of a K-tile are ~900 cycles of that pipe), and
-        // with all eight waves issuing in the same phase every wave sat in that queue IN FRONT of its MFMAs (tools/gemm_stamps.py, debug bits: fills 0.41 us of a
-        // 1.46 us K-tile).  Waves 4-7 — the SIMD partners of waves 0-3 — issue their pieces BEHIND their MFMAs instead: while one wave of a SIMD queues, the
-        // other one feeds the matrix pipe.  Every wave's own order of fills and waits is unchanged.
-        if (n2 && !late) { issueX(FIRST); issueX(SECOND); advX(); }
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 3: the four X pieces of K-tile g + 2 go into this parity ----
+        {
+            const unsigned d = smem0 + (unsigned)(xi & 1) * C::PAR + C::WREG + (unsigned)w * 1024u;
+            const unsigned go = (unsigned)xk * (unsigned)TILE_BYTES;
 #pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-            for (int i = 0; i < FIH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(wb[sh][i], xb[sh][j], acc[FIH + i][2 + j]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (n2 && late) { issueX(FIRST); issueX(SECOND); advX(); }
+            for (int m = 0; m < NM; ++m) {
+                constexpr int PER = NM / 4;
+                if (m % PER == 0 && n2 && !late) glds16_s(p.X, voff + (xso[m / PER] + go), d + (m / PER) * 8192);
+                mm1(wb, xb, m, FIH, 2);
+                if (m % PER == PER - 1 && n2 && late) glds16_s(p.X, voff + (xso[m / PER] + go), d + (m / PER) * 8192);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (n2) advX();
+        }
         if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a): everything but X(g + 2) has landed = K-tile g + 1 complete
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- phase 4 ----
+        // ---- phase 4: next K-tile's first fragments from the other parity; the W pieces of K-tile g + 2 into this one ----
+        {
+            const unsigned d = smem0 + (unsigned)(wi & 1) * C::PAR + (unsigned)w * 1024u;
+            const unsigned go = (unsigned)wk * (unsigned)TILE_BYTES;
 #pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-#pragma unroll
-            for (int i = 0; i < FIH; ++i) wnx[sh][i] = *(const f16x8*)(bn + woff[sh] + i * 16 * 128);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) xnx[sh][j] = *(const f16x8*)(bn + xoff[sh] + j * 16 * 128);
+            for (int m = 0; m < NM; ++m) {
+                constexpr int PER = NM / NWQ;
+                if (m % PER == 0 && m / PER < NWQ && n2 && !late) glds16_s(p.W, voff + (wso[m / PER] + go), d + (m / PER) * 8192);
+                mm1(wb, xa, m, FIH, 0);
+                if (m < 2 * (FIH + 2)) {   // in the order phase 1 consumes them: the first K half's X and W fragments, then the second half's
+                    const int sh = m / (FIH + 2), q = m % (FIH + 2);
+                    if (q < 2) xnx[sh][q] = *(const f16x8*)(bn + xoff[sh] + q * 16 * 128);
+                    else wnx[sh][q - 2] = *(const f16x8*)(bn + woff[sh] + (q - 2) * 16 * 128);
+                }
+                if (m % PER == PER - 1 && m / PER < NWQ && n2 && late) glds16_s(p.W, voff + (wso[m / PER] + go), d + (m / PER) * 8192);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (n2) advW();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n2 && !late) { issueW(FIRST); issueW(SECOND); advW(); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh)
-#pragma unroll
-            for (int i = 0; i < FIH; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma(wb[sh][i], xa[sh][j], acc[FIH + i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (n2 && late) { issueW(FIRST); issueW(SECOND); advW(); }
     };
     for (int g = 0; g < S; g += 2) {
         ktile(g, wA, xA, wB, xB);
@@ -2941,14 +2946,14 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if (shape == 24) return launch_l<EPI, 4, 2, 1, 2, 3, 2>(p, splitk, stream);   // 64 x 48, 6 compute + 2 loader waves (the skinny shape 11 on the loader-wave kernel)
     if (shape == 26) return launch_l<EPI, 4, 2, 2, 2, 3, 2>(p, splitk, stream);   // 64 x 96, 6 compute + 2 loader waves (shape 14 likewise)
 #ifdef GTAV_EXPERIMENTS
-    {   // shapes that exist only in the experiments build (8, 9, 16, 21, 23, 25, 27, 28, 30, 32, 33, 40): gemm_experiments.inc
+    {   // shapes that exist only in the experiments build (8, 9, 16, 21, 23, 25, 27, 28, 30, 32, 33, 40, 42): gemm_experiments.inc
         bool handled = false;
         const int rc_ = launch_experiment_shape<EPI>(p, ns, shape, splitk, stream, handled);
         if (handled) return rc_;
     }
 #else
     GTAV_REQUIRE(shape != 8 && shape != 9 && shape != 16 && shape != 21 && shape != 23 && shape != 25 && shape != 27 && shape != 28 && shape != 30 && shape != 32 &&
-                 shape != 33 && shape != 40, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
+                 shape != 33 && shape != 40 && shape != 42, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
 #endif
     if (shape == 41) {   // persistent 256-token tiles (round 4): 192 x 256 (N x M)
         if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {

@@ -523,7 +523,7 @@ def test_gemm_other_tiles_all_epilogues(shape):
 @pytest.mark.parametrize("M,N,K", [(5760, 4096, 1024), (5760, 3072, 1024), (2312, 384, 896), (192, 128, 128), (11520, 1024, 1024), (100, 256, 128),
                                    (700, 192, 384), (1152, 4096, 256)])
 def test_persistent_256_token_tile_kernel(shape, M, N, K):
-    """Block shape 41 (round 4; 40, its 256 x 256 form, lives in the experiments build): the persistent 256-token-tile kernel — one block per CU walks whole rounds of 192 x 256 tiles with the
+    """Block shape 41 (round 4; 40, its 256 x 256 form, and 42, the sixteen-wave 256 x 256 form, live in the experiments build and passed this test there): the persistent 256-token-tile kernel — one block per CU walks whole rounds of 192 x 256 tiles with the
     two-parity LDS ring running on across tile boundaries, epilogue straight from the accumulators; a remainder of at most half a round of tiles is split in
     two K halves whose partial sums change hands through a workspace and a flag (agent-scope release / acquire).  Cases: two whole rounds (506 tiles), one
     round + split remainder (368 tiles: 256 + 112 split), fewer tiles than CUs with every tile split (20 and 14 tiles), a handful of tiles with K too short to

@@ -115,7 +115,7 @@ def main():
                 print(f"      epilogue:                                med {pct(epi_, .5):5.2f} p90 {pct(epi_, .9):5.2f} us")
                 print(f"      block total:                             med {pct(tot, .5):5.2f} p90 {pct(tot, .9):5.2f} us   (sum of block time / 256 CUs / span = "
                       f"{float(tot.sum()) / 256 / span_us:.2f} blocks resident per CU on average)")
-                if int(lstart.max()) != 0 and wm in (40, 41):   # persistent 256-token tiles: slot 7 = the block's end (all its units); the phases above are its FIRST unit
+                if int(lstart.max()) != 0 and wm in (40, 41, 42):   # persistent 256-token tiles: slot 7 = the block's end (all its units); the phases above are its FIRST unit
                     print(f"      whole block (all units): med {pct(f(lstart - t0), .5):6.2f} p90 {pct(f(lstart - t0), .9):6.2f} us; first unit's share: main {pct(main_, .5):5.2f} + epilogue {pct(epi_, .5):5.2f}")
                 print(f"      resident blocks by phase, averaged over the span: prologue {inp.mean():6.1f}  main {inm.mean():6.1f}  epilogue {ine.mean():6.1f}"
                       f"   | time with NO block in its main loop: {float((inm == 0).double().mean()) * 100:4.1f} %")
