@@ -241,14 +241,22 @@ def rank_main(args):
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch
     have = torch.cuda.device_count()          # does not initialise the GPU
-    if have < world or not torch.cuda.is_available():
+    # Rehearsal of the N > 1 control flow on a ONE-GPU box (tools/bench_rehearsal.sh): every rank uses cuda:0 and the collectives run over gloo.  Its numbers mean
+    # nothing (the ranks share one GPU) and the line says so; RCCL itself refuses two ranks on one device.
+    rehearse = os.environ.get("GTAV_BENCH_REHEARSE_ONE_GPU") == "1" and world > 1
+    if rehearse:
+        local_rank = 0
+    if have < (1 if rehearse else world) or not torch.cuda.is_available():
         sys.stderr.write(f"bench.py rank {rank}/{world}: needs {world} GPUs, this host has {have}; there is no CPU fallback for the product path\n")
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
     try:
         if args.mode in ("train", "train_step"):
@@ -674,7 +682,8 @@ def bench_generate(args, world, rank, dev, dist, torch):
             "metric": "generated frames/sec (32-frame clip, 100 noise steps)", "value": round(value, 4), "unit": "generated frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp16 (fp32 accumulate/residual)",
-            "data": "synthetic (seeded CPU-generated prompt frames + noise by global sample id, hash-seeded random weights incl. adaLN)",
+            "data": "synthetic (seeded CPU-generated prompt frames + noise by global sample id, hash-seeded random weights incl. adaLN)" +
+                    (" — REHEARSAL: all ranks on one GPU over gloo, the numbers mean nothing" if os.environ.get("GTAV_BENCH_REHEARSE_ONE_GPU") == "1" and world > 1 else ""),
             "config": {"workload": "BASELINE configs[%d]: %s, %d frames (%d prompt), %d noise steps, batch %d per GPU%s" %
                                    (2 if args.use_actions else 1, cfg_name, total, n_prompt, steps, B,
                                     ", action-conditioned" if args.use_actions else ", no actions"),
