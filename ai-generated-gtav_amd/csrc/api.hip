@@ -333,7 +333,7 @@ struct gtav_dit {
         f16 *xnF = nullptr, *xp = nullptr;
         float *z0 = nullptr, *cpre = nullptr;                   // pre-SiLU values of the conditioning path
         float *dres = nullptr, *dtmp = nullptr, *stats = nullptr, *dmod = nullptr, *dSc = nullptr, *ada_part = nullptr, *dc = nullptr, *dh0 = nullptr, *dz0 = nullptr;
-        f16 *g_d = nullptr, *g_h = nullptr, *g_u = nullptr, *g_qkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dfo = nullptr;
+        f16 *g_d = nullptr, *g_d2 = nullptr, *g_h = nullptr, *g_u = nullptr, *g_qkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dfo = nullptr;
         // grouped weight gradients (launch_gemm_dw_grouped): the transposed operand pairs of a half-block's four dW GEMMs (fc2, fc1, out-proj, QKV)
         // stay alive until its ONE grouped launch; null when the widths are not multiples of 256
         f16 *tAg[4] = {nullptr, nullptr, nullptr, nullptr}, *tBg[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -341,6 +341,7 @@ struct gtav_dit {
 };
 
 static int g_dw_grouped = GTAV_ENV_INT("GTAV_DW_GROUPED", 1);   // experiments build: 0 = one launch per weight gradient (A/B runs)
+static int g_dw_tn = GTAV_ENV_INT("GTAV_DW_TN", 1);             // experiments build: 0 = transposed operand copies in front of the grouped launch (A/B runs)
 
 // LayerNorm fold: tables, statistics and the grouped-GEMM descriptors, allocated by the first gtav_dit_set_fold that can fold anything
 static int fold_alloc(gtav_dit* h) {
@@ -1072,7 +1073,7 @@ int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena
     RET_IF(a.alloc_t(&t.dres, Mx * D)); RET_IF(a.alloc_t(&t.dtmp, Mx * D)); RET_IF(a.alloc_t(&t.stats, 2 * Mx));
     RET_IF(a.alloc_t(&t.dmod, R * h->MODW)); RET_IF(a.alloc_t(&t.dSc, R * D)); RET_IF(a.alloc_t(&t.ada_part, ada_bwd_dx_workspace(h->MODW, D, (int)R))); RET_IF(a.alloc_t(&t.dc, R * D)); RET_IF(a.alloc_t(&t.dh0, R * D));
     RET_IF(a.alloc_t(&t.dz0, R * D));
-    RET_IF(a.alloc_t(&t.g_d, Mx * D)); RET_IF(a.alloc_t(&t.g_h, Mx * Hp)); RET_IF(a.alloc_t(&t.g_u, Mx * Hp)); RET_IF(a.alloc_t(&t.g_qkv, Mx * 3 * D));
+    RET_IF(a.alloc_t(&t.g_d, Mx * D)); RET_IF(a.alloc_t(&t.g_d2, Mx * D)); RET_IF(a.alloc_t(&t.g_h, Mx * Hp)); RET_IF(a.alloc_t(&t.g_u, Mx * Hp)); RET_IF(a.alloc_t(&t.g_qkv, Mx * 3 * D));
     RET_IF(a.alloc_t(&t.dao, Mm * D)); RET_IF(a.alloc_t(&t.dfo, Mx * 64));
     const size_t widest = (size_t)(Hp > 3 * D ? Hp : 3 * D);
     RET_IF(a.alloc_t(&t.tA, widest * Mp)); RET_IF(a.alloc_t(&t.tB, widest * Mp));
@@ -1244,13 +1245,21 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
                                       {tr.tAg[3], tr.tBg[3], tr.dres, 3 * D, D, D}};
         defer_dw = gemm_dw_grouped_ok(probe, 4, Mp);
     }
+    // Whole 128-token row tiles: the grouped launch contracts over the rows of the tile-major operands THEMSELVES (transposing LDS reads, gemm.hip
+    // mainloop256_tn) — no transposed copies (8 of the 17 us transposes per half-block).  The operands must then live until flush_dw: the out-projection's
+    // dY gets a buffer of its own (g_d2), the saved activations and g_u / g_qkv are not rewritten inside a half-block.
+    const bool tn_dw = defer_dw && g_dw_tn && M % 128 == 0;
     auto flush_dw = [&]() -> int {
         if (!ndw) return 0;
         const int n = ndw;
         ndw = 0;
-        return launch_gemm_dw_grouped(dwg, n, Mp, h->err_flag, s);
+        return launch_gemm_dw_grouped(dwg, n, tn_dw ? M : Mp, h->err_flag, s, tn_dw);
     };
     auto gemm_dw = [&](const f16* dY, int N, const f16* X, int K, float* grad, int slot_i = -1) -> int {
+        if (tn_dw && slot_i >= 0) {
+            dwg[ndw++] = GemmDwGroup{dY, X, grad, N, K, K};
+            return 0;
+        }
         if (defer_dw && slot_i >= 0) {
             RET_IF(launch_transpose_tiled_f16(dY, M, N, tr.tAg[slot_i], s));
             RET_IF(launch_transpose_tiled_f16(X, M, K, tr.tBg[slot_i], s));
@@ -1328,11 +1337,12 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i + 1], mb + 4 * D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
         RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i + 1], tr.stats, NB, P, D, dmb + 3 * D, dmb + 4 * D, MODW, s));
         // r_{2i+1} = r_{2i} + gate_msa y1
-        RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
+        f16* const g_o = tn_dw ? tr.g_d2 : tr.g_d;   // (the fc2 weight gradient above still reads g_d when the grouped launch is deferred without copies)
+        RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, g_o, h->err_flag, s));
         RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
-        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, s));
-        RET_IF(gemm_dw(tr.g_d, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad, 2));
-        RET_IF(gemm_dx(tr.g_d, slot(P_ + "attn.to_out.weight").wT, D, D, EPI_F16, tr.dao, D));
+        RET_IF(launch_colsum_tiled_f16(g_o, M, D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, s));
+        RET_IF(gemm_dw(g_o, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad, 2));
+        RET_IF(gemm_dx(g_o, slot(P_ + "attn.to_out.weight").wT, D, D, EPI_F16, tr.dao, D));
         if (hf == 0) RET_IF(launch_attn_spatial_bwd(b.q, b.k, b.v, tr.dao, NB, h->heads, P, D, h->rope_s.cs_dev, tr.g_qkv, h->err_flag, s));
         else RET_IF(launch_attn_temporal_bwd(b.q, b.k, tr.dao, B, P, D, T, h->maxT, h->rope_t.cs_dev, tr.g_qkv, h->err_flag, s));
         RET_IF(gemm_dw(tr.g_qkv, 3 * D, b.xnA, D, slot(P_ + "attn.to_qkv.weight").grad, 3));

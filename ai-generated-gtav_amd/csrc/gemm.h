@@ -108,7 +108,8 @@ int launch_gemm_grouped(const GemmGroup* groups_dev, int n_groups, int max_N, in
 constexpr int GEMM_DW_MAX_GROUPS = 4;
 struct GemmDwGroup { const f16* X; const f16* W; float* out; int M; int N; int ldo; };
 bool gemm_dw_grouped_ok(const GemmDwGroup* g, int n, int K);
-int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hipStream_t stream);
+// tn = true: X / W are the operands themselves, tile-major [K tokens][M | N features] (no transposed copies; K % 128 == 0): gemm.hip mainloop256_tn
+int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hipStream_t stream, bool tn = false);
 
 // Enqueues the GEMM on `stream`. Returns 0 on success.
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);

@@ -1539,6 +1539,137 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     bs.end(p);
 }
 
+// mainloop256 for operands that are tile-major [tokens][features] with the contraction over the TOKENS (weight gradients: out[m][n] += sum_t X[t][m] W[t][n];
+// p.M = X features, p.N = W features, p.K = tokens; nct_x / nct_w = 64-feature column tiles per row tile of X / W) — no operand transposes.  Same four phases,
+// same fill schedule and barriers as mainloop256; what changes is the stage image and the fragment reads:
+//   * a K-tile is 64 tokens of 256 + 256 features: 64 pieces of [8 tokens][64 features] (1 KiB, copied verbatim: half of a source tile's column), pieces
+//     0-31 = W column tiles 0-3, 32-63 = X column tiles 0-3, at a stride of 1088 bytes (gemm_tn_kernel: with 1024 the two 16-lane groups of a transposing
+//     read's 32-lane half meet on the same banks); the four fill regions of mainloop256 are column-tile pairs (W 0-1, W 2-3, X 0-1, X 2-3), wave w copies
+//     two adjacent token pieces of column tile w / 4 of each;
+//   * a fragment (16 features x 32 tokens) is two ds_read_b64_tr_b16: lane (16 g + 4 q + pp) reads token row 32 sh + 8 g + 4 h + q, features 16 i + 4 pp ..,
+//     h = 0 / 1 (TnFrag, as gemm_tn_kernel).  Eight per-lane offsets (h, 16-byte chunk pair) serve every fragment of both operands: column tile and
+//     K half enter as immediates, the operand's piece base as one add.  The reads are inline asm (behind the builtin hipcc waits vmcnt(0) before every
+//     first read), so the LDS waits are counted by hand and name the fragments they retire.
+__device__ __forceinline__ void mainloop256_tn(const GemmParams& p, char* smem, int n0, int m0, int nkt, int nct_w, int nct_x, f32x4 (&acc)[8][4], BlockStamps& bs) {
+    constexpr int PSTR = 1088, PAR = 64 * PSTR, HALF = 8192;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wm = w >> 1;
+    // fills: region h (0, 1: W column tiles 2 h, 2 h + 1; 2, 3: X column tiles 2 (h - 2), + 1), wave w -> column tile w / 4 of the region, token pieces 2 w & 7, + 1
+    const size_t po = (size_t)((2 * w) & 7) * 1024 + lane * 16;
+    const char* const sw0 = (const char*)p.W + (size_t)((n0 >> 6) + (w >> 2)) * TILE_BYTES + po;
+    const char* const sw1 = sw0 + (size_t)2 * TILE_BYTES;
+    const char* const sx0 = (const char*)p.X + (size_t)((m0 >> 6) + (w >> 2)) * TILE_BYTES + po;
+    const char* const sx1 = sx0 + (size_t)2 * TILE_BYTES;
+    const size_t rtw = (size_t)nct_w * TILE_BYTES, rtx = (size_t)nct_x * TILE_BYTES;   // bytes per 128-token row tile
+    char* const dst0 = smem + (2 * w) * PSTR + lane * 16;
+    auto stage = [&](const char* src, size_t rt_bytes, int h, int t) {
+        const char* s = src + (size_t)(t >> 1) * rt_bytes + (size_t)(t & 1) * HALF;
+        char* d = dst0 + (t & 1) * PAR + h * 16 * PSTR;
+        glds16(s, d);
+        glds16(s + 1024, d + PSTR);
+    };
+    const int li = lane & 15, g = lane >> 4, qq = li >> 2, pp = li & 3;
+    unsigned aw[2][4], ax[2][4];   // [h][chunk pair c]: W / X fragment (column tile 0 of the wave, K half 0) of tile c
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int r7 = 4 * hh + qq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned o = (unsigned)(g * PSTR + r7 * 128 + (((2 * c + (pp >> 1)) ^ r7) << 4) + (pp & 1) * 8);
+            aw[hh][c] = o + (unsigned)(2 * wn * 8 * PSTR);
+            ax[hh][c] = o + (unsigned)((32 + wm * 8) * PSTR);
+        }
+    }
+    // W tile i (16 features) of the wave: column tile 2 wn + i / 4 -> + (i / 4) * 8 pieces; K half sh: + 4 sh pieces
+    auto rdw = [&](TnFrag& f, unsigned b, int i, int sh) {
+        lds_read_tr_asm(f.u[0], b + aw[0][i & 3] + (unsigned)(((i >> 2) * 8 + 4 * sh) * PSTR));
+        lds_read_tr_asm(f.u[1], b + aw[1][i & 3] + (unsigned)(((i >> 2) * 8 + 4 * sh) * PSTR));
+    };
+    auto rdx = [&](TnFrag& f, unsigned b, int j, int sh) {
+        lds_read_tr_asm(f.u[0], b + ax[0][j] + (unsigned)(4 * sh * PSTR));
+        lds_read_tr_asm(f.u[1], b + ax[1][j] + (unsigned)(4 * sh * PSTR));
+    };
+    auto mma = [&](const TnFrag& wv, const TnFrag& xv, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv.h, xv.h, c, 0, 0, 0); };
+
+    stage(sx0, rtx, 2, 0); stage(sx1, rtx, 3, 0); stage(sw0, rtw, 0, 0); stage(sw1, rtw, 1, 0);
+    if (nkt > 1) {
+        stage(sx0, rtx, 2, 1); stage(sx1, rtx, 3, 1);
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    GTAV_STAMP(bs.t[1]);
+    const unsigned smem0 = lds_offset(smem);
+#define GTAV_TNF(f) "+v"((f).u[0]), "+v"((f).u[1])
+    for (int t = 0; t < nkt; ++t) {
+        const unsigned b = smem0 + (unsigned)(t & 1) * PAR;
+        const bool n1 = t + 1 < nkt, n2 = t + 2 < nkt;
+        TnFrag wa[2][4], wb[2][4], xa[2][2], xb[2][2];
+        // (lgkmcnt is a 4-bit counter: at most 15 reads may be outstanding — every group below is 8 or 12 reads, issued in front of the MFMAs of the group before)
+        // ---- phase 1: W[0:4] x X[0:2] ----
+        if (n1) stage(sw0, rtw, 0, t + 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rdw(wa[0][i], b, i, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rdx(xa[0][j], b, j, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : GTAV_TNF(wa[0][0]), GTAV_TNF(wa[0][1]), GTAV_TNF(wa[0][2]), GTAV_TNF(wa[0][3]), GTAV_TNF(xa[0][0]), GTAV_TNF(xa[0][1]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rdw(wa[1][i], b, i, 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rdx(xa[1][j], b, j, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma(wa[0][i], xa[0][j], acc[i][j]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : GTAV_TNF(wa[1][0]), GTAV_TNF(wa[1][1]), GTAV_TNF(wa[1][2]), GTAV_TNF(wa[1][3]), GTAV_TNF(xa[1][0]), GTAV_TNF(xa[1][1]));
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) rdx(xb[sh][j], b, 2 + j, sh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma(wa[1][i], xa[1][j], acc[i][j]);
+        // ---- phase 2: W[0:4] x X[2:4]; the fragments of W[4:8] for phases 3 / 4 ----
+        if (n1) stage(sw1, rtw, 1, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : GTAV_TNF(xb[0][0]), GTAV_TNF(xb[0][1]), GTAV_TNF(xb[1][0]), GTAV_TNF(xb[1][1]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rdw(wb[0][i], b, 4 + i, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma(wa[0][i], xb[0][j], acc[i][2 + j]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : GTAV_TNF(wb[0][0]), GTAV_TNF(wb[0][1]), GTAV_TNF(wb[0][2]), GTAV_TNF(wb[0][3]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rdw(wb[1][i], b, 4 + i, 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma(wa[1][i], xb[1][j], acc[i][2 + j]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : GTAV_TNF(wb[1][0]), GTAV_TNF(wb[1][1]), GTAV_TNF(wb[1][2]), GTAV_TNF(wb[1][3]) : : "memory");   // (b)
+        // ---- phase 3 ----
+        if (n2) stage(sx0, rtx, 2, t + 2);
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(wb[sh][i], xb[sh][j], acc[4 + i][2 + j]);
+        // ---- phase 4 ----
+        if (n2) stage(sx1, rtx, 3, t + 2);
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(wb[sh][i], xa[sh][j], acc[4 + i][j]);
+        if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a)
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+#undef GTAV_TNF
+}
+
 // Grouped weight-gradient launch (launch_gemm_dw_grouped; training): the four dW GEMMs of a half-block — outputs
 // 4096 x 1024, 1024 x 4096, 3072 x 1024 and 1024 x 1024, contraction over the 11 520 tokens of a batch-16 step — as ONE grid of 256 x 256
 // tiles (64 + 64 + 48 + 16 = 192 tiles: one per CU, one round).  Alone each of them fills the chip only with 128 x 128 tiles, whose
@@ -1551,8 +1682,10 @@ struct GemmDwGroups {
     int first[GEMM_DW_MAX_GROUPS + 1];   // first[i] = tiles of groups 0 .. i-1
     int n;
 };
+// TN = true: the groups' operands are the activations themselves, tile-major [tokens][features] (X: M features, W: N features, K tokens): mainloop256_tn
+template <bool TN>
 __global__ __launch_bounds__(512, 1) void gemm256_dw_grouped_kernel(GemmParams p0, GemmDwGroups gs) {
-    __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[TN ? 2 * 64 * 1088 : 8 * TILE_BYTES];
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     const int swz = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
@@ -1575,7 +1708,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_dw_grouped_kernel(GemmParams p
     f32x4 pbias[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) pbias[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mainloop256<false>(p, smem, n0, m0, 0, p.K / TK, acc, bs, []() {});
+    if constexpr (TN) mainloop256_tn(p, smem, n0, m0, p.K / TK, p.N >> 6, p.M >> 6, acc, bs);
+    else mainloop256<false>(p, smem, n0, m0, 0, p.K / TK, acc, bs, []() {});
     GTAV_STAMP(bs.t[2]);
     epilogue<EPI_RESID, 8, 4, 4>(p, acc, pbias, smem, n0, m0, 0, false);
     bs.end(p);
@@ -3095,7 +3229,7 @@ bool gemm_dw_grouped_ok(const GemmDwGroup* g, int n, int K) {
     return cus > 0 && 2 * tiles >= cus && tiles <= 2 * cus && K >= 2048;
 }
 
-int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hipStream_t stream) {
+int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hipStream_t stream, bool tn) {
     GTAV_REQUIRE(g && n >= 1 && n <= GEMM_DW_MAX_GROUPS && K > 0 && K % TK == 0, "gemm_dw_grouped: bad arguments (n=%d K=%d)", n, K);
     GemmDwGroups gs;
     memset(&gs, 0, sizeof(gs));
@@ -3114,7 +3248,12 @@ int launch_gemm_dw_grouped(const GemmDwGroup* g, int n, int K, int* err_flag, hi
 #ifdef GTAV_EXPERIMENTS
     p.stamps = g_stamps;
 #endif
-    GTAV_LAUNCH(gemm256_dw_grouped_kernel, dim3(gs.first[n]), dim3(512), 0, stream, p, gs);
+    if (tn) {   // operands tile-major [tokens][features]: K tokens in whole 128-row tiles (the pad rows of a ragged last tile are not zero)
+        GTAV_REQUIRE(K % 128 == 0, "gemm_dw_grouped: the transpose-free form contracts over whole 128-token row tiles (K=%d)", K);
+        GTAV_LAUNCH(gemm256_dw_grouped_kernel<true>, dim3(gs.first[n]), dim3(512), 0, stream, p, gs);
+    } else {
+        GTAV_LAUNCH(gemm256_dw_grouped_kernel<false>, dim3(gs.first[n]), dim3(512), 0, stream, p, gs);
+    }
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

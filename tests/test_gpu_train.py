@@ -190,20 +190,23 @@ def test_full_size_gradients_match_autograd():
     assert max(worst.values()) < GRAD_TOL, worst
 
 
-def test_full_size_gradients_grouped_weight_gradient_launch():
+@pytest.mark.parametrize("B,T", [(3, 5), (4, 4)])
+def test_full_size_gradients_grouped_weight_gradient_launch(B, T):
     """DiT-S/2 at its real size with B = 3 clips (M = 2160 tokens): from 2048 tokens on the four weight gradients of a half-block run as ONE
     grouped launch of 256 x 256 tiles (gemm.h launch_gemm_dw_grouped, 192 tiles) instead of four launches of 128 x 128 tiles — every Linear
-    weight gradient of the first, a middle and the last block against torch autograd, and two backward passes bit-identical."""
+    weight gradient of the first, a middle and the last block against torch autograd, and two backward passes bit-identical.
+    B = 4, T = 4 (M = 2304 = 18 whole 128-token row tiles): the transpose-free form of that launch (mainloop256_tn: the contraction runs over the rows of the
+    tile-major activations themselves); M = 2160 has a ragged last row tile and goes through the transposed copies."""
     import gtav_amd.weights as W
     from gtav_amd.model.dit import DiT_models
     from oracle import ref_cpu as O
     sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
     g = torch.Generator().manual_seed(12)
-    B = 3
-    x = torch.randn(B, 5, 16, 18, 32, generator=g) * 0.7
-    t = torch.tensor([[15, 15, 15, 15, 420], [15, 15, 15, 15, 77], [15, 15, 15, 15, 901]])
-    a = torch.zeros(B, 5, 25)
-    a[torch.arange(B)[:, None], torch.arange(5)[None], torch.randint(0, 25, (B, 5), generator=g)] = 1
+    x = torch.randn(B, T, 16, 18, 32, generator=g) * 0.7
+    t = torch.full((B, T), 15, dtype=torch.long)
+    t[:, -1] = torch.tensor([420, 77, 901, 333][:B])
+    a = torch.zeros(B, T, 25)
+    a[torch.arange(B)[:, None], torch.arange(T)[None], torch.randint(0, 25, (B, T), generator=g)] = 1
     vt = torch.randn(B, 1, 16, 18, 32, generator=g)
     torch.set_num_threads(16)
     _, v_ref, grads = O.dit_loss_and_grads(sd, O.dit_s_2(), x, t, a, vt)
