@@ -341,6 +341,7 @@ struct gtav_dit {
 };
 
 static int g_dw_grouped = GTAV_ENV_INT("GTAV_DW_GROUPED", 1);   // experiments build: 0 = one launch per weight gradient (A/B runs)
+static int g_fuse_gate = GTAV_ENV_INT("GTAV_FUSE_GATE", 1);     // experiments build: 0 = gate_bwd, frame_reduce_gate and the bias column sums as three launches (A/B runs)
 static int g_dw_tn = GTAV_ENV_INT("GTAV_DW_TN", 1);             // experiments build: 0 = transposed operand copies in front of the grouped launch (A/B runs)
 
 // LayerNorm fold: tables, statistics and the grouped-GEMM descriptors, allocated by the first gtav_dit_set_fold that can fold anything
@@ -1249,6 +1250,9 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     // mainloop256_tn) — no transposed copies (8 of the 17 us transposes per half-block).  The operands must then live until flush_dw: the out-projection's
     // dY gets a buffer of its own (g_d2), the saved activations and g_u / g_qkv are not rewritten inside a half-block.
     const bool tn_dw = defer_dw && g_dw_tn && M % 128 == 0;
+    // gate backward, the gate's own gradient and the bias gradient of the Linear in front of it in one pass over dres (train.hip gate_bwd_fused_kernel): the
+    // per-frame partial sums of the bias gradient (NB x D floats) must fit the reduction workspace
+    const bool fuse_gate = g_fuse_gate && M == NB * P && (size_t)NB * D <= colsum_workspace(h->Mmax > h->max_rows ? h->Mmax : h->max_rows, h->Hm_pad > 6 * D ? h->Hm_pad : 6 * D);
     auto flush_dw = [&]() -> int {
         if (!ndw) return 0;
         const int n = ndw;
@@ -1325,9 +1329,13 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         const float* mb = mod + (size_t)i * 6 * D;
         float* dmb = dmod + (size_t)i * 6 * D;
         // r_{2i+2} = r_{2i+1} + gate_mlp y2
-        RET_IF(launch_gate_bwd(tr.dres, mb + 5 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
-        RET_IF(launch_frame_reduce_gate(tr.dres, b.y2, NB, P, D, dmb + 5 * D, MODW, s));
-        RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "mlp.fc2.bias").grad, tr.red_ws, s));
+        if (fuse_gate) {
+            RET_IF(launch_gate_bwd_fused(tr.dres, b.y2, mb + 5 * D, MODW, NB, P, D, tr.g_d, dmb + 5 * D, slot(P_ + "mlp.fc2.bias").grad, tr.red_ws, h->err_flag, s));
+        } else {
+            RET_IF(launch_gate_bwd(tr.dres, mb + 5 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
+            RET_IF(launch_frame_reduce_gate(tr.dres, b.y2, NB, P, D, dmb + 5 * D, MODW, s));
+            RET_IF(launch_colsum_tiled_f16(tr.g_d, M, D, slot(P_ + "mlp.fc2.bias").grad, tr.red_ws, s));
+        }
         RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad, 0));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "mlp.fc2.weight").wT, Hp, D, EPI_F16_TILED, tr.g_h, Hp));
         RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
@@ -1338,9 +1346,13 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i + 1], tr.stats, NB, P, D, dmb + 3 * D, dmb + 4 * D, MODW, s));
         // r_{2i+1} = r_{2i} + gate_msa y1
         f16* const g_o = tn_dw ? tr.g_d2 : tr.g_d;   // (the fc2 weight gradient above still reads g_d when the grouped launch is deferred without copies)
-        RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, g_o, h->err_flag, s));
-        RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
-        RET_IF(launch_colsum_tiled_f16(g_o, M, D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, s));
+        if (fuse_gate) {
+            RET_IF(launch_gate_bwd_fused(tr.dres, b.y1, mb + 2 * D, MODW, NB, P, D, g_o, dmb + 2 * D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, h->err_flag, s));
+        } else {
+            RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, g_o, h->err_flag, s));
+            RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
+            RET_IF(launch_colsum_tiled_f16(g_o, M, D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, s));
+        }
         RET_IF(gemm_dw(g_o, D, b.ao, D, slot(P_ + "attn.to_out.weight").grad, 2));
         RET_IF(gemm_dx(g_o, slot(P_ + "attn.to_out.weight").wT, D, D, EPI_F16, tr.dao, D));
         if (hf == 0) RET_IF(launch_attn_spatial_bwd(b.q, b.k, b.v, tr.dao, NB, h->heads, P, D, h->rope_s.cs_dev, tr.g_qkv, h->err_flag, s));

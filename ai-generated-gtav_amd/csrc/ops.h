@@ -153,6 +153,9 @@ int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats,
                            hipStream_t stream);
 int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int rows_per_mod, int M, int D, f16* dy_tiled, int* err_flag, hipStream_t stream);
 int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream);
+// the two above + db[n] += sum_m dy[m][n] in one pass over dres (M = frames x P rows; ws: frames x D floats)
+int launch_gate_bwd_fused(const float* dres, const f16* y, const float* gate, int mod_stride, int frames, int P, int D, f16* dy_tiled, float* dgate, float* db,
+                          float* ws, int* err_flag, hipStream_t stream);
 // column sums in a fixed order (no float atomics): ws = colsum_workspace(M, N) floats of scratch for the per-row-split partial sums
 size_t colsum_workspace(int M, int N);
 int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, float* ws, hipStream_t stream);     // db[n] += sum_m dy[m][n]

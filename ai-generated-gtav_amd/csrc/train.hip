@@ -190,6 +190,41 @@ __global__ __launch_bounds__(256) void frame_reduce_gate_kernel(const float* __r
     if (tg == 0 && d < D) dgate[(size_t)f * mod_stride + d] = (ra[0][dl] + ra[1][dl]) + (ra[2][dl] + ra[3][dl]);
 }
 
+// gate_bwd + frame_reduce_gate + the bias gradient of the Linear in front of the gate in ONE pass over dres (round 4): block = 64 features of one frame,
+// 16 feature quads x 16 token lanes.  dy = sat16(gate dres) tile-major; dgate[f][n] = sum_t dres y; bias_part[f][n] = gate[f][n] sum_t dres (= the frame's share of
+// sum_m dy[m][n], from the unrounded products; colsum_reduce_kernel adds the frames in order).  The three kernels it replaces read dres twice and dy once more.
+__global__ __launch_bounds__(256) void gate_bwd_fused_kernel(const float* __restrict__ dres, const f16* __restrict__ y, const float* __restrict__ gate, int mod_stride,
+                                                             int P, int D, f16* __restrict__ dy, float* __restrict__ dgate, float* __restrict__ bias_part, int* err_flag) {
+    __shared__ float ra[16][65], rs[16][65];
+    const int qd = threadIdx.x & 15, tl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * qd, f = blockIdx.y;
+    f32x4 gt = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (gate) gt = *(const f32x4*)(gate + (size_t)f * mod_stride + c);
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, sm = a;
+    float amax = 0.f;
+    for (int t = tl; t < P; t += 16) {
+        const size_t m = (size_t)f * P + t;
+        const f32x4 v = *(const f32x4*)(dres + m * D + c);
+        const f16x4 yy = *(const f16x4*)(y + m * D + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += v[e] * (float)yy[e];
+        sm = sm + v;
+        const f32x4 o = v * gt;
+        *(f16x4*)(dy + tiled_off((int)m, c, D)) = sat4(o[0], o[1], o[2], o[3], amax);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ra[tl][4 * qd + e] = a[e]; rs[tl][4 * qd + e] = sm[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float ta = 0.f, ts = 0.f;
+        for (int i = 0; i < 16; ++i) { ta += ra[i][threadIdx.x]; ts += rs[i][threadIdx.x]; }
+        const int n = blockIdx.x * 64 + threadIdx.x;
+        dgate[(size_t)f * mod_stride + n] = ta;
+        if (bias_part) bias_part[(size_t)f * D + n] = (gate ? gate[(size_t)f * mod_stride + n] : 1.0f) * ts;
+    }
+    sat_report(amax, err_flag);
+}
+
 // db[n] += sum_m dY[m][n] for a tile-major fp16 dY (logical [M][N], N % 64 == 0).  Block = one 64-column tile column x a slice of rows;
 // thread = (8-column chunk, row lane): one 16-byte load per row.
 // Row splits: with `ws` the per-split column sums go to ws[split][N] and colsum_reduce_kernel adds them to db in split order — a fixed
@@ -1153,6 +1188,15 @@ int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int ro
 }
 int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream) {
     hipLaunchKernelGGL(frame_reduce_gate_kernel, dim3(cdiv(D, 64), frames), dim3(256), 0, stream, dres, y, frames, P, D, dgate, mod_stride);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// fused form of launch_gate_bwd + launch_frame_reduce_gate + launch_colsum_tiled_f16(dy -> db): ws holds frames x D floats
+int launch_gate_bwd_fused(const float* dres, const f16* y, const float* gate, int mod_stride, int frames, int P, int D, f16* dy_tiled, float* dgate, float* db,
+                          float* ws, int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(D % 64 == 0 && frames > 0 && P > 0 && ws && db, "gate_bwd_fused: D=%d frames=%d P=%d", D, frames, P);
+    hipLaunchKernelGGL(gate_bwd_fused_kernel, dim3(D / 64, frames), dim3(256), 0, stream, dres, y, gate, mod_stride, P, D, dy_tiled, dgate, ws, err_flag);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, stream, ws, frames, D, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
