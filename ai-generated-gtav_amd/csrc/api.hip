@@ -323,6 +323,7 @@ struct gtav_dit {
         float* grad_arena = nullptr;        // all gradients, contiguous (one all-reduce); caller-owned when passed to train_enable
         size_t grad_count = 0;
         float* ctl = nullptr;               // [8]: sumsq, step coefficient, skipped steps, grad norm, applied steps, bias corrections
+        float *ln_part = nullptr;   // per-(frame, 16-row chunk) partial rows of the fused LayerNorm backward (train.hip ln_mod_bwd_fused_kernel)
         float *red_ws = nullptr, *sumsq_part = nullptr;   // partial sums of the fixed-order reductions (bias gradients, gradient norm)
         AdamParam* adam_params = nullptr;   // device tables of the multi-tensor AdamW launch
         AdamItem* adam_items = nullptr;
@@ -341,6 +342,8 @@ struct gtav_dit {
 };
 
 static int g_dw_grouped = GTAV_ENV_INT("GTAV_DW_GROUPED", 1);   // experiments build: 0 = one launch per weight gradient (A/B runs)
+static int g_fuse_gelu = GTAV_ENV_INT("GTAV_FUSE_GELU_BWD", 1); // experiments build: 0 = gelu_bwd and the fc1 bias column sums as two launches (A/B runs)
+static int g_fuse_ln = GTAV_ENV_INT("GTAV_FUSE_LN_BWD", 1);     // experiments build: 0 = ln_mod_bwd and frame_reduce_ln as two launches (A/B runs)
 static int g_fuse_gate = GTAV_ENV_INT("GTAV_FUSE_GATE", 1);     // experiments build: 0 = gate_bwd, frame_reduce_gate and the bias column sums as three launches (A/B runs)
 static int g_dw_tn = GTAV_ENV_INT("GTAV_DW_TN", 1);             // experiments build: 0 = transposed operand copies in front of the grouped launch (A/B runs)
 
@@ -1072,6 +1075,7 @@ int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena
     const size_t R = h->max_rows;
     RET_IF(a.alloc_t(&t.z0, R * D)); RET_IF(a.alloc_t(&t.cpre, R * D));
     RET_IF(a.alloc_t(&t.dres, Mx * D)); RET_IF(a.alloc_t(&t.dtmp, Mx * D)); RET_IF(a.alloc_t(&t.stats, 2 * Mx));
+    if (ln_bwd_fused_ok(D)) RET_IF(a.alloc_t(&t.ln_part, ln_bwd_fused_workspace((int)R, h->P, D)));
     RET_IF(a.alloc_t(&t.dmod, R * h->MODW)); RET_IF(a.alloc_t(&t.dSc, R * D)); RET_IF(a.alloc_t(&t.ada_part, ada_bwd_dx_workspace(h->MODW, D, (int)R))); RET_IF(a.alloc_t(&t.dc, R * D)); RET_IF(a.alloc_t(&t.dh0, R * D));
     RET_IF(a.alloc_t(&t.dz0, R * D));
     RET_IF(a.alloc_t(&t.g_d, Mx * D)); RET_IF(a.alloc_t(&t.g_d2, Mx * D)); RET_IF(a.alloc_t(&t.g_h, Mx * Hp)); RET_IF(a.alloc_t(&t.g_u, Mx * Hp)); RET_IF(a.alloc_t(&t.g_qkv, Mx * 3 * D));
@@ -1252,7 +1256,14 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     const bool tn_dw = defer_dw && g_dw_tn && M % 128 == 0;
     // gate backward, the gate's own gradient and the bias gradient of the Linear in front of it in one pass over dres (train.hip gate_bwd_fused_kernel): the
     // per-frame partial sums of the bias gradient (NB x D floats) must fit the reduction workspace
-    const bool fuse_gate = g_fuse_gate && M == NB * P && (size_t)NB * D <= colsum_workspace(h->Mmax > h->max_rows ? h->Mmax : h->max_rows, h->Hm_pad > 6 * D ? h->Hm_pad : 6 * D);
+    const bool fuse_ln = g_fuse_ln && tr.ln_part && M == NB * P && NB <= rows;
+    auto ln_bwd = [&](const float* dxn, const float* x, const float* scale, int accumulate, float* dshift, float* dscale) -> int {
+        if (fuse_ln) return launch_ln_mod_bwd_fused(dxn, x, scale, MODW, NB, P, D, tr.dres, accumulate, dshift, dscale, tr.ln_part, s);
+        RET_IF(launch_ln_mod_bwd(dxn, x, scale, MODW, P, M, D, tr.dres, accumulate, tr.stats, s));
+        return launch_frame_reduce_ln(dxn, x, tr.stats, NB, P, D, dshift, dscale, MODW, s);
+    };
+    const size_t ws_cap = colsum_workspace(h->Mmax > h->max_rows ? h->Mmax : h->max_rows, h->Hm_pad > 6 * D ? h->Hm_pad : 6 * D);   // floats of tr.red_ws
+    const bool fuse_gate = g_fuse_gate && M == NB * P && (size_t)NB * D <= ws_cap;
     auto flush_dw = [&]() -> int {
         if (!ndw) return 0;
         const int n = ndw;
@@ -1312,8 +1323,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         RET_IF(gemm_dx(tr.dfo, wf.wT, D, 64, EPI_F32, tr.dtmp, D));
         const float* mf = mod + (size_t)L * 12 * D;
         float* dmf = dmod + (size_t)L * 12 * D;
-        RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[4 * L], mf + D, MODW, P, M, D, tr.dres, 0, tr.stats, s));
-        RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[4 * L], tr.stats, NB, P, D, dmf, dmf + D, MODW, s));
+        RET_IF(ln_bwd(tr.dtmp, tr.res[4 * L], mf + D, 0, dmf, dmf + D));
         RET_IF(ada_grads((size_t)L * 12 * D, 2 * D, "final_layer.adaLN_modulation.1.weight", "final_layer.adaLN_modulation.1.bias"));
     }
     }
@@ -1338,12 +1348,15 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         }
         RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad, 0));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "mlp.fc2.weight").wT, Hp, D, EPI_F16_TILED, tr.g_h, Hp));
-        RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
-        RET_IF(launch_colsum_tiled_f16(tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, tr.red_ws, s));
+        if (g_fuse_gelu && colsum_workspace(round_up(M, 128), Hp) <= ws_cap) {
+            RET_IF(launch_gelu_bwd_tiled_colsum(tr.g_h, b.u, tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, tr.red_ws, h->err_flag, s));
+        } else {
+            RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
+            RET_IF(launch_colsum_tiled_f16(tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, tr.red_ws, s));
+        }
         RET_IF(gemm_dw(tr.g_u, Hp, b.xnB, D, slot(P_ + "mlp.fc1.weight").grad, 1));
         RET_IF(gemm_dx(tr.g_u, slot(P_ + "mlp.fc1.weight").wT, D, Hp, EPI_F32, tr.dtmp, D));
-        RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i + 1], mb + 4 * D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
-        RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i + 1], tr.stats, NB, P, D, dmb + 3 * D, dmb + 4 * D, MODW, s));
+        RET_IF(ln_bwd(tr.dtmp, tr.res[2 * i + 1], mb + 4 * D, 1, dmb + 3 * D, dmb + 4 * D));
         // r_{2i+1} = r_{2i} + gate_msa y1
         f16* const g_o = tn_dw ? tr.g_d2 : tr.g_d;   // (the fc2 weight gradient above still reads g_d when the grouped launch is deferred without copies)
         if (fuse_gate) {
@@ -1360,8 +1373,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         RET_IF(gemm_dw(tr.g_qkv, 3 * D, b.xnA, D, slot(P_ + "attn.to_qkv.weight").grad, 3));
         RET_IF(flush_dw());
         RET_IF(gemm_dx(tr.g_qkv, slot(P_ + "attn.to_qkv.weight").wT, D, 3 * D, EPI_F32, tr.dtmp, D));
-        RET_IF(launch_ln_mod_bwd(tr.dtmp, tr.res[2 * i], mb + D, MODW, P, M, D, tr.dres, 1, tr.stats, s));
-        RET_IF(launch_frame_reduce_ln(tr.dtmp, tr.res[2 * i], tr.stats, NB, P, D, dmb, dmb + D, MODW, s));
+        RET_IF(ln_bwd(tr.dtmp, tr.res[2 * i], mb + D, 1, dmb, dmb + D));
         // all six dmod chunks of this half-block are in place: its adaLN projection's gradients
         RET_IF(ada_grads((size_t)i * 6 * D, 6 * D, P_ + "adaLN_modulation.1.weight", P_ + "adaLN_modulation.1.bias"));
     }

@@ -151,6 +151,13 @@ int launch_ln_mod_bwd(const float* dxn, const float* x, const float* scale, int 
                       float* stats, hipStream_t stream);
 int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats, int frames, int P, int D, float* dshift, float* dscale, int mod_stride,
                            hipStream_t stream);
+// launch_gelu_bwd_tiled + the column sums of its output (db[n] += sum_m du[m][n]) in one pass
+int launch_gelu_bwd_tiled_colsum(const f16* dh, const f16* u, f16* du, int M, int N, float* db, float* ws, int* err_flag, hipStream_t stream);
+// launch_ln_mod_bwd + launch_frame_reduce_ln in one pass over dxn and x (M = frames x P rows)
+bool ln_bwd_fused_ok(int D);
+size_t ln_bwd_fused_workspace(int frames, int P, int D);
+int launch_ln_mod_bwd_fused(const float* dxn, const float* x, const float* scale, int mod_stride, int frames, int P, int D, float* dres, int accumulate,
+                            float* dshift, float* dscale, float* part, hipStream_t stream);
 int launch_gate_bwd(const float* dres, const float* gate, int mod_stride, int rows_per_mod, int M, int D, f16* dy_tiled, int* err_flag, hipStream_t stream);
 int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P, int D, float* dgate, int mod_stride, hipStream_t stream);
 // the two above + db[n] += sum_m dy[m][n] in one pass over dres (M = frames x P rows; ws: frames x D floats)

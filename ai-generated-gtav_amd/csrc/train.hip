@@ -159,6 +159,93 @@ __global__ __launch_bounds__(256) void frame_reduce_ln_kernel(const float* __res
     }
 }
 
+// ln_mod_bwd + frame_reduce_ln in ONE pass over dxn and x (round 4).  Block = 16 token rows of one frame, four waves; a WAVE owns a row (D / 256 float4 per lane,
+// DPP reductions: no LDS, no barrier per row) and walks rows w, w + 4, ...; the per-feature sums of the frame's adaLN gradients (dshift = sum dxn, dscale = sum dxn
+// xhat) stay in registers over the wave's rows, the four waves are combined through LDS in wave order and the block writes ONE partial row pair; the partial rows of
+// a frame are added in chunk order by frame_partials_reduce_kernel.  The pair of kernels it replaces read dxn and x twice.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_mod_bwd_fused_kernel(const float* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ scale, int mod_stride,
+                                                               int P, float* __restrict__ dres, int accumulate, float* __restrict__ part /*[frames][chunks][2][D]*/) {
+    constexpr int D = 256 * NV, RB = 16;
+    __shared__ float comb[4][2][D];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int f = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+    f32x4 sc[NV], ash[NV], asc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        sc[q] = *(const f32x4*)(scale + (size_t)f * mod_stride + 4 * (lane + 64 * q));
+        ash[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asc[q] = ash[q];
+    }
+    const int t_end = min(P, (chunk + 1) * RB);
+    for (int t = chunk * RB + w; t < t_end; t += 4) {
+        const size_t m = (size_t)f * P + t;
+        f32x4 xv[NV], gv[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            xv[q] = *(const f32x4*)(x + m * D + 4 * (lane + 64 * q));
+            gv[q] = *(const f32x4*)(dxn + m * D + 4 * (lane + 64 * q));
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) s += (xv[q][0] + xv[q][1]) + (xv[q][2] + xv[q][3]);
+        const float mean = wave_sum_dpp(s) / (float)D;
+        s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            xv[q] = xv[q] - mean;
+            s += (xv[q][0] * xv[q][0] + xv[q][1] * xv[q][1]) + (xv[q][2] * xv[q][2] + xv[q][3] * xv[q][3]);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum_dpp(s) / (float)D + 1e-6f);
+        float s1 = 0.f, s2 = 0.f;
+        f32x4 g[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            xv[q] = xv[q] * rstd;                                   // xhat
+            ash[q] = ash[q] + gv[q];
+            asc[q] = asc[q] + gv[q] * xv[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[q][e] = gv[q][e] * (1.0f + (sc[q][e] + 1e-6f));
+            s1 += (g[q][0] + g[q][1]) + (g[q][2] + g[q][3]);
+            s2 += (g[q][0] * xv[q][0] + g[q][1] * xv[q][1]) + (g[q][2] * xv[q][2] + g[q][3] * xv[q][3]);
+        }
+        s1 = wave_sum_dpp(s1) / (float)D;
+        s2 = wave_sum_dpp(s2) / (float)D;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            float* o = dres + m * D + 4 * (lane + 64 * q);
+            f32x4 dx;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] = rstd * (g[q][e] - s1 - xv[q][e] * s2);
+            if (accumulate) dx = dx + *(const f32x4*)o;
+            *(f32x4*)o = dx;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        *(f32x4*)(&comb[w][0][4 * (lane + 64 * q)]) = ash[q];
+        *(f32x4*)(&comb[w][1][4 * (lane + 64 * q)]) = asc[q];
+    }
+    __syncthreads();
+    float* out = part + ((size_t)f * chunks + chunk) * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int k = i / D, n = i - k * D;
+        out[i] = (comb[0][k][n] + comb[1][k][n]) + (comb[2][k][n] + comb[3][k][n]);
+    }
+}
+// dshift[f][n] / dscale[f][n] = the frame's partial rows added in chunk order
+__global__ __launch_bounds__(256) void frame_partials_reduce_kernel(const float* __restrict__ part, int chunks, int D, float* __restrict__ dshift, float* __restrict__ dscale, int mod_stride) {
+    const int n = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (n >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        a += part[(((size_t)f * chunks + c) * 2 + 0) * D + n];
+        b += part[(((size_t)f * chunks + c) * 2 + 1) * D + n];
+    }
+    dshift[(size_t)f * mod_stride + n] = a;
+    dscale[(size_t)f * mod_stride + n] = b;
+}
+
 // Gated residual branch x += gate y (model/dit.py:207-223) backward: dy = gate dres -> fp16 TILE-MAJOR (the dX / dW GEMM operand);
 // dgate[f][d] = sum over the frame's tokens of dres y (frame_reduce_gate_kernel; y = the branch output saved by the forward).
 __global__ void gate_bwd_kernel(const float* __restrict__ dres, const float* __restrict__ gate, int mod_stride, int rows_per_mod, int M, int D,
@@ -188,6 +275,47 @@ __global__ __launch_bounds__(256) void frame_reduce_gate_kernel(const float* __r
     ra[tg][dl] = a;
     __syncthreads();
     if (tg == 0 && d < D) dgate[(size_t)f * mod_stride + d] = (ra[0][dl] + ra[1][dl]) + (ra[2][dl] + ra[3][dl]);
+}
+
+// gelu_bwd_tiled + the column sums of its output (the fc1 bias gradient) in one pass (round 4): block = one 64-column tile column x a slice of rows (the layout of
+// colsum_tiled_kernel), thread = (8-column chunk, row lane).  du = sat16(dh gelu'(u)) for every row of the padded image; the sums take the unrounded products of the
+// M real rows: ws[split][N], added in split order by colsum_reduce_kernel.
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const f16* __restrict__ dh, const f16* __restrict__ u, f16* __restrict__ du, int M, int Mp, int N,
+                                                              int rows_per_block, float* __restrict__ ws, int* err_flag) {
+    __shared__ float part[32][65];
+    const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int n0 = blockIdx.x * 64;
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(Mp, r_begin + rows_per_block);
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float amax = 0.f;
+    for (int r = r_begin + rl; r < r_end; r += 32) {
+        const size_t off = tiled_off(r, n0 + 8 * ch, N);
+        union { uint4 q; f16 e[8]; } x, b, o;
+        x.q = *(const uint4*)(dh + off);
+        b.q = *(const uint4*)(u + off);
+        const float real = r < M ? 1.0f : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xx = (float)b.e[j];
+            const float k = 0.7978845608028654f, c = 0.044715f;
+            const float s = 1.0f / (1.0f + __expf(-2.0f * k * xx * (1.0f + c * xx * xx)));
+            const float g = s + xx * s * (1.0f - s) * 2.0f * k * (1.0f + 3.0f * c * xx * xx);
+            const float v = (float)x.e[j] * g;
+            amax = fmaxf(amax, fabsf(v));
+            o.e[j] = (f16)__builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+            a[j] += real * v;
+        }
+        *(uint4*)(du + off) = o.q;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[rl][8 * ch + i] = a[i];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += part[i][threadIdx.x];
+        ws[(size_t)blockIdx.y * N + n0 + threadIdx.x] = t;
+    }
+    sat_report(amax, err_flag);
 }
 
 // gate_bwd + frame_reduce_gate + the bias gradient of the Linear in front of the gate in ONE pass over dres (round 4): block = 64 features of one frame,
@@ -1167,10 +1295,34 @@ int launch_gelu_bwd_tiled(const f16* dh, const f16* u, f16* du, size_t n, int* e
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
+// launch_gelu_bwd_tiled + launch_colsum_tiled_f16(du -> db) in one pass: dh / u / du tile-major [round_up(M, 128)][N]; ws = colsum_workspace(M, N) floats
+int launch_gelu_bwd_tiled_colsum(const f16* dh, const f16* u, f16* du, int M, int N, float* db, float* ws, int* err_flag, hipStream_t stream) {
+    GTAV_REQUIRE(N % 64 == 0 && M > 0 && ws && db, "gelu_bwd_colsum: M=%d N=%d", M, N);
+    const int Mp = round_up(M, 128), splits = cdiv(Mp, 512);
+    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dh, u, du, M, Mp, N, cdiv(Mp, splits), ws, err_flag);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, ws, splits, N, db);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_ln_mod_bwd(const float* dxn, const float* x, const float* scale, int mod_stride, int rows_per_mod, int M, int D, float* dres, int accumulate,
                       float* stats, hipStream_t stream) {
     GTAV_REQUIRE(D % 4 == 0 && D <= 2048, "ln_mod_bwd: D=%d", D);
     hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(M), dim3(round_up(D / 4, 64)), 0, stream, dxn, x, scale, mod_stride, rows_per_mod, M, D, dres, accumulate, stats);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+// fused form of launch_ln_mod_bwd + launch_frame_reduce_ln (D = 1024 or 2048; part: ln_bwd_fused_workspace(frames, P, D) floats)
+bool ln_bwd_fused_ok(int D) { return D == 1024 || D == 2048 || D == 512 || D == 256; }
+size_t ln_bwd_fused_workspace(int frames, int P, int D) { return (size_t)frames * (size_t)cdiv(P, 16) * 2 * (size_t)D; }
+int launch_ln_mod_bwd_fused(const float* dxn, const float* x, const float* scale, int mod_stride, int frames, int P, int D, float* dres, int accumulate,
+                            float* dshift, float* dscale, float* part, hipStream_t stream) {
+    GTAV_REQUIRE(ln_bwd_fused_ok(D) && part && frames > 0 && P > 0, "ln_mod_bwd_fused: D=%d", D);
+    const dim3 grid(cdiv(P, 16), frames);
+    if (D == 256) hipLaunchKernelGGL(ln_mod_bwd_fused_kernel<1>, grid, dim3(256), 0, stream, dxn, x, scale, mod_stride, P, dres, accumulate, part);
+    else if (D == 512) hipLaunchKernelGGL(ln_mod_bwd_fused_kernel<2>, grid, dim3(256), 0, stream, dxn, x, scale, mod_stride, P, dres, accumulate, part);
+    else if (D == 1024) hipLaunchKernelGGL(ln_mod_bwd_fused_kernel<4>, grid, dim3(256), 0, stream, dxn, x, scale, mod_stride, P, dres, accumulate, part);
+    else hipLaunchKernelGGL(ln_mod_bwd_fused_kernel<8>, grid, dim3(256), 0, stream, dxn, x, scale, mod_stride, P, dres, accumulate, part);
+    hipLaunchKernelGGL(frame_partials_reduce_kernel, dim3(cdiv(D, 256), frames), dim3(256), 0, stream, part, cdiv(P, 16), D, dshift, dscale, mod_stride);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
