@@ -360,9 +360,17 @@ __global__ __launch_bounds__(256) void gate_bwd_fused_kernel(const float* __rest
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int splits, int N, float* __restrict__ db) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    float t = 0.f;
-    for (int sp = 0; sp < splits; ++sp) t += ws[(size_t)sp * N + n];
-    db[n] += t;
+    // four independent chains (a fixed order all the same): one chain of `splits` dependent adds made this launch one memory round trip per split
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= splits; sp += 4) {
+        t0 += ws[(size_t)sp * N + n];
+        t1 += ws[(size_t)(sp + 1) * N + n];
+        t2 += ws[(size_t)(sp + 2) * N + n];
+        t3 += ws[(size_t)(sp + 3) * N + n];
+    }
+    for (; sp < splits; ++sp) t0 += ws[(size_t)sp * N + n];
+    db[n] += (t0 + t1) + (t2 + t3);
 }
 __global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block, float* __restrict__ ws) {
     __shared__ float part[32][65];
@@ -390,8 +398,16 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int r_begin = blockIdx.y * rows_per_block, r_end = min(M, r_begin + rows_per_block);
-    float s = 0.f;
-    for (int r = r_begin; r < r_end; ++r) s += a[(size_t)r * lda + n];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // (four independent chains, as colsum_reduce_kernel)
+    int r = r_begin;
+    for (; r + 4 <= r_end; r += 4) {
+        s0 += a[(size_t)r * lda + n];
+        s1 += a[(size_t)(r + 1) * lda + n];
+        s2 += a[(size_t)(r + 2) * lda + n];
+        s3 += a[(size_t)(r + 3) * lda + n];
+    }
+    for (; r < r_end; ++r) s0 += a[(size_t)r * lda + n];
+    const float s = (s0 + s1) + (s2 + s3);
     if (ws) ws[(size_t)blockIdx.y * N + n] = s;
     else db[n] += s;
 }
