@@ -342,6 +342,7 @@ struct gtav_dit {
 };
 
 static int g_dw_grouped = GTAV_ENV_INT("GTAV_DW_GROUPED", 1);   // experiments build: 0 = one launch per weight gradient (A/B runs)
+static int g_fuse_gelu_fwd = GTAV_ENV_INT("GTAV_FUSE_GELU_FWD", 1); // experiments build: 0 = h = GELU(u) by the flat elementwise kernel behind fc1 (A/B runs)
 static int g_fuse_gelu = GTAV_ENV_INT("GTAV_FUSE_GELU_BWD", 1); // experiments build: 0 = gelu_bwd and the fc1 bias column sums as two launches (A/B runs)
 static int g_fuse_ln = GTAV_ENV_INT("GTAV_FUSE_LN_BWD", 1);     // experiments build: 0 = ln_mod_bwd and frame_reduce_ln as two launches (A/B runs)
 static int g_fuse_gate = GTAV_ENV_INT("GTAV_FUSE_GATE", 1);     // experiments build: 0 = gate_bwd, frame_reduce_gate and the bias column sums as three launches (A/B runs)
@@ -1192,8 +1193,9 @@ int gtav_dit_train_forward(gtav_dit* h, const float* x, const int64_t* t64, cons
             have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = b.xnB; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = b.u; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
+            if (g_fuse_gelu_fwd) g.out2 = b.hh;             // h = GELU(u) as a second image of the same epilogue (gemm.h out2)
             RET_IF(launch_gemm(g, EPI_F16_TILED, s));       // the pre-activation is kept: gelu'(u) in the backward pass
-            RET_IF(launch_gelu_tiled(b.u, b.hh, (size_t)round_up(M, 128) * h->Hm_pad, s));
+            if (!g_fuse_gelu_fwd) RET_IF(launch_gelu_tiled(b.u, b.hh, (size_t)round_up(M, 128) * h->Hm_pad, s));
             RET_IF(resid_gemm(b.hh, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, tr.res[2 * i + 2], b.y2));
         }
     const float* mf = mod + (size_t)L * 12 * D;

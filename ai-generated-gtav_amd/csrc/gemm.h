@@ -44,6 +44,7 @@ struct GemmParams {
     int out_sc1;   // set by launch_gemm: 16-byte output stores bypass-and-drop in L2 (large outputs)
     int splitk;    // EPI_PARTIAL only: number of K slices (grid = tiles * splitk); (K / 64) % splitk == 0
     const float* bias;  // [N] or nullptr
+    void* out2;         // EPI_F16_TILED only, optional: a second tile-major f16 image = GELU-tanh of the values written to `out` (training forward: u and h = GELU(u))
     void* out;          // EPI_F32/RESID/PARTIAL: f32 row-major [M][ldo]; EPI_F16: f16 row-major [M][ldo];
                         // EPI_GELU_*: f16 TILE-MAJOR with logical row length ldo (the next GEMM's K)
     int ldo;

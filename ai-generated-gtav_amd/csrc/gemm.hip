@@ -1149,15 +1149,45 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
         __syncthreads();
         const int nkt_out = p.ldo >> 6, last_rt = (p.M - 1) >> 7;
         constexpr int PR = TM / 8;                      // 1-KiB pieces (8 token rows) per 64-feature sub-tile column
-        for (int q = wraw; q < CT * PR; q += (int)(blockDim.x >> 6)) {
-            const int cs = q / PR, pq = q - cs * PR;
-            const int gr = m0 + 8 * pq;                 // first token row of the piece (m0 % 8 == 0)
-            const int rt = gr >> 7;
-            if (rt > last_rt || (n0 >> 6) + cs >= nkt_out) continue;   // ragged last block tile (tokens / features)
-            const uint4 val = *(const uint4*)(smem + (cs * TM + 8 * pq) * 128 + lane * 16);
-            char* dst = (char*)p.out + ((size_t)rt * nkt_out + (n0 >> 6) + cs) * TILE_BYTES + ((gr & 127) >> 3) * 1024 + lane * 16;
-            if (p.out_sc1) store16q_sc1(dst, val);
-            else *(uint4*)dst = val;
+        auto copy_out = [&](void* out) {
+            for (int q = wraw; q < CT * PR; q += (int)(blockDim.x >> 6)) {
+                const int cs = q / PR, pq = q - cs * PR;
+                const int gr = m0 + 8 * pq;                 // first token row of the piece (m0 % 8 == 0)
+                const int rt = gr >> 7;
+                if (rt > last_rt || (n0 >> 6) + cs >= nkt_out) continue;   // ragged last block tile (tokens / features)
+                const uint4 val = *(const uint4*)(smem + (cs * TM + 8 * pq) * 128 + lane * 16);
+                char* dst = (char*)out + ((size_t)rt * nkt_out + (n0 >> 6) + cs) * TILE_BYTES + ((gr & 127) >> 3) * 1024 + lane * 16;
+                if (p.out_sc1) store16q_sc1(dst, val);
+                else *(uint4*)dst = val;
+            }
+        };
+        copy_out(p.out);
+        if constexpr (EPI == EPI_F16_TILED && !FOLD) {
+            // Training forward (fc1): a SECOND tile-major image, GELU-tanh of the fp16 values just written (p.out2: h = GELU(u) beside the pre-activation u the
+            // backward pass needs) — from the accumulators, rounded to fp16 first, so h is bit-identical to what the flat elementwise kernel computed from u;
+            // that kernel read and wrote 94 MB per launch at batch 16.
+            if (p.out2) {
+                __syncthreads();   // the first image has been copied out
+                if (compute_wave) {
+                    float dummy = 0.f;
+#pragma unroll
+                    for (int i = 0; i < FI; ++i) {
+                        const int nl = 16 * FI * wn + 16 * i + 4 * g;
+                        const f32x4 bv = pbias[i];
+                        const int c = nl & 63;
+#pragma unroll
+                        for (int j = 0; j < FJ; ++j) {
+                            const int ml = 16 * FJ * wm + 16 * j + li;
+                            char* dst = smem + ((nl >> 6) * TM + ml) * 128 + (((c >> 3) ^ (ml & 7)) << 4) + (c & 7) * 2;
+                            const f32x4 v = acc[i][j] + bv;
+                            const f16x4 u16 = sat4(v[0], v[1], v[2], v[3], dummy);
+                            *(uint2*)dst = pack4(dummy, gelu_tanh_f((float)u16[0]), gelu_tanh_f((float)u16[1]), gelu_tanh_f((float)u16[2]), gelu_tanh_f((float)u16[3]));
+                        }
+                    }
+                }
+                __syncthreads();
+                copy_out(p.out2);
+            }
         }
         return;
     }
@@ -3089,6 +3119,7 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     GTAV_REQUIRE(shape != 8 && shape != 9 && shape != 16 && shape != 21 && shape != 23 && shape != 25 && shape != 27 && shape != 28 && shape != 30 && shape != 32 &&
                  shape != 33 && shape != 40 && shape != 42, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
 #endif
+    GTAV_REQUIRE(!p.out2 || (EPI == EPI_F16_TILED && shape != 31 && shape != 41), "gemm: a second output image (out2) exists for EPI_F16_TILED on the staged epilogue only (epilogue %d, block shape %d)", (int)EPI, shape);
     if (shape == 41) {   // persistent 256-token tiles (round 4): 192 x 256 (N x M)
         if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent 256-token-tile kernel splits K itself (one slab, N %% 8 == 0)");

@@ -358,19 +358,17 @@ __global__ __launch_bounds__(256) void gate_bwd_fused_kernel(const float* __rest
 // Row splits: with `ws` the per-split column sums go to ws[split][N] and colsum_reduce_kernel adds them to db in split order — a fixed
 // summation order (bit-reproducible gradients: the resume test compares weights bit for bit); without it (one split) the block adds directly.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int splits, int N, float* __restrict__ db) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    // four independent chains (a fixed order all the same): one chain of `splits` dependent adds made this launch one memory round trip per split
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-    int sp = 0;
-    for (; sp + 4 <= splits; sp += 4) {
-        t0 += ws[(size_t)sp * N + n];
-        t1 += ws[(size_t)(sp + 1) * N + n];
-        t2 += ws[(size_t)(sp + 2) * N + n];
-        t3 += ws[(size_t)(sp + 3) * N + n];
-    }
-    for (; sp < splits; ++sp) t0 += ws[(size_t)sp * N + n];
-    db[n] += (t0 + t1) + (t2 + t3);
+    // block = 32 columns x 8 split lanes: lane j of a column adds splits j, j + 8, ... (independent loads), the eight lane sums are added in lane order through LDS.
+    // (one thread per column made this launch `splits` dependent memory round trips on 4-16 blocks: 7 us for a few hundred KB)
+    __shared__ float part[8][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cl;
+    float t = 0.f;
+    if (n < N)
+        for (int sp = sl; sp < splits; sp += 8) t += ws[(size_t)sp * N + n];
+    part[sl][cl] = t;
+    __syncthreads();
+    if (sl == 0 && n < N) db[n] += ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) + ((part[4][cl] + part[5][cl]) + (part[6][cl] + part[7][cl]));
 }
 __global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block, float* __restrict__ ws) {
     __shared__ float part[32][65];
@@ -1316,7 +1314,7 @@ int launch_gelu_bwd_tiled_colsum(const f16* dh, const f16* u, f16* du, int M, in
     GTAV_REQUIRE(N % 64 == 0 && M > 0 && ws && db, "gelu_bwd_colsum: M=%d N=%d", M, N);
     const int Mp = round_up(M, 128), splits = cdiv(Mp, 512);
     hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dh, u, du, M, Mp, N, cdiv(Mp, splits), ws, err_flag);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, ws, splits, N, db);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, stream, ws, splits, N, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1364,7 +1362,7 @@ int launch_gate_bwd_fused(const float* dres, const f16* y, const float* gate, in
                           float* ws, int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(D % 64 == 0 && frames > 0 && P > 0 && ws && db, "gate_bwd_fused: D=%d frames=%d P=%d", D, frames, P);
     hipLaunchKernelGGL(gate_bwd_fused_kernel, dim3(D / 64, frames), dim3(256), 0, stream, dres, y, gate, mod_stride, P, D, dy_tiled, dgate, ws, err_flag);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, stream, ws, frames, D, db);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 32)), dim3(256), 0, stream, ws, frames, D, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1374,7 +1372,7 @@ int launch_colsum_tiled_f16(const f16* dy, int M, int N, float* db, float* ws, h
     const int splits = cdiv(M, 512);
     GTAV_REQUIRE(splits == 1 || ws, "colsum: %d row splits need the partial-sum workspace", splits);
     hipLaunchKernelGGL(colsum_tiled_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dy, M, N, db, cdiv(M, splits), splits > 1 ? ws : nullptr);
-    if (splits > 1) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, ws, splits, N, db);
+    if (splits > 1) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, stream, ws, splits, N, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1382,7 +1380,7 @@ int launch_colsum_f32(const float* a, int lda, int M, int N, float* db, float* w
     const int splits = cdiv(M, 256);
     GTAV_REQUIRE(splits == 1 || ws, "colsum: %d row splits need the partial-sum workspace", splits);
     hipLaunchKernelGGL(colsum_f32_kernel, dim3(cdiv(N, 256), splits), dim3(256), 0, stream, a, lda, M, N, db, cdiv(M, splits), splits > 1 ? ws : nullptr);
-    if (splits > 1) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, stream, ws, splits, N, db);
+    if (splits > 1) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, stream, ws, splits, N, db);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
