@@ -997,17 +997,16 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_mfma_kernel(const float* __re
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[b], av[a], acc[a][b], 0, 0, 0);
     }
-    // D[row = n 16 a + 4 g + e][col = k 16 b + li]
+    // X is the A operand: D[row = k 16 b + 4 g + e][col = n 16 a + li] — a lane holds four CONSECUTIVE k of one n: one 16-byte read-modify-write per tile
+    // (with dY as the A operand it held four n of one k: sixteen 4-byte read-modify-writes per lane where there are four now; same products, same order)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+        float* o = dW + (size_t)(n0 + 16 * a + li) * lddw + k0 + 4 * g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float* o = dW + (size_t)(n0 + 16 * a + 4 * g + e) * lddw + k0 + li;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) o[16 * b] += acc[a][b][e];
-        }
+        for (int b = 0; b < 4; ++b) *(f32x4*)(o + 16 * b) = *(const f32x4*)(o + 16 * b) + acc[a][b];
+    }
 }
 // dX[r][k] = sum_n dY[r][n] W[n][k]       (one thread per (r, k))
 __global__ void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ W, int ldw, int R, int N, int K, float* __restrict__ dX,
