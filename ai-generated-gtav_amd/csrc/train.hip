@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const f16* __restr
         union { uint4 q; f16 e[8]; } x, b, o;
         x.q = *(const uint4*)(dh + off);
         b.q = *(const uint4*)(u + off);
-        const float real = r < M ? 1.0f : 0.0f;
+        const bool real = r < M;   // (pad rows of the 128-row image are transformed like the others but must not reach the sums — they may hold anything, NaN included)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xx = (float)b.e[j];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const f16* __restr
             const float v = (float)x.e[j] * g;
             amax = fmaxf(amax, fabsf(v));
             o.e[j] = (f16)__builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
-            a[j] += real * v;
+            a[j] += real ? v : 0.f;
         }
         *(uint4*)(du + off) = o.q;
     }

@@ -215,6 +215,8 @@ def test_full_size_gradients_grouped_weight_gradient_launch(B, T):
     v = m.forward_train(x, t, a)
     assert rel_l2(v, v_ref) < 1e-3
     keys = [f"blocks.{l}.{h}_{n}.weight" for l in (0, 7, 15) for h in "st" for n in ("attn.to_qkv", "attn.to_out", "mlp.fc1", "mlp.fc2")]
+    # ... and what the fused elementwise backward kernels produce at this width (bias gradients from the gate / GELU passes, adaLN gradients from the LayerNorm pass)
+    keys += ["blocks.7.s_mlp.fc1.bias", "blocks.7.t_mlp.fc2.bias", "blocks.7.t_attn.to_out.bias", "blocks.0.s_adaLN_modulation.1.weight", "blocks.15.t_adaLN_modulation.1.bias"]
     runs = []
     for _ in range(2):
         m.zero_grad()
