@@ -1815,7 +1815,7 @@ static int op_sk_workspace(GemmParams& g) {
 }
 int gtav_op_gemm_f16(const void* x, int32_t ldx, const void* w, const float* bias, void* out, int32_t ldo, int32_t M, int32_t N,
                      int32_t K, int32_t epilogue, const float* gate, int32_t gate_stride, int32_t rows_per_gate, void* stream) {
-    GTAV_REQUIRE((epilogue >= 0 && epilogue <= 4) || epilogue == EPI_PARTIAL, "op_gemm_f16: epilogue %d", epilogue);
+    GTAV_REQUIRE((epilogue >= 0 && epilogue <= 4) || epilogue == EPI_PARTIAL || epilogue == EPI_F16_TILED, "op_gemm_f16: epilogue %d", epilogue);
     GemmParams g;
     memset(&g, 0, sizeof(g));
     RET_IF(op_sk_workspace(g));

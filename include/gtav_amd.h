@@ -280,7 +280,8 @@ int gtav_latents_to_tokens(const float* lat_dev, float* z_dev, int32_t N, int32_
  * Kernel-level entry points (used by the parity tests in tests/ and by bench.py's roofline probe)
  * ---------------------------------------------------------------------------------------------- */
 /* epilogues: 0 f32, 1 f16, 2 gelu-tanh f16, 3 gelu-erf f16, 4 residual (+gate) f32 in place,
- * 6 split-K partial slabs out[ks][M][N] f32 (the split factor is passed in gate_stride) */
+ * 6 split-K partial slabs out[ks][M][N] f32 (the split factor is passed in gate_stride), 7 f16 tile-major without an activation (the training forward's
+ * MLP pre-activation; rows padded to 128, ldo % 64 == 0) */
 int gtav_op_gemm_f16(const void* x_f16_dev, int32_t ldx, const void* w_f16_dev, const float* bias_dev, void* out_dev,
                      int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* gate_dev,
                      int32_t gate_stride, int32_t rows_per_gate, void* stream);

@@ -26,6 +26,8 @@ def main():
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     shapes = [("qkv", 3072, 1024, 5), ("qkvt", 3072, 1024, 7), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]   # epi 7 here = temporal QKV
+    if "train" in a.only:   # GEMMs of the training step without an activation: fc1 forward / fc2 dX (fp16 tile-major out, code 70 = EPI_F16_TILED), fc1 dX / to_qkv dX (fp32 out)
+        shapes += [("train_f16t", 4096, 1024, 70), ("train_f32_k4096", 1024, 4096, 0), ("train_f32_k3072", 1024, 3072, 0)]
     if "floor" in a.only:   # one K-step only: launch + first tile + epilogue (the per-launch floor of each epilogue)
         shapes += [("floor_gelu", 4096, 64, 2), ("floor_f32", 4096, 64, 0), ("floor_part", 1024, 64, 6), ("floor_n128", 128, 64, 0)]
     print(f"{'shape':>5} {'M':>6} {'N':>5} {'K':>5} {'ns':>3} {'split':>5} {'us':>9} {'TFLOP/s':>9}")
@@ -66,7 +68,7 @@ def main():
                         g = lib.gtav_op_gemm_splitk_ln  # noqa: F841  (partial GEMM only: use the raw op below)
                         L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), 0, out.data_ptr(), N, M, N, K, 6, 0, sk, 1, st))
                     else:
-                        L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, M, N, K, epi, 0, 0,
+                        L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, M, N, K, 7 if epi == 70 else epi, 0, 0,
                                                      1, st))
                 try:
                     for i in range(8):
