@@ -15,27 +15,36 @@ namespace {
 // stream; at hundreds — the adaLN table of a batch-8 frame, 808 rows x 198 656 features — FT = RT = 1 was bound by the LDS read per four MFMAs (11.3 ms = 30 TFLOP/s),
 // FT = 4 by re-streaming W_ada once per 16 rows (7.2 ms = 5.9 TB/s out of L2 / Infinity Cache), hence 32-row slabs on top (tools/skinny_bench.py).  Per output the
 // same fp32 fma chain in the same order for every FT / RT.
-template <int ACT, int FT, int RT>
+// KC = 0: the whole K of the slab is staged once (RT <= 2 at K = 1024).  KC > 0 (round 4): the slab is staged KC columns at a time, which lets a block keep 80-112 rows
+// (RT = 5 .. 7): W_ada is then streamed ONCE for the 80 rows of a training batch / the 101 rows of a batch-1 frame instead of three or four times, and 9 instead of 26
+// times for the 808 rows of a batch-8 frame.
+template <int ACT, int FT, int RT, int KC = 0>
 __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ Y, int ldy,
                                                         int M, int N, int K) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [16 RT][K + 8]
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [16 RT][(KC ? KC : K) + 8]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * 16 * RT;
     const int n0 = (blockIdx.x * 4 + w) * 16 * FT;
-    const int ldk = K + 8;
+    const int kspan = KC ? KC : K;          // columns staged at a time (K % KC == 0, host-checked)
+    const int ldk = kspan + 8;
+    const bool live = n0 < N;               // (with KC every wave takes part in the staging barriers)
 
-    // stage the X slab (rows beyond M are zero)
-    const int kq = K >> 2;
-    for (int idx = tid; idx < 16 * RT * kq; idx += 256) {
-        const int r = idx / kq, c = idx - r * kq;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M) v = *(const f32x4*)(X + (size_t)(m0 + r) * ldx + 4 * c);
-        *(f32x4*)(xs + r * ldk + 4 * c) = v;
+    auto stage = [&](int k0) {              // rows beyond M are zero
+        const int kq = kspan >> 2;
+        for (int idx = tid; idx < 16 * RT * kq; idx += 256) {
+            const int r = idx / kq, c = idx - r * kq;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m0 + r < M) v = *(const f32x4*)(X + (size_t)(m0 + r) * ldx + k0 + 4 * c);
+            *(f32x4*)(xs + r * ldk + 4 * c) = v;
+        }
+    };
+    if constexpr (KC == 0) {
+        stage(0);
+        __syncthreads();
+        if (!live) return;
     }
-    __syncthreads();
-    if (n0 >= N) return;
 
     const float* wp[FT];
 #pragma unroll
@@ -51,8 +60,15 @@ __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // K % 32 == 0; each step covers 32 k: lane group g holds k = kb + 16 i + 4 g + e
+    for (int k0 = 0; k0 < K; k0 += kspan) {
+    if constexpr (KC != 0) {
+        if (k0) __syncthreads();            // every wave has read the chunk before
+        stage(k0);
+        __syncthreads();
+    }
+    if (live)
 #pragma unroll 2
-    for (int kb = 0; kb < K; kb += 32) {
+    for (int kb = 0; kb < kspan; kb += 32) {
         f32x4 x0[RT], x1[RT], w0[FT], w1[FT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
@@ -61,8 +77,8 @@ __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict
         }
 #pragma unroll
         for (int f = 0; f < FT; ++f) {
-            w0[f] = *(const f32x4*)(wp[f] + kb);
-            w1[f] = *(const f32x4*)(wp[f] + kb + 16);
+            w0[f] = *(const f32x4*)(wp[f] + k0 + kb);
+            w1[f] = *(const f32x4*)(wp[f] + k0 + kb + 16);
         }
 #pragma unroll
         for (int f = 0; f < FT; ++f)
@@ -74,6 +90,8 @@ __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict
                 for (int e = 0; e < 4; ++e) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[f][e], x1[t][e], acc[f][t], 0, 0, 0);
             }
     }
+    }
+    if (!live) return;
     // D[row = feature 4g + r][col = X row li]
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -98,6 +116,7 @@ __global__ __launch_bounds__(256) void skinny_f32_kernel(const float* __restrict
 
 // (FT, RT) variants: (1, 1) small projections; (4, 1) many features, tens of rows (the adaLN table at batch 1); (4, 2) / (8, 2) hundreds of rows
 #define GTAV_SKINNY_VARIANTS(X) X(0, 1, 1) X(1, 1, 1) X(0, 4, 1) X(1, 4, 1) X(0, 4, 2) X(1, 4, 2) X(0, 8, 2)
+#define GTAV_SKINNY_CHUNKED(X) X(5) X(6) X(7)   // (ACT 0, FT 4, RT, KC 128)
 int skinny_init() {
     static unsigned long long done_devs = 0;   // the attribute is per device (see attention.hip)
     int devid = 0;
@@ -106,6 +125,9 @@ int skinny_init() {
 #define GTAV_SKINNY_ATTR(A, F, R) GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<A, F, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     GTAV_SKINNY_VARIANTS(GTAV_SKINNY_ATTR)
 #undef GTAV_SKINNY_ATTR
+#define GTAV_SKINNY_ATTR_C(R) GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)skinny_f32_kernel<0, 4, R, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GTAV_SKINNY_CHUNKED(GTAV_SKINNY_ATTR_C)
+#undef GTAV_SKINNY_ATTR_C
     done_devs |= 1ull << (devid & 63);
     return 0;
 }
@@ -126,6 +148,19 @@ int launch_skinny_f32(const float* X, int ldx, const float* W, const float* bias
             rt = 2;
             if (!act_silu && (long long)cdiv(N, 512) * cdiv(M, 32) >= ft_min_blocks) ft = 8;
         }
+    }
+    // many features, more than two row tiles, no activation (the adaLN table): 80-112 rows per block on K chunks of 128 (44-61 KiB of LDS: two or three blocks per CU) — W is streamed once per 5-7 row tiles
+    static const int chunked = GTAV_ENV_INT("GTAV_SKINNY_CHUNKED", 1);   // experiments build: 0 = the whole-K slabs above (A/B)
+    if (chunked && !act_silu && M > 32 && K % 128 == 0 && (long long)cdiv(N, 256) >= 256 && variant == 0) {
+        const int tiles = cdiv(M, 16);
+        const int rtc = tiles <= 5 ? 5 : tiles == 6 ? 6 : tiles == 7 ? 7 : 6;   // one block of rows up to 112 rows, 96-row blocks beyond
+        dim3 grid(cdiv(N, 256), cdiv(M, 16 * rtc)), block(256);
+        const size_t lds = (size_t)16 * rtc * (128 + 8) * sizeof(float);
+#define GTAV_SKINNY_LAUNCH_C(R) if (rtc == R) hipLaunchKernelGGL((skinny_f32_kernel<0, 4, R, 128>), grid, block, lds, stream, X, ldx, W, bias, Y, ldy, M, N, K);
+        GTAV_SKINNY_CHUNKED(GTAV_SKINNY_LAUNCH_C)
+#undef GTAV_SKINNY_LAUNCH_C
+        GTAV_CHECK_HIP(hipGetLastError());
+        return 0;
     }
     if (variant == 41) ft = 4, rt = 1;
     if (variant == 42) ft = 4, rt = 2;

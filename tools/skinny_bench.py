@@ -8,7 +8,7 @@ lib = L.load_experiments()
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream().cuda_stream
 N, K = 198656, 1024
 w = torch.randn(N, K, device=dev) * 0.03; b = torch.randn(N, device=dev)
-for M in (101, 808):
+for M in (80, 101, 808):
     x = torch.randn(M, K, device=dev); y = torch.empty(M, N, device=dev)
     run = lambda: L.check(lib.gtav_op_skinny_f32(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, N, K, 0, st))
     for _ in range(2): run()
