@@ -1009,24 +1009,44 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_mfma_kernel(const float* __re
     }
 }
 // dX[r][k] = sum_n dY[r][n] W[n][k]       (one thread per (r, k))
-// Block = one wave = 64 columns k x up to 16 rows r: W[n][k] is loaded once per n for the block's rows (their dY values are wave-uniform).  One thread per (r, k)
-// with its own pass over W was 370 us for the 80 x 1024 x 1024 product of the conditioning path's backward.
+// Block = one wave = 64 columns k x up to 16 rows r (80 blocks for the 80 x 1024 product: a wider block leaves most of the chip idle); the rows of dY sit in LDS (broadcast reads), W[n][k] is loaded once per n for the block's rows.  One thread per (r, k)
+// with its own pass over W was 370 us for the 80 x 1024 x 1024 product of the conditioning path's backward (a first rewrite that kept dY in global memory: 570 us).
+template <int RB>
 __global__ __launch_bounds__(64) void gemm_nn_f32_kernel(const float* __restrict__ dY, int lddy, const float* __restrict__ W, int ldw, int R, int N, int K,
-                                                         float* __restrict__ dX, int lddx) {
-    constexpr int RB = 16;
+                                                          float* __restrict__ dX, int lddx) {
+    extern __shared__ __attribute__((aligned(16))) float sdy[];   // [RB][N]  (N % 4 == 0)
     const int k = blockIdx.x * 64 + threadIdx.x;
     const int r0 = blockIdx.y * RB;
+    for (int idx = threadIdx.x; idx < RB * (N / 4); idx += 64) {
+        const int i = idx / (N / 4), c = idx - i * (N / 4);
+        const int r = r0 + i < R ? r0 + i : R - 1;              // (clamped rows compute a value nobody stores)
+        *(f32x4*)(sdy + (size_t)i * N + 4 * c) = *(const f32x4*)(dY + (size_t)r * lddy + 4 * c);
+    }
+    __syncthreads();
     if (k >= K) return;
     float a[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) a[i] = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float w = W[(size_t)n * ldw + k];
+    // sixteen rows of W at a time, the next sixteen requested before the current ones are used (N % 16 == 0, host-checked): with four loads per iteration and
+    // nothing in flight across iterations the loop was a chain of 256 memory round trips (160 us)
+    float w[16], wn[16];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int r = r0 + i < R ? r0 + i : R - 1;          // (clamped rows compute a value nobody stores)
-            a[i] += dY[(size_t)r * lddy + n] * w;
+    for (int e = 0; e < 16; ++e) w[e] = W[(size_t)e * ldw + k];
+    for (int n = 0; n < N; n += 16) {
+        if (n + 16 < N) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wn[e] = W[(size_t)(n + 16 + e) * ldw + k];
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const f32x4 d = *(const f32x4*)(sdy + (size_t)i * N + n + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[i] += d[e] * w[4 * q + e];   // n ascending: the order of the kernel it replaces
+            }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) w[e] = wn[e];
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i)
@@ -1478,7 +1498,13 @@ int launch_gemm_tn_f32(const float* dY, int lddy, const float* X, int ldx, int R
     return 0;
 }
 int launch_gemm_nn_f32(const float* dY, int lddy, const float* W, int ldw, int R, int N, int K, float* dX, int lddx, hipStream_t stream) {
-    hipLaunchKernelGGL(gemm_nn_f32_kernel, dim3(cdiv(K, 64), cdiv(R, 16)), dim3(64), 0, stream, dY, lddy, W, ldw, R, N, K, dX, lddx);
+    GTAV_REQUIRE(N % 16 == 0 && lddy % 4 == 0 && (size_t)4 * N * sizeof(float) <= 64 * 1024, "gemm_nn_f32: N=%d (a multiple of 16; 4 rows of dY must fit 64 KiB of LDS)", N);
+    if ((size_t)16 * N * sizeof(float) <= 64 * 1024)   // rows of dY per block: as many of 16 / 8 / 4 as fit 64 KiB of LDS
+        hipLaunchKernelGGL(gemm_nn_f32_kernel<16>, dim3(cdiv(K, 64), cdiv(R, 16)), dim3(64), (size_t)16 * N * sizeof(float), stream, dY, lddy, W, ldw, R, N, K, dX, lddx);
+    else if ((size_t)8 * N * sizeof(float) <= 64 * 1024)
+        hipLaunchKernelGGL(gemm_nn_f32_kernel<8>, dim3(cdiv(K, 64), cdiv(R, 8)), dim3(64), (size_t)8 * N * sizeof(float), stream, dY, lddy, W, ldw, R, N, K, dX, lddx);
+    else
+        hipLaunchKernelGGL(gemm_nn_f32_kernel<4>, dim3(cdiv(K, 64), cdiv(R, 4)), dim3(64), (size_t)4 * N * sizeof(float), stream, dY, lddy, W, ldw, R, N, K, dX, lddx);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
