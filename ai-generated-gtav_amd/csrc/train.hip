@@ -982,22 +982,33 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_mfma_kernel(const float* __re
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* dy = dY + n0 + li;
     const float* x = X + k0 + li;
-#pragma unroll 2
-    for (int r0 = 0; r0 < R; r0 += 4) {
-        const int r = r0 + g;
-        const bool ok = r < R;
-        const size_t rr = ok ? r : 0;
-        float av[4], bv[4];
+    // the gradient tile this wave accumulates into is requested FIRST (its read used to start after the main loop), and the operand values of sixteen conditioning rows
+    // are requested together (four dependent round trips per sixteen rows before): the launch is a handful of memory round trips, not FLOPs
+    f32x4 old[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            av[t] = dy[rr * lddy + 16 * t];
-            bv[t] = x[rr * ldx + 16 * t];
-            if (!ok) av[t] = 0.f;
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) old[a][b] = *(const f32x4*)(dW + (size_t)(n0 + 16 * a + li) * lddw + k0 + 4 * g + 16 * b);
+    for (int r0 = 0; r0 < R; r0 += 16) {
+        float av[4][4], bv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 4 * q + g;
+            const bool ok = r < R;
+            const size_t rr = ok ? r : 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                av[q][t] = dy[rr * lddy + 16 * t];
+                bv[q][t] = x[rr * ldx + 16 * t];
+                if (!ok) av[q][t] = 0.f;
+            }
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int q = 0; q < 4; ++q)     // rows in ascending order per output: the fma chain of the loop this replaces
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[b], av[a], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[q][b], av[q][a], acc[a][b], 0, 0, 0);
     }
     // X is the A operand: D[row = k 16 b + 4 g + e][col = n 16 a + li] — a lane holds four CONSECUTIVE k of one n: one 16-byte read-modify-write per tile
     // (with dY as the A operand it held four n of one k: sixteen 4-byte read-modify-writes per lane where there are four now; same products, same order)
@@ -1005,7 +1016,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_mfma_kernel(const float* __re
     for (int a = 0; a < 4; ++a) {
         float* o = dW + (size_t)(n0 + 16 * a + li) * lddw + k0 + 4 * g;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) *(f32x4*)(o + 16 * b) = *(const f32x4*)(o + 16 * b) + acc[a][b];
+        for (int b = 0; b < 4; ++b) *(f32x4*)(o + 16 * b) = old[a][b] + acc[a][b];
     }
 }
 // dX[r][k] = sum_n dY[r][n] W[n][k]       (one thread per (r, k))
