@@ -1266,6 +1266,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
     };
     const size_t ws_cap = colsum_workspace(h->Mmax > h->max_rows ? h->Mmax : h->max_rows, h->Hm_pad > 6 * D ? h->Hm_pad : 6 * D);   // floats of tr.red_ws
     const bool fuse_gate = g_fuse_gate && M == NB * P && (size_t)NB * D <= ws_cap;
+    const bool defer_bias = fuse_gate && g_fuse_gelu && (size_t)2 * NB * D + (size_t)gelu_bwd_colsum_splits(M) * Hp <= ws_cap;
     auto flush_dw = [&]() -> int {
         if (!ndw) return 0;
         const int n = ndw;
@@ -1341,8 +1342,10 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         const float* mb = mod + (size_t)i * 6 * D;
         float* dmb = dmod + (size_t)i * 6 * D;
         // r_{2i+2} = r_{2i+1} + gate_mlp y2
+        // (defer_bias: the partial sums of the half-block's three bias gradients go to three regions of the workspace and ONE launch adds them at the end of the half-block)
+        float* const ws_fc2 = tr.red_ws, *const ws_out = tr.red_ws + (defer_bias ? (size_t)NB * D : 0), *const ws_fc1 = tr.red_ws + (defer_bias ? (size_t)2 * NB * D : 0);   // (not deferred: every reduction follows its partial sums at once and the regions may coincide)
         if (fuse_gate) {
-            RET_IF(launch_gate_bwd_fused(tr.dres, b.y2, mb + 5 * D, MODW, NB, P, D, tr.g_d, dmb + 5 * D, slot(P_ + "mlp.fc2.bias").grad, tr.red_ws, h->err_flag, s));
+            RET_IF(launch_gate_bwd_fused(tr.dres, b.y2, mb + 5 * D, MODW, NB, P, D, tr.g_d, dmb + 5 * D, defer_bias ? nullptr : slot(P_ + "mlp.fc2.bias").grad, ws_fc2, h->err_flag, s));
         } else {
             RET_IF(launch_gate_bwd(tr.dres, mb + 5 * D, MODW, P, M, D, tr.g_d, h->err_flag, s));
             RET_IF(launch_frame_reduce_gate(tr.dres, b.y2, NB, P, D, dmb + 5 * D, MODW, s));
@@ -1350,7 +1353,9 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         }
         RET_IF(gemm_dw(tr.g_d, D, b.hh, Hp, slot(P_ + "mlp.fc2.weight").grad, 0));
         RET_IF(gemm_dx(tr.g_d, slot(P_ + "mlp.fc2.weight").wT, Hp, D, EPI_F16_TILED, tr.g_h, Hp));
-        if (g_fuse_gelu && colsum_workspace(round_up(M, 128), Hp) <= ws_cap) {
+        if (defer_bias) {
+            RET_IF(launch_gelu_bwd_tiled_colsum(tr.g_h, b.u, tr.g_u, M, Hp, nullptr, ws_fc1, h->err_flag, s));
+        } else if (g_fuse_gelu && colsum_workspace(round_up(M, 128), Hp) <= ws_cap) {
             RET_IF(launch_gelu_bwd_tiled_colsum(tr.g_h, b.u, tr.g_u, M, Hp, slot(P_ + "mlp.fc1.bias").grad, tr.red_ws, h->err_flag, s));
         } else {
             RET_IF(launch_gelu_bwd_tiled(tr.g_h, b.u, tr.g_u, (size_t)round_up(M, 128) * Hp, h->err_flag, s));
@@ -1362,7 +1367,7 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         // r_{2i+1} = r_{2i} + gate_msa y1
         f16* const g_o = tn_dw ? tr.g_d2 : tr.g_d;   // (the fc2 weight gradient above still reads g_d when the grouped launch is deferred without copies)
         if (fuse_gate) {
-            RET_IF(launch_gate_bwd_fused(tr.dres, b.y1, mb + 2 * D, MODW, NB, P, D, g_o, dmb + 2 * D, slot(P_ + "attn.to_out.bias").grad, tr.red_ws, h->err_flag, s));
+            RET_IF(launch_gate_bwd_fused(tr.dres, b.y1, mb + 2 * D, MODW, NB, P, D, g_o, dmb + 2 * D, defer_bias ? nullptr : slot(P_ + "attn.to_out.bias").grad, ws_out, h->err_flag, s));
         } else {
             RET_IF(launch_gate_bwd(tr.dres, mb + 2 * D, MODW, P, M, D, g_o, h->err_flag, s));
             RET_IF(launch_frame_reduce_gate(tr.dres, b.y1, NB, P, D, dmb + 2 * D, MODW, s));
@@ -1373,6 +1378,12 @@ int gtav_dit_train_backward_phases(gtav_dit* h, const float* v_pred, const float
         if (hf == 0) RET_IF(launch_attn_spatial_bwd(b.q, b.k, b.v, tr.dao, NB, h->heads, P, D, h->rope_s.cs_dev, tr.g_qkv, h->err_flag, s));
         else RET_IF(launch_attn_temporal_bwd(b.q, b.k, tr.dao, B, P, D, T, h->maxT, h->rope_t.cs_dev, tr.g_qkv, h->err_flag, s));
         RET_IF(gemm_dw(tr.g_qkv, 3 * D, b.xnA, D, slot(P_ + "attn.to_qkv.weight").grad, 3));
+        if (defer_bias) {
+            const float* wsv[3] = {ws_fc2, ws_out, ws_fc1};
+            float* dbv[3] = {slot(P_ + "mlp.fc2.bias").grad, slot(P_ + "attn.to_out.bias").grad, slot(P_ + "mlp.fc1.bias").grad};
+            const int spv[3] = {NB, NB, gelu_bwd_colsum_splits(M)}, nv[3] = {D, D, Hp};
+            RET_IF(launch_colsum_reduce_multi(wsv, dbv, spv, nv, 3, s));
+        }
         RET_IF(flush_dw());
         RET_IF(gemm_dx(tr.g_qkv, slot(P_ + "attn.to_qkv.weight").wT, D, 3 * D, EPI_F32, tr.dtmp, D));
         RET_IF(ln_bwd(tr.dtmp, tr.res[2 * i], mb + D, 1, dmb, dmb + D));

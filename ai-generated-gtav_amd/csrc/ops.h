@@ -153,6 +153,9 @@ int launch_frame_reduce_ln(const float* dxn, const float* x, const float* stats,
                            hipStream_t stream);
 // launch_gelu_bwd_tiled + the column sums of its output (db[n] += sum_m du[m][n]) in one pass
 int launch_gelu_bwd_tiled_colsum(const f16* dh, const f16* u, f16* du, int M, int N, float* db, float* ws, int* err_flag, hipStream_t stream);
+// db == nullptr in the two fused launchers: the per-split / per-frame partial sums stay in ws and the caller adds them later, several bias gradients per launch
+int gelu_bwd_colsum_splits(int M);
+int launch_colsum_reduce_multi(const float* const* ws, float* const* db, const int* splits, const int* N, int njobs, hipStream_t stream);
 // launch_ln_mod_bwd + launch_frame_reduce_ln in one pass over dxn and x (M = frames x P rows)
 bool ln_bwd_fused_ok(int D);
 size_t ln_bwd_fused_workspace(int frames, int P, int D);

@@ -370,6 +370,23 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     __syncthreads();
     if (sl == 0 && n < N) db[n] += ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) + ((part[4][cl] + part[5][cl]) + (part[6][cl] + part[7][cl]));
 }
+// up to four column-sum reductions in ONE launch (blockIdx.y = job): the three bias gradients of a half-block (fc2, fc1, out-projection) each paid a launch of their own
+struct ColsumJobs { const float* ws[4]; float* db[4]; int splits[4]; int N[4]; };
+__global__ __launch_bounds__(256) void colsum_reduce_multi_kernel(ColsumJobs jobs) {
+    __shared__ float part[8][33];
+    const int j = blockIdx.y;
+    const float* ws = jobs.ws[j];
+    const int N = jobs.N[j], splits = jobs.splits[j];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cl;
+    if (blockIdx.x * 32 >= N) return;      // (block-uniform)
+    float t = 0.f;
+    if (n < N)
+        for (int sp = sl; sp < splits; sp += 8) t += ws[(size_t)sp * N + n];
+    part[sl][cl] = t;
+    __syncthreads();
+    if (sl == 0 && n < N) jobs.db[j][n] += ((part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl])) + ((part[4][cl] + part[5][cl]) + (part[6][cl] + part[7][cl]));
+}
 __global__ __launch_bounds__(256) void colsum_tiled_kernel(const f16* __restrict__ dy, int M, int N, float* __restrict__ db, int rows_per_block, float* __restrict__ ws) {
     __shared__ float part[32][65];
     const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -1369,11 +1386,12 @@ int launch_gelu_bwd_tiled(const f16* dh, const f16* u, f16* du, size_t n, int* e
     return 0;
 }
 // launch_gelu_bwd_tiled + launch_colsum_tiled_f16(du -> db) in one pass: dh / u / du tile-major [round_up(M, 128)][N]; ws = colsum_workspace(M, N) floats
+int gelu_bwd_colsum_splits(int M) { return cdiv(round_up(M, 128), 512); }
 int launch_gelu_bwd_tiled_colsum(const f16* dh, const f16* u, f16* du, int M, int N, float* db, float* ws, int* err_flag, hipStream_t stream) {
-    GTAV_REQUIRE(N % 64 == 0 && M > 0 && ws && db, "gelu_bwd_colsum: M=%d N=%d", M, N);
-    const int Mp = round_up(M, 128), splits = cdiv(Mp, 512);
+    GTAV_REQUIRE(N % 64 == 0 && M > 0 && ws, "gelu_bwd_colsum: M=%d N=%d", M, N);
+    const int Mp = round_up(M, 128), splits = gelu_bwd_colsum_splits(M);
     hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3(N / 64, splits), dim3(256), 0, stream, dh, u, du, M, Mp, N, cdiv(Mp, splits), ws, err_flag);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, stream, ws, splits, N, db);
+    if (db) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, stream, ws, splits, N, db);   // (db == nullptr: the caller reduces ws later, launch_colsum_reduce_multi)
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1419,9 +1437,21 @@ int launch_frame_reduce_gate(const float* dres, const f16* y, int frames, int P,
 // fused form of launch_gate_bwd + launch_frame_reduce_gate + launch_colsum_tiled_f16(dy -> db): ws holds frames x D floats
 int launch_gate_bwd_fused(const float* dres, const f16* y, const float* gate, int mod_stride, int frames, int P, int D, f16* dy_tiled, float* dgate, float* db,
                           float* ws, int* err_flag, hipStream_t stream) {
-    GTAV_REQUIRE(D % 64 == 0 && frames > 0 && P > 0 && ws && db, "gate_bwd_fused: D=%d frames=%d P=%d", D, frames, P);
+    GTAV_REQUIRE(D % 64 == 0 && frames > 0 && P > 0 && ws, "gate_bwd_fused: D=%d frames=%d P=%d", D, frames, P);
     hipLaunchKernelGGL(gate_bwd_fused_kernel, dim3(D / 64, frames), dim3(256), 0, stream, dres, y, gate, mod_stride, P, D, dy_tiled, dgate, ws, err_flag);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 32)), dim3(256), 0, stream, ws, frames, D, db);
+    if (db) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 32)), dim3(256), 0, stream, ws, frames, D, db);   // (db == nullptr: reduced later, launch_colsum_reduce_multi)
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_colsum_reduce_multi(const float* const* ws, float* const* db, const int* splits, const int* N, int njobs, hipStream_t stream) {
+    GTAV_REQUIRE(njobs >= 1 && njobs <= 4, "colsum_reduce_multi: %d jobs", njobs);
+    ColsumJobs jobs = {};
+    int nmax = 0;
+    for (int j = 0; j < njobs; ++j) {
+        jobs.ws[j] = ws[j]; jobs.db[j] = db[j]; jobs.splits[j] = splits[j]; jobs.N[j] = N[j];
+        nmax = N[j] > nmax ? N[j] : nmax;
+    }
+    hipLaunchKernelGGL(colsum_reduce_multi_kernel, dim3(cdiv(nmax, 32), njobs), dim3(256), 0, stream, jobs);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
