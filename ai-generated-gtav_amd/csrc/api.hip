@@ -1560,7 +1560,7 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = dim; q.K = K; q.out = h->parts; q.ldo = dim;
-        if (gemm_pp_ok(M, dim, K, EPI_RESID)) {   // large M: in-place residual epilogue of the ping-pong kernel (see dit_forward_core)
+        if (gemm_resid_inplace_ok(M, dim, K, 0)) {   // large M: in-place residual epilogue of the persistent loader-wave kernel (see dit_forward_core): no slab round trip
             q.out = h->resid; q.bias = bias;
             RET_IF(launch_gemm(q, EPI_RESID, s));
             have_pend = false;

@@ -352,6 +352,267 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __r
     }
 }
 
+// ---- long sequences (S_pad > 160: the VAE's 576 tokens per frame; round 5) ---------------------------------------------------------------
+// attn_spatial_kernel above keeps ALL of K / Vt of a (frame, head) in LDS (148 KB at S = 576: one 4-wave block per CU, whose 144 KB prologue load
+// nothing hides) and walks 16-query tiles one at a time, so every K / Vt fragment read from LDS feeds ONE MFMA (64 B/clk/SIMD = the whole LDS
+// bandwidth at the MFMA issue rate) and every 64-key block pays the online-softmax rescale: 0.106 of the MFMA peak at 40 frames x 16 heads
+// (profiles/round4/train_step_kernel_stats.csv).  This kernel is the flash form of the same arithmetic:
+//   * a block = 4 waves x NQT 16-query tiles (NQT = 3: 192 queries; S = 576 is three blocks per (frame, head), whose ids are 8 apart = one XCD's L2
+//     under round-robin placement, speed only); several blocks per CU (48 KiB of LDS, <= 168 registers)
+//   * K / Vt arrive in 64-key blocks by LDS-DMA (global_load_lds_dwordx4, 4 pieces per wave and block) into a 3-slot ring: counted vmcnt, ONE barrier
+//     per key block, block kb + 2 in flight while block kb is consumed; the bank swizzles are applied to the per-lane SOURCE address (the LDS image
+//     of an LDS-DMA is lane-linear): K rows chunk ^ kswz(key), Vt rows chunk ^ ((d >> 1) & 7): every fragment is one conflict-free ds_read_b128
+//   * every K / Vt fragment feeds NQT MFMAs; S^T = K Q^T and O^T += Vt P^T with the operand maps of the kernels above (P^T straight from the score registers)
+//   * the running maximum moves only when a block's maximum exceeds it by more than 8 in the exponent (P <= 2^8: exact in fp16 to the same 11 bits, the
+//     sums are fp32): the rescale of O is a rare wave-uniform branch instead of 16 NQT multiplies per key block; exponent as ONE fma + v_exp_f32 per score;
+//     the cross-lane maxima are v_permlane16_swap / v_permlane32_swap (no LDS crossbar)
+constexpr float kLazyThr = 8.0f / kScaleLog2e;   // in raw-score units
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr int attn_waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+// 16-byte direct-to-LDS load, scalar-base form: address = sbase (SGPR pair) + voff (32-bit per-lane byte offset); LDS destination = lds_addr (-> M0) + lane * 16
+__device__ __forceinline__ void glds16_s_attn(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+// bank swizzle of the K rows of the flash kernel (16-byte chunk c of key row r sits at c ^ kswz(r)): its lanes read the rows 8 (li >> 2) + (li & 3) (+ 4),
+// and with (r & 7) the lanes li and li + 12 / li + 4 and li + 8 of a ds_read_b128 lane group would share banks; bits 1, 3, 4 of the row separate all sixteen
+__device__ __forceinline__ int kswz(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+// max over the four lanes li, li + 16, li + 32, li + 48 (every lane ends with the result)
+__device__ __forceinline__ float max_over_g(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // rows 1 <-> 0, 3 <-> 2
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // lanes 32-63 <-> 0-31
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float sum_over_g(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+template <int NQT, int OCC>   // OCC = blocks per CU the register budget must admit (launch bound)
+__global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
+                                                            f16* __restrict__ O, int heads, int S, int nfh, int nqb, int sc1) {
+    constexpr int SLOT = 16384, NSLOT = 3;          // per slot: K block [64 keys][128 B] | Vt block [64 d][128 B]
+    __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the LDS-DMA base goes to M0 (no waterfall loop)
+    const int li = lane & 15, g = lane >> 4;
+    // block -> ((frame, head), query block).  The nqb query blocks of one (frame, head) re-read the same K / Vt: give them ids that are 8 apart
+    int fh, qb;
+    {
+        const int bid = blockIdx.x;
+        if ((nfh & 7) == 0) {
+            const int x = bid & 7, j = bid >> 3, fl = j / nqb;
+            qb = j - fl * nqb;
+            fh = fl * 8 + x;
+        } else {
+            fh = bid / nqb;
+            qb = bid - fh * nqb;
+        }
+    }
+    const int nb = fh / heads, head = fh - nb * heads;
+    const f16* Kg = K + (size_t)fh * S * 64;
+    const f16* Vg = Vt + (size_t)fh * 64 * S;
+    const f16* Qg = Q + (size_t)fh * S * 64;
+    const int qt0 = (qb * 4 + w) * NQT;            // first 16-query tile of this wave
+
+    // LDS-DMA of key block kb into ring slot `slot`: 8 K pieces + 8 Vt pieces of 1 KiB (8 rows of 128 B each); wave w owns pieces 2 w, 2 w + 1 of both.
+    // Rows / columns beyond S are clamped to valid memory (finite values): their scores are masked and their probabilities are exactly 0.
+    // The fills are inline asm in the scalar-base form (wave-uniform base + 32-bit lane offset): behind the builtin, hipcc's wait-count pass assumes
+    // every later ds_read may alias a fill in flight and drains vmcnt(0) in front of the first fragment read of EVERY key block (the ring's prefetch gone).
+    const int prow = lane >> 3, pcp = lane & 7;
+    const unsigned smem_base = (unsigned)(size_t)(lptr_t)smem;
+    unsigned kvo[2], vvo[2];          // per-lane source offsets (bytes) of this wave's two K / two Vt pieces inside key block 0
+    int vcol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (2 * w + i) + prow;     // key row / feature row of the piece's lane
+        kvo[i] = (unsigned)(r * 128 + ((pcp ^ kswz(r)) << 4));
+        vcol[i] = (pcp ^ ((r >> 1) & 7)) << 3;
+        vvo[i] = (unsigned)(r * S * 2);
+    }
+    const int klast = (S - 1) * 128;              // byte offset of the last valid K row
+    auto issue = [&](int kb, int slot) {
+        const unsigned base = smem_base + slot * SLOT + 2 * w * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned off = kvo[i] + (unsigned)(kb * 8192);
+            if ((S & 63) != 0) {                  // ragged last block only (wave-uniform): clamp the ROW, keep the chunk
+                const int rowoff = (int)(off & ~127u);
+                off = (unsigned)(rowoff < klast ? rowoff : klast) + (off & 127u);
+            }
+            glds16_s_attn(Kg, off, base + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int col = kb * 64 + vcol[i];
+            if ((S & 63) != 0) col = col < S ? col : S - 8;   // S % 8 == 0
+            glds16_s_attn(Vg, vvo[i] + (unsigned)(col * 2), base + 8192 + i * 1024);
+        }
+    };
+
+    const int nkb = (S + 63) >> 6;
+    issue(0, 0);
+    if (nkb > 1) issue(1, 1);
+
+    f16x8 qf[NQT][2];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        int qr = (qt0 + qt) * 16 + li;
+        qr = qr < S ? qr : S - 1;
+        qf[qt][0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
+        qf[qt][1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
+    }
+    // The compiler's own wait for the Q loads must sit HERE, ahead of the loop (the empty asm "uses" the registers): left to the first MFMA it lands INSIDE
+    // the loop, and since the wait-count pass cannot see the inline-asm fills it is a vmcnt(0) that drains the ring's prefetch in every key block
+    // (vmcnt retires in order: the first two key blocks, issued before Q, have landed here too)
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) asm volatile("" : "+v"(qf[qt][0]), "+v"(qf[qt][1]));
+
+    // per-lane LDS offsets of the fragment reads inside a slot.  Key tile kt holds the keys 32 (kt >> 1) + 8 (i >> 2) + 4 (kt & 1) + (i & 3) on its rows i
+    // (a lane simply reads that K row): the score registers of tiles 2 s and 2 s + 1 are then the P^T operand of the keys 32 s + 8 g .. + 7 in natural
+    // order, and the Vt fragment of a lane is ONE 16-byte read (chunk 4 s + g of feature row d) instead of two 8-byte reads 32 bytes apart
+    int koff[2][2];   // [kt & 1][k-step]  (+ (kt >> 1) * 4096)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 8 * (li >> 2) + 4 * e + (li & 3);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) koff[e][ks] = r * 128 + (((4 * ks + g) ^ kswz(r)) << 4);
+    }
+    int voff[2];      // [s2]  (+ dt * 2048)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) voff[s2] = 8192 + li * 128 + (((4 * s2 + g) ^ ((li >> 1) & 7)) << 4);
+
+    f32x4 o[NQT][4];
+    float mref[NQT], lsum[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        mref[qt] = -INFINITY;
+        lsum[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    int slot = 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        // this wave's pieces of block kb have landed (block kb + 1 may still be in flight); the barrier then (a) makes every wave's pieces visible and
+        // (b) proves every wave has finished reading block kb - 1, whose slot block kb + 2 overwrites
+        if (kb + 1 < nkb) __builtin_amdgcn_s_waitcnt(attn_waitcnt_imm(4, 15));
+        else __builtin_amdgcn_s_waitcnt(attn_waitcnt_imm(0, 15));
+        asm volatile("s_barrier" ::: "memory");
+        if (kb + 2 < nkb) issue(kb + 2, slot >= 1 ? slot - 1 : NSLOT - 1);
+        const char* sb = smem + slot * SLOT;
+        slot = slot + 1 < NSLOT ? slot + 1 : 0;
+
+        // ---- S^T = K Q^T: 4 key tiles x NQT query tiles, every K fragment feeds NQT MFMAs ----
+        f32x4 sc[NQT][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f16x8 k0 = *(const f16x8*)(sb + (kt >> 1) * 4096 + koff[kt & 1][0]);
+            const f16x8 k1 = *(const f16x8*)(sb + (kt >> 1) * 4096 + koff[kt & 1][1]);
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qt][1], sc[qt][kt], 0, 0, 0);
+            }
+        }
+        if (kb * 64 + 64 > S) {   // padded keys exist only in the last block (wave-uniform)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kb * 64 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= S) {
+#pragma unroll
+                        for (int qt = 0; qt < NQT; ++qt) sc[qt][kt][r] = -INFINITY;
+                    }
+        }
+        // ---- block maxima; the reference maximum moves only when one of them exceeds it by more than the threshold ----
+        float bm[NQT];
+        bool need = false;
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                m = __builtin_fmaxf(__builtin_fmaxf(sc[qt][kt][0], sc[qt][kt][1]), m);   // v_max3_f32
+                m = __builtin_fmaxf(__builtin_fmaxf(sc[qt][kt][2], sc[qt][kt][3]), m);
+            }
+            bm[qt] = max_over_g(m);
+            need = need || (bm[qt] > mref[qt] + kLazyThr);
+        }
+        if (__any(need)) {   // first block always; later only on a jump of the maximum (rare): every accumulator at the old maximum is rescaled exactly once
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) {
+                const float mnew = __builtin_fmaxf(mref[qt], bm[qt]);
+                const float alpha = __builtin_amdgcn_exp2f((mref[qt] - mnew) * kScaleLog2e);   // exp2(-inf) = 0 in the first block (o = l = 0 there)
+                mref[qt] = mnew;
+                lsum[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+            }
+        }
+        // ---- P = exp2((s - mref) / 8 log2 e): one fma + one v_exp_f32 per score; row sums in fp32 ----
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) {
+            const float nmc = -mref[qt] * kScaleLog2e;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qt][kt][r], kScaleLog2e, nmc));
+                    sc[qt][kt][r] = pv;
+                    ps += pv;
+                }
+            lsum[qt] += ps;
+        }
+        // ---- O^T += Vt P^T: two 32-key steps x 4 feature tiles, every Vt fragment feeds NQT MFMAs ----
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 pf[NQT];
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[qt][r] = (f16)sc[qt][2 * s2][r];
+                    pf[qt][4 + r] = (f16)sc[qt][2 * s2 + 1][r];
+                }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f16x8 vf = *(const f16x8*)(sb + dt * 2048 + voff[s2]);
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], o[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+
+    const int Dm = heads * 64;
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) {
+        const float inv = 1.0f / sum_over_g(lsum[qt]);
+        const int qrow = (qt0 + qt) * 16 + li;
+        if (qrow < S) {
+            const int mrow = nb * S + qrow;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (f16)(o[qt][dt][r] * inv);
+                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1);
+            }
+        }
+    }
+}
+
 // One thread per 8 consecutive features (16-byte loads / stores; 8 lanes per head), D/8 threads per (b, p) column and as many
 // columns per block as fit in 256 threads; grid = (column groups, query-frame group): with `split` every query frame of a column
 // gets its own block, which loads only the K / V frames its causal mask admits — five times as many independent blocks for the
@@ -469,6 +730,28 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
         else if (nk == 8) GTAV_ATTN_1P(8);
         else GTAV_ATTN_1P(10);
 #undef GTAV_ATTN_1P
+        GTAV_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    static const int use_flash = GTAV_ENV_INT("GTAV_ATTN_FLASH", 1);   // experiments build: 0 = the round-1 kernel (all of K / Vt in LDS), for A/B runs
+    if (use_flash) {   // long sequences (the VAE's 576 tokens): flash form, K / Vt streamed through a 3-slot LDS ring, 4 waves x NQT query tiles per block
+        // NQT by the fewest padded query tiles; on a tie the larger tile once the grid fills the chip, else the smaller (more blocks)
+        int best = 0, best_pad = 1 << 30, best_nqb = 0;
+        for (int c = 2; c <= 4; ++c) {
+            const int nqb_c = cdiv(nqt, 4 * c), pad = nqb_c * c;
+            const bool better = pad < best_pad || (pad == best_pad && NB * heads * best_nqb >= 512);
+            if (better) best = c, best_pad = pad, best_nqb = nqb_c;
+        }
+        static const int force_nqt = GTAV_ENV_INT("GTAV_ATTN_FLASH_NQT", 0), occ3 = GTAV_ENV_INT("GTAV_ATTN_FLASH_OCC3", 1);   // experiments build: A/B runs
+        if (force_nqt >= 2 && force_nqt <= 4) best = force_nqt, best_nqb = cdiv(nqt, 4 * force_nqt);
+        const int nfh = NB * heads;
+        const dim3 fgrid(nfh * best_nqb);
+#define GTAV_ATTN_FLASH(NQT_, OCC_) GTAV_LAUNCH((attn_flash_kernel<NQT_, OCC_>), fgrid, dim3(256), 0, stream, Q, K, Vt, O, heads, S, nfh, best_nqb, g_attn_sc1)
+        if (best == 2) GTAV_ATTN_FLASH(2, 3);
+        else if (best == 3 && occ3) GTAV_ATTN_FLASH(3, 3);
+        else if (best == 3) GTAV_ATTN_FLASH(3, 2);
+        else GTAV_ATTN_FLASH(4, 2);
+#undef GTAV_ATTN_FLASH
         GTAV_CHECK_HIP(hipGetLastError());
         return 0;
     }

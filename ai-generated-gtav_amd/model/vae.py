@@ -89,7 +89,7 @@ class AutoencoderKL(_HipModule):
         self._dirty = True
 
     def _ensure(self, n: int):
-        want = min(max(n, 1), 64)
+        want = min(max(n, 1), 128)
         if want > self._capacity:
             self._capacity = want
             self._free()

@@ -163,7 +163,7 @@ def test_layernorm_kernels(D, M):
     assert rel_l2(untile(out, M, D).float(), torch.nn.functional.layer_norm(x, (D,), g, b, eps=1e-6)) < 5e-4
 
 
-@pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72)])
+@pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72), (1, 2, 200), (3, 8, 256), (1, 3, 328), (5, 16, 576)])
 def test_attention_spatial(NB, heads, S):
     q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
     q = q * 1.5
@@ -189,6 +189,35 @@ def test_attention_spatial_online_softmax_spike():
     got = untile(o, S, 64).float()
     assert rel_l2(got, ref) < 1.5e-3
     assert rel_l2(got[7], ref[7]) < 2e-3
+
+
+@pytest.mark.parametrize("S,jump", [(576, 4.0), (576, 0.45), (200, 4.0)])
+def test_attention_flash_running_max_jump(S, jump):
+    """Long sequences run the flash kernel (csrc/attention.hip attn_flash_kernel), whose reference maximum moves only when a key block's maximum
+    exceeds it by more than 8 in the exponent: a key in a LATE block that dominates one query by far more than that (jump = 4: the rescale
+    branch), and one that stays under the threshold (jump = 0.45: probabilities up to 2^8 against the stale maximum), against fp32 math on
+    every row; 50 repetitions must agree bit for bit (the ring is refilled by LDS-DMA while it is read)."""
+    NB, heads = 2, 3
+    q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
+    late = S - 9
+    k[1, 2, late] = q[1, 2, 7] * jump           # key `late` (last key block) against query 7
+    k[0, 1, 70] = q[0, 1, 150] * jump           # a jump in the second key block too
+    vt = v.transpose(-1, -2).contiguous()
+    rows = (NB * S + 127) // 128 * 128
+    qd, kd, vd = q.to(dev()), k.to(dev()), vt.to(dev())
+    outs = []
+    for _ in range(50):
+        o = torch.zeros(rows, heads * 64, device=dev(), dtype=torch.float16)
+        L.check(L.load().gtav_op_attn_spatial(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), o.data_ptr(), NB, heads, S, stream()))
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    ref = ref.permute(0, 2, 1, 3).reshape(NB * S, heads * 64)
+    got = untile(outs[0], NB * S, heads * 64).float()
+    assert rel_l2(got, ref) < 1.5e-3
+    for (b, h, row) in ((1, 2, 7), (0, 1, 150)):
+        assert rel_l2(got[b * S + row, h * 64:(h + 1) * 64], ref[b * S + row, h * 64:(h + 1) * 64]) < 2e-3
 
 
 @pytest.mark.parametrize("Tq,t0", [(5, 0), (1, 4), (2, 1), (1, 0)])
