@@ -125,6 +125,7 @@ struct RopeTable {
     float* cos_dev = nullptr;
     float* sin_dev = nullptr;
     float* cs_dev = nullptr;   // interleaved (cos, sin) table consumed by the QKV epilogue
+    float* csq_dev = nullptr;  // VAE only: cs_dev x 1/8 log2 e, the table the q features rotate by when the flash attention kernel follows (GemmParams::rope_cs_q)
     int npos = 0;
     bool set_cos = false, set_sin = false;
 };
@@ -1546,6 +1547,7 @@ struct gtav_vae {
     int* err_flag = nullptr;
     size_t parts_rows = 0;
     bool finalized = false;
+    Profiler prof;   // gtav_vae_profile: per-class dispatch-attached events (bench.py's config4 roofline)
 };
 
 static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim, int heads, const RopeTable& rope, int N,
@@ -1556,41 +1558,44 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
     GemmParams g;
     LnPending pend;
     bool have_pend = false;
-    auto resid_gemm = [&](const f16* X, int ldx, const f16* Wt, int K, const float* bias) -> int {
+    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias) -> int {
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = dim; q.K = K; q.out = h->parts; q.ldo = dim;
         if (gemm_resid_inplace_ok(M, dim, K, 0)) {   // large M: in-place residual epilogue of the persistent loader-wave kernel (see dit_forward_core): no slab round trip
             q.out = h->resid; q.bias = bias;
-            RET_IF(launch_gemm(q, EPI_RESID, s));
+            PROF(h, cls, s, launch_gemm(q, EPI_RESID, s));
             have_pend = false;
             return 0;
         }
         q.splitk = gemm_choose_splitk(M, dim, K);
         GTAV_REQUIRE((size_t)q.splitk * M * dim <= h->parts_rows * (size_t)h->Dmax, "split-K slabs exceed workspace");
-        RET_IF(launch_gemm(q, EPI_PARTIAL, s));
+        PROF(h, cls, s, launch_gemm(q, EPI_PARTIAL, s));
         memset(&pend, 0, sizeof(pend));
         pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * dim; pend.ld = dim; pend.bias = bias;
         have_pend = true;
         return 0;
     };
     for (auto& b : blocks) {
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, h->err_flag, s));
+        PROF(h, PC_LN, s, launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, h->err_flag, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_qkv; g.M = M; g.N = 3 * dim; g.K = dim; g.bias = b.b_qkv; g.D = dim; g.S = h->S;
         g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cs = rope.cs_dev; g.err_flag = h->err_flag;
-        RET_IF(launch_gemm(g, EPI_QKV, s));
-        RET_IF(launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s));
-        RET_IF(resid_gemm(h->ao, dim, b.w_proj, dim, b.b_proj));
-        RET_IF(launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, h->err_flag, s));
+        const bool qps = attn_spatial_wants_prescaled_q(h->S);   // long sequences: q leaves the epilogue in the exponent's unit of the flash attention kernel
+        g.rope_cs_q = qps ? rope.csq_dev : nullptr;
+        PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
+        PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s, qps));
+        RET_IF(resid_gemm(PC_OUT, h->ao, dim, b.w_proj, dim, b.b_proj));
+        PROF(h, PC_LN, s, launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, h->err_flag, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad; g.err_flag = h->err_flag;
-        RET_IF(launch_gemm(g, EPI_GELU_ERF, s));
-        RET_IF(resid_gemm(h->hbuf, Hm_pad, b.w_fc2, Hm_pad, b.b_fc2));
+        PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_ERF, s));
+        RET_IF(resid_gemm(PC_FC2, h->hbuf, Hm_pad, b.w_fc2, Hm_pad, b.b_fc2));
     }
-    return launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, h->err_flag, s);
+    PROF(h, PC_LN, s, launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, h->err_flag, s));
+    return 0;
 }
 
 extern "C" {
@@ -1660,6 +1665,7 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->rope_d.cos_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_cos", h->S, 64, h->rope_d.cos_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_d.sin_dev, (size_t)h->S * 64)); wt.add_f32("tables.rope_dec_sin", h->S, 64, h->rope_d.sin_dev, 64, 0, false);
     A_(a.alloc_t(&h->rope_e.cs_dev, (size_t)h->S * 64)); A_(a.alloc_t(&h->rope_d.cs_dev, (size_t)h->S * 64));
+    A_(a.alloc_t(&h->rope_e.csq_dev, (size_t)h->S * 64)); A_(a.alloc_t(&h->rope_d.csq_dev, (size_t)h->S * 64));
     const size_t Mx = round_up(h->Mmax, 128), Dm = h->Dmax;
     A_(a.alloc_t(&h->xp, Mx * h->Kp)); A_(a.alloc_t(&h->xn, Mx * Dm)); A_(a.alloc_t(&h->q, Mx * Dm)); A_(a.alloc_t(&h->k, Mx * Dm));
     A_(a.alloc_t(&h->vt, Mx * Dm)); A_(a.alloc_t(&h->ao, Mx * Dm)); A_(a.alloc_t(&h->hbuf, Mx * h->Hmax)); A_(a.alloc_t(&h->zin, Mx * 64));
@@ -1705,6 +1711,10 @@ int gtav_vae_finalize(gtav_vae* h, void* stream) {
     RET_IF(build(h->rope_d, "tables.rope_dec_cos", "tables.rope_dec_sin"));
     RET_IF(launch_rope_interleave(h->rope_e.cos_dev, h->rope_e.sin_dev, h->rope_e.cs_dev, h->S, (hipStream_t)stream));
     RET_IF(launch_rope_interleave(h->rope_d.cos_dev, h->rope_d.sin_dev, h->rope_d.cs_dev, h->S, (hipStream_t)stream));
+    for (RopeTable* r : {&h->rope_e, &h->rope_d}) {   // csq = 0 + (1/8 log2 e) cs
+        GTAV_CHECK_HIP(hipMemsetAsync(r->csq_dev, 0, (size_t)h->S * 64 * sizeof(float), (hipStream_t)stream));
+        RET_IF(launch_axpy_f32(r->csq_dev, r->cs_dev, kAttnQScale, (size_t)h->S * 64, (hipStream_t)stream));
+    }
     GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     h->finalized = true;
     return 0;
@@ -1716,17 +1726,21 @@ int gtav_vae_encode(gtav_vae* h, const float* img, float in_scale, float in_shif
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_encode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int De = h->cfg.enc_dim, M = N * h->S;
-    RET_IF(launch_patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, h->err_flag, s));
+    PROF(h, PC_OTHER, s, launch_patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, h->err_flag, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kp; g.W = h->w_patch; g.M = M; g.N = De; g.K = h->Kp; g.bias = h->b_patch; g.out = h->resid; g.ldo = De;
-    RET_IF(launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
     RET_IF(vae_blocks(h, h->enc, De, h->cfg.enc_heads, h->rope_e, N, h->g_enc, h->be_enc, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = De; g.W = h->w_quant; g.M = M; g.N = h->Mom; g.K = De; g.bias = h->b_quant; g.out = moments; g.ldo = h->Mom;
-    RET_IF(launch_gemm(g, EPI_F32, s));
-    if (h->cfg.use_variational) RET_IF(launch_clamp_cols(moments, M, h->Mom, h->Lat, h->Mom, -30.f, 20.f, s));
-    return 0;
+    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    if (h->cfg.use_variational) PROF(h, PC_OTHER, s, launch_clamp_cols(moments, M, h->Mom, h->Lat, h->Mom, -30.f, 20.f, s));
+    if (h->prof.on) {
+        RET_IF(h->prof.begin(PC_EMPTY, s));
+        RET_IF(h->prof.end(s));
+    }
+    return h->prof.collect(s);
 }
 
 int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, float out_scale, float out_shift, int32_t N,
@@ -1736,16 +1750,33 @@ int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, floa
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_decode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int Dd = h->cfg.dec_dim, M = N * h->S;
-    RET_IF(launch_convert_pad_f16(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s));
+    PROF(h, PC_OTHER, s, launch_convert_pad_f16(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->zin; g.ldx = 64; g.W = h->w_post; g.M = M; g.N = Dd; g.K = 64; g.bias = h->b_post; g.out = h->resid; g.ldo = Dd;
-    RET_IF(launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
     RET_IF(vae_blocks(h, h->dec, Dd, h->cfg.dec_heads, h->rope_d, N, h->g_dec, h->be_dec, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = Dd; g.W = h->w_pred; g.M = M; g.N = h->Npred; g.K = Dd; g.bias = h->b_pred; g.out = h->po; g.ldo = h->Npred;
-    RET_IF(launch_gemm(g, EPI_F32, s));
-    RET_IF(launch_unpatchify(h->po, h->Npred, img, N, 3, h->H, h->W, h->p, 1, out_scale, out_shift, s));
+    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, launch_unpatchify(h->po, h->Npred, img, N, 3, h->H, h->W, h->p, 1, out_scale, out_shift, s));
+    if (h->prof.on) {
+        RET_IF(h->prof.begin(PC_EMPTY, s));
+        RET_IF(h->prof.end(s));
+    }
+    return h->prof.collect(s);
+}
+
+int gtav_vae_profile(gtav_vae* h, int32_t enable) {
+    GTAV_REQUIRE(h, "vae_profile: null handle");
+    h->prof.on = enable != 0;
+    h->prof.used = 0;
+    for (int i = 0; i < PC_COUNT; ++i) { h->prof.ms[i] = 0; h->prof.n[i] = 0; }
+    return 0;
+}
+int gtav_vae_profile_read(gtav_vae* h, double* ms_by_class, int64_t* launches_by_class) {
+    GTAV_REQUIRE(h && ms_by_class && launches_by_class, "vae_profile_read: null argument");
+    for (int i = 0; i < PC_COUNT; ++i) { ms_by_class[i] = h->prof.ms[i]; launches_by_class[i] = h->prof.n[i]; }
     return 0;
 }
 

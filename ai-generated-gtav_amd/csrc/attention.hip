@@ -20,7 +20,7 @@ namespace gtav {
 
 namespace {
 
-constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+constexpr float kScaleLog2e = kAttnQScale;  // 1/sqrt(64) * log2(e)
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
@@ -363,10 +363,14 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __r
 //     per key block, block kb + 2 in flight while block kb is consumed; the bank swizzles are applied to the per-lane SOURCE address (the LDS image
 //     of an LDS-DMA is lane-linear): K rows chunk ^ kswz(key), Vt rows chunk ^ ((d >> 1) & 7): every fragment is one conflict-free ds_read_b128
 //   * every K / Vt fragment feeds NQT MFMAs; S^T = K Q^T and O^T += Vt P^T with the operand maps of the kernels above (P^T straight from the score registers)
-//   * the running maximum moves only when a block's maximum exceeds it by more than 8 in the exponent (P <= 2^8: exact in fp16 to the same 11 bits, the
-//     sums are fp32): the rescale of O is a rare wave-uniform branch instead of 16 NQT multiplies per key block; exponent as ONE fma + v_exp_f32 per score;
-//     the cross-lane maxima are v_permlane16_swap / v_permlane32_swap (no LDS crossbar)
-constexpr float kLazyThr = 8.0f / kScaleLog2e;   // in raw-score units
+//   * scores live in the exponent's own unit: Q carries 1/8 log2 e (applied in fp32 by the to_qkv epilogue — GemmParams::rope_cs_q — or, for callers with
+//     plain q, by this kernel on the fp16 fragments), and the reference maximum is the C INPUT of the score MFMAs (S' = K Q^T - mref comes out of the
+//     matrix pipe), so a probability is ONE v_exp_f32; the reference maximum moves only when a score exceeds it by more than 8 (P <= 2^8: exact in fp16
+//     to the same 11 bits; the sums are fp32): detection is lane-local (8 v_max3 + 1 compare per query tile), the cross-lane maximum (v_permlane16_swap /
+//     v_permlane32_swap) and the rescale of O are a rare wave-uniform branch; the row sums are a fifth output tile of the PV product (a ones A operand:
+//     6 more MFMAs per key block instead of 48 additions per lane, and no cross-lane sum at the end)
+//   profiles/round5/attn_flash_*: 373 -> 159 us (first version) -> see there, per 80-frame x 16-head launch
+constexpr float kLazyThr = 8.0f;   // in exponent units (log2)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -390,18 +394,10 @@ __device__ __forceinline__ float max_over_g(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);   // lanes 32-63 <-> 0-31
     return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
 }
-__device__ __forceinline__ float sum_over_g(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
-    const unsigned w = __builtin_bit_cast(unsigned, v);
-    auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
-}
-
-template <int NQT, int OCC>   // OCC = blocks per CU the register budget must admit (launch bound)
+template <int NQT, int OCC, bool RAGGED, bool PRESCALED>   // OCC = blocks per CU the register budget must admit; RAGGED: S % 64 != 0; PRESCALED: Q holds q / 8 log2 e
 __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restrict__ Q, const f16* __restrict__ K, const f16* __restrict__ Vt,
                                                             f16* __restrict__ O, int heads, int S, int nfh, int nqb, int sc1) {
+    const bool dbg_force = (sc1 & 2) != 0;
     constexpr int SLOT = 16384, NSLOT = 3;          // per slot: K block [64 keys][128 B] | Vt block [64 d][128 B]
     __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the LDS-DMA base goes to M0 (no waterfall loop)
@@ -432,31 +428,31 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
     const int prow = lane >> 3, pcp = lane & 7;
     const unsigned smem_base = (unsigned)(size_t)(lptr_t)smem;
     unsigned kvo[2], vvo[2];          // per-lane source offsets (bytes) of this wave's two K / two Vt pieces inside key block 0
-    int vcol[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = 8 * (2 * w + i) + prow;     // key row / feature row of the piece's lane
         kvo[i] = (unsigned)(r * 128 + ((pcp ^ kswz(r)) << 4));
-        vcol[i] = (pcp ^ ((r >> 1) & 7)) << 3;
-        vvo[i] = (unsigned)(r * S * 2);
+        vvo[i] = (unsigned)(r * S * 2 + ((pcp ^ ((r >> 1) & 7)) << 4));
     }
-    const int klast = (S - 1) * 128;              // byte offset of the last valid K row
     auto issue = [&](int kb, int slot) {
         const unsigned base = smem_base + slot * SLOT + 2 * w * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             unsigned off = kvo[i] + (unsigned)(kb * 8192);
-            if ((S & 63) != 0) {                  // ragged last block only (wave-uniform): clamp the ROW, keep the chunk
-                const int rowoff = (int)(off & ~127u);
+            if constexpr (RAGGED) {               // clamp the ROW to the last valid key, keep the chunk
+                const int rowoff = (int)(off & ~127u), klast = (S - 1) * 128;
                 off = (unsigned)(rowoff < klast ? rowoff : klast) + (off & 127u);
             }
             glds16_s_attn(Kg, off, base + i * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            int col = kb * 64 + vcol[i];
-            if ((S & 63) != 0) col = col < S ? col : S - 8;   // S % 8 == 0
-            glds16_s_attn(Vg, vvo[i] + (unsigned)(col * 2), base + 8192 + i * 1024);
+            unsigned off = vvo[i] + (unsigned)(kb * 128);
+            if constexpr (RAGGED) {               // clamp the 8-key chunk to the last valid one (S % 8 == 0)
+                const int r = 8 * (2 * w + i) + prow, col = kb * 64 + ((pcp ^ ((r >> 1) & 7)) << 3);
+                off = (unsigned)(r * S * 2) + (unsigned)((col < S ? col : S - 8) * 2);
+            }
+            glds16_s_attn(Vg, off, base + 8192 + i * 1024);
         }
     };
 
@@ -477,6 +473,14 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
     // (vmcnt retires in order: the first two key blocks, issued before Q, have landed here too)
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) asm volatile("" : "+v"(qf[qt][0]), "+v"(qf[qt][1]));
+    if constexpr (!PRESCALED) {   // plain q: the exponent's unit goes onto the fp16 fragments here (one more fp16 rounding of q than the prescaled form)
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[qt][h][e] = (f16)((float)qf[qt][h][e] * kScaleLog2e);
+    }
 
     // per-lane LDS offsets of the fragment reads inside a slot.  Key tile kt holds the keys 32 (kt >> 1) + 8 (i >> 2) + 4 (kt & 1) + (i & 3) on its rows i
     // (a lane simply reads that K row): the score registers of tiles 2 s and 2 s + 1 are then the P^T operand of the keys 32 s + 8 g .. + 7 in natural
@@ -492,15 +496,17 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) voff[s2] = 8192 + li * 128 + (((4 * s2 + g) ^ ((li >> 1) & 7)) << 4);
 
-    f32x4 o[NQT][4];
-    float mref[NQT], lsum[NQT];
+    f32x4 o[NQT][5];      // [4] = the row sums: O^T tile of an all-ones feature tile (every row of it holds sum_k P[k][q])
+    float nmref[NQT];     // minus the reference maximum of the lane's query: splat, it is the C operand of the score MFMAs
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
-        mref[qt] = -INFINITY;
-        lsum[qt] = 0.f;
+        nmref[qt] = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    f16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (f16)1.0f;
 
     int slot = 0;
     for (int kb = 0; kb < nkb; ++kb) {
@@ -513,69 +519,73 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
         const char* sb = smem + slot * SLOT;
         slot = slot + 1 < NSLOT ? slot + 1 : 0;
 
-        // ---- S^T = K Q^T: 4 key tiles x NQT query tiles, every K fragment feeds NQT MFMAs ----
-        f32x4 sc[NQT][4];
+        // ---- S' = K Q^T - mref: 4 key tiles x NQT query tiles, every K fragment feeds NQT MFMAs ----
+        f32x4 sc[NQT][4], cin[NQT];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) cin[qt] = f32x4{nmref[qt], nmref[qt], nmref[qt], nmref[qt]};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const f16x8 k0 = *(const f16x8*)(sb + (kt >> 1) * 4096 + koff[kt & 1][0]);
             const f16x8 k1 = *(const f16x8*)(sb + (kt >> 1) * 4096 + koff[kt & 1][1]);
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
-                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[qt][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[qt][0], cin[qt], 0, 0, 0);
                 sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qt][1], sc[qt][kt], 0, 0, 0);
             }
         }
-        if (kb * 64 + 64 > S) {   // padded keys exist only in the last block (wave-uniform)
+        if constexpr (RAGGED) {
+            if (kb * 64 + 64 > S) {   // padded keys exist only in the last block (wave-uniform)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kb * 64 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= S) {
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * 64 + 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + r >= S) {
 #pragma unroll
-                        for (int qt = 0; qt < NQT; ++qt) sc[qt][kt][r] = -INFINITY;
-                    }
+                            for (int qt = 0; qt < NQT; ++qt) sc[qt][kt][r] = -INFINITY;
+                        }
+            }
         }
-        // ---- block maxima; the reference maximum moves only when one of them exceeds it by more than the threshold ----
-        float bm[NQT];
-        bool need = false;
+        // ---- does any score exceed its reference maximum by more than the threshold?  Lane-local: every key sits in some lane ----
+        // Signed-INTEGER maxima of the score bits: a positive float is its bit pattern in integer order and every negative one is a negative integer, which is
+        // all that "some score > 8" needs (v_max3_i32; behind fmaxf hipcc canonicalises every MFMA result with a v_max_f32 x, x, x of its own, and inline
+        // asm must not read MFMA results: the compiler pads that hazard only for instructions it emits itself)
+        bool need = kb == 0 || dbg_force;   // the first block SETS the reference maximum (with cin = 0 a row of very negative scores would underflow to a zero sum)
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
-            float m = -INFINITY;
+            int im = (int)0x80000000;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                m = __builtin_fmaxf(__builtin_fmaxf(sc[qt][kt][0], sc[qt][kt][1]), m);   // v_max3_f32
-                m = __builtin_fmaxf(__builtin_fmaxf(sc[qt][kt][2], sc[qt][kt][3]), m);
+                // (every element through a scalar float first: __builtin_bit_cast applied to the vector subscript itself read element 0 four times — hipcc, ROCm 7.2)
+                const float s0 = sc[qt][kt][0], s1 = sc[qt][kt][1], s2_ = sc[qt][kt][2], s3 = sc[qt][kt][3];
+                im = max(max(__float_as_int(s0), __float_as_int(s1)), im);
+                im = max(max(__float_as_int(s2_), __float_as_int(s3)), im);
             }
-            bm[qt] = max_over_g(m);
-            need = need || (bm[qt] > mref[qt] + kLazyThr);
+            need = need || (im > __float_as_int(kLazyThr));
         }
-        if (__any(need)) {   // first block always; later only on a jump of the maximum (rare): every accumulator at the old maximum is rescaled exactly once
+        if (__any(need)) {   // rare after the first block: a jump of the maximum.  Everything at the old reference is rescaled exactly once, the pending scores re-based
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
-                const float mnew = __builtin_fmaxf(mref[qt], bm[qt]);
-                const float alpha = __builtin_amdgcn_exp2f((mref[qt] - mnew) * kScaleLog2e);   // exp2(-inf) = 0 in the first block (o = l = 0 there)
-                mref[qt] = mnew;
-                lsum[qt] *= alpha;
+                float m = -INFINITY;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+                for (int kt = 0; kt < 4; ++kt) {
+                    m = __builtin_fmaxf(__builtin_fmaxf(sc[qt][kt][0], sc[qt][kt][1]), m);
+                    m = __builtin_fmaxf(__builtin_fmaxf(sc[qt][kt][2], sc[qt][kt][3]), m);
+                }
+                const float bm = max_over_g(m);
+                const float delta = kb == 0 ? bm : __builtin_fmaxf(bm, 0.f);   // the reference only ever rises after the first block
+                if (kb != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int dt = 0; dt < 5; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+                }
+                nmref[qt] -= delta;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[qt][kt][r] -= delta;
             }
         }
-        // ---- P = exp2((s - mref) / 8 log2 e): one fma + one v_exp_f32 per score; row sums in fp32 ----
-#pragma unroll
-        for (int qt = 0; qt < NQT; ++qt) {
-            const float nmc = -mref[qt] * kScaleLog2e;
-            float ps = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[qt][kt][r], kScaleLog2e, nmc));
-                    sc[qt][kt][r] = pv;
-                    ps += pv;
-                }
-            lsum[qt] += ps;
-        }
-        // ---- O^T += Vt P^T: two 32-key steps x 4 feature tiles, every Vt fragment feeds NQT MFMAs ----
+        // ---- P = 2^S' (one v_exp_f32 per score), then O^T += Vt P^T: two 32-key steps x (4 feature tiles + the ones tile); every Vt fragment feeds NQT MFMAs ----
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             f16x8 pf[NQT];
@@ -583,8 +593,8 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
             for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pf[qt][r] = (f16)sc[qt][2 * s2][r];
-                    pf[qt][4 + r] = (f16)sc[qt][2 * s2 + 1][r];
+                    pf[qt][r] = (f16)__builtin_amdgcn_exp2f(sc[qt][2 * s2][r]);
+                    pf[qt][4 + r] = (f16)__builtin_amdgcn_exp2f(sc[qt][2 * s2 + 1][r]);
                 }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
@@ -592,13 +602,15 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
 #pragma unroll
                 for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], o[qt][dt], 0, 0, 0);
             }
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) o[qt][4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt], o[qt][4], 0, 0, 0);
         }
     }
 
     const int Dm = heads * 64;
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) {
-        const float inv = 1.0f / sum_over_g(lsum[qt]);
+        const float inv = 1.0f / o[qt][4][0];
         const int qrow = (qt0 + qt) * 16 + li;
         if (qrow < S) {
             const int mrow = nb * S + qrow;
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
                 f16x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = (f16)(o[qt][dt][r] * inv);
-                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1);
+                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1 & 1);
             }
         }
     }
@@ -689,9 +701,11 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 // second model on another GPU of the same process (model.to("cuda:1")) gets its opt-in too
 static unsigned long long g_attn_attr_devs = 0;
 // output as paired 16-byte write-through stores (common.h store_f16x4_paired); experiments build: GTAV_ATTN_SC1=1 enables it
-static int g_attn_sc1 = GTAV_ENV_INT("GTAV_ATTN_SC1", 0);   // measured neutral at B = 1 (attention re-reads nothing, writes little)
+static int g_attn_sc1 = GTAV_ENV_INT("GTAV_ATTN_SC1", 0) | (GTAV_ENV_INT("GTAV_ATTN_DBG_FORCE", 0) ? 2 : 0);   // measured neutral at B = 1 (attention re-reads nothing, writes little)
 
-int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream) {
+bool attn_spatial_wants_prescaled_q(int S) { return S > 0 && S % 8 == 0 && round_up(S, 32) > 160 && GTAV_ENV_INT("GTAV_ATTN_FLASH", 1) != 0; }
+
+int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream, bool q_prescaled) {
     GTAV_REQUIRE(S > 0 && S % 8 == 0, "attn_spatial: S=%d must be a positive multiple of 8", S);
     const int S_pad = round_up(S, 32);
     const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
@@ -733,6 +747,7 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
         GTAV_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    GTAV_REQUIRE(!q_prescaled || attn_spatial_wants_prescaled_q(S), "attn_spatial: S=%d runs a kernel that takes plain q", S);
     static const int use_flash = GTAV_ENV_INT("GTAV_ATTN_FLASH", 1);   // experiments build: 0 = the round-1 kernel (all of K / Vt in LDS), for A/B runs
     if (use_flash) {   // long sequences (the VAE's 576 tokens): flash form, K / Vt streamed through a 3-slot LDS ring, 4 waves x NQT query tiles per block
         // NQT by the fewest padded query tiles; on a tie the larger tile once the grid fills the chip, else the smaller (more blocks)
@@ -746,12 +761,18 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
         if (force_nqt >= 2 && force_nqt <= 4) best = force_nqt, best_nqb = cdiv(nqt, 4 * force_nqt);
         const int nfh = NB * heads;
         const dim3 fgrid(nfh * best_nqb);
-#define GTAV_ATTN_FLASH(NQT_, OCC_) GTAV_LAUNCH((attn_flash_kernel<NQT_, OCC_>), fgrid, dim3(256), 0, stream, Q, K, Vt, O, heads, S, nfh, best_nqb, g_attn_sc1)
+#define GTAV_ATTN_FLASH_(NQT_, OCC_, RG_, PS_) GTAV_LAUNCH((attn_flash_kernel<NQT_, OCC_, RG_, PS_>), fgrid, dim3(256), 0, stream, Q, K, Vt, O, heads, S, nfh, best_nqb, g_attn_sc1)
+#define GTAV_ATTN_FLASH(NQT_, OCC_)                                                                    \
+        do {                                                                                           \
+            if (S % 64 != 0) { if (q_prescaled) GTAV_ATTN_FLASH_(NQT_, OCC_, true, true); else GTAV_ATTN_FLASH_(NQT_, OCC_, true, false); }   \
+            else { if (q_prescaled) GTAV_ATTN_FLASH_(NQT_, OCC_, false, true); else GTAV_ATTN_FLASH_(NQT_, OCC_, false, false); }             \
+        } while (0)
         if (best == 2) GTAV_ATTN_FLASH(2, 3);
         else if (best == 3 && occ3) GTAV_ATTN_FLASH(3, 3);
         else if (best == 3) GTAV_ATTN_FLASH(3, 2);
         else GTAV_ATTN_FLASH(4, 2);
 #undef GTAV_ATTN_FLASH
+#undef GTAV_ATTN_FLASH_
         GTAV_CHECK_HIP(hipGetLastError());
         return 0;
     }

@@ -177,8 +177,35 @@ __device__ __forceinline__ void gelu_tanh_f4(const float (&x)[4], float (&y)[4])
     }
 }
 
-// exact (erf) GELU: 0.5 x (1 + erf(x / sqrt(2)))
+// exact (erf) GELU: 0.5 x (1 + erf(x / sqrt(2)))  (model/vae.py:128, torch.nn.GELU()) through libm's erff: ~36 VALU instructions per value
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+
+// The same function for the GEMM epilogues (round 5): erf(x / sqrt 2) = z Q(z^2 - 1) with z = x sqrt 2 / 4.5 clamped to [-sqrt 2, sqrt 2] (beyond |x| = 4.5 the
+// polynomial's end value, 1 to 3e-8, stands for erf) and Q a degree-9 minimax polynomial in a variable that spans [-1, 1] (coefficients of order 1: no
+// cancellation in fp32), fitted to the ABSOLUTE error of the GELU value: |error| <= 3.0e-5 for every fp32 x in [-65504, 65504] (tools/gelu_poly_fit.py prints
+// the table and re-measures it), an order of magnitude under the fp16 rounding of the stored activation (4.9e-4 relative) — no sigmoid shortcut, the
+// definition itself.  14 operations per value, all but the clamp as packed fp32 (v_pk_mul / v_pk_fma: two values per instruction): ~7.5 issue slots per value.
+constexpr float kGeluErfL = 4.5f;
+constexpr float kGeluErfC[10] = {9.985491633e-01f, -4.911968410e-01f, 3.479329944e-01f, -2.564433515e-01f, 1.821636558e-01f,
+                                 -1.155658439e-01f, 6.453407556e-02f, -4.252957553e-02f, 2.962661162e-02f, -9.964072146e-03f};
+__device__ __forceinline__ void gelu_erf_f4(const float (&x)[4], float (&y)[4]) {
+    constexpr float r2 = 1.4142135623730951f, zs = r2 / kGeluErfL;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2_ v = f32x2_{x[2 * h], x[2 * h + 1]};
+        const f32x2_ z = v * f32x2_{zs, zs};
+        const f32x2_ zc = f32x2_{__builtin_amdgcn_fmed3f(z[0], -r2, r2), __builtin_amdgcn_fmed3f(z[1], -r2, r2)};
+        const f32x2_ sm = __builtin_elementwise_fma(zc, zc, f32x2_{-1.0f, -1.0f});
+        f32x2_ q = f32x2_{kGeluErfC[9], kGeluErfC[9]};
+#pragma unroll
+        for (int k = 8; k >= 0; --k) q = __builtin_elementwise_fma(q, sm, f32x2_{kGeluErfC[k], kGeluErfC[k]});
+        const f32x2_ f = zc * q;
+        const f32x2_ hx = v * f32x2_{0.5f, 0.5f};
+        const f32x2_ o = __builtin_elementwise_fma(hx, f, hx);
+        y[2 * h] = o[0];
+        y[2 * h + 1] = o[1];
+    }
+}
 
 // Wave-wide sum with DPP moves instead of six ds_bpermute shuffles (each of those is an LDS round trip on the critical path):
 // quad xor 1, quad xor 2, half-row mirror, row mirror leave every 16-lane row's total in all its lanes; row_bcast15 /

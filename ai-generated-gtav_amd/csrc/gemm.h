@@ -65,6 +65,8 @@ struct GemmParams {
     int Tmax;   // temporal: frames in the kv cache per batch item
     const float* rope_cs;   // [npos][32][2]: (cos, sin) of rotation pair k at [pos][k] (interleaved-pair RoPE;
                             // cos/sin of features 2k and 2k+1 are equal, rotary_embedding_torch.py:337)
+    const float* rope_cs_q; // optional: the table the q features (n < D) rotate by instead — the VAE passes rope_cs scaled by 1/8 log2 e, so that q leaves
+                            // the epilogue in the exponent's unit of its flash attention (one fp32 multiply folded into the rotation, no extra rounding)
     // block -> tile map constants of the loader-wave kernels, filled by their launcher (host): the map's three integer divisions
     // by run-time values cost ~110 scalar instructions (two float-reciprocal sequences) = 0.3-0.4 us in front of the first fill;
     // with the divisors' 32-bit reciprocals (a / d == mulhi(a, ceil(2^32 / d)) for a * d < 2^32) they are three s_mul_hi_u32

@@ -93,6 +93,9 @@ __device__ __forceinline__ f32x4 rope4(const f32x4 v, const f32x4 cs) {
     return r;
 }
 
+// the (cos, sin) table feature n of a QKV output rotates by: q features may have a table of their own (GemmParams::rope_cs_q)
+__device__ __forceinline__ const float* rope_tab(const GemmParams& p, int n) { return (p.rope_cs_q && n < p.D) ? p.rope_cs_q : p.rope_cs; }
+
 template <int VM>
 __device__ __forceinline__ void wait_vm() {
     static_assert(VM >= 0 && VM < 64, "vmcnt is a 6-bit field");
@@ -813,7 +816,7 @@ __device__ __forceinline__ void prefetch_rope(const GemmParams& p, int n0, int m
         for (int i = 0; i < FI; ++i) {
             const int n = n0 + 16 * FI * wn + 16 * i + 4 * g;
             prope[i][j] = f32x4{1.f, 0.f, 1.f, 0.f};
-            if (w >= 0 && w < WN * WM && n < 2 * p.D) prope[i][j] = *(const f32x4*)(p.rope_cs + pos * 64 + (n & 63));
+            if (w >= 0 && w < WN * WM && n < 2 * p.D) prope[i][j] = *(const f32x4*)(rope_tab(p, n) + pos * 64 + (n & 63));
         }
     }
 }
@@ -907,7 +910,7 @@ __device__ __forceinline__ void qkv_staged(const GemmParams& p, f32x4 (&acc)[FI]
                     if (rope) {
                         f32x4 cs;
                         if constexpr (PRE) cs = prope[i][j];
-                        else cs = *(const f32x4*)(p.rope_cs + pos[j] * 64 + d);
+                        else cs = *(const f32x4*)(rope_tab(p, n) + pos[j] * 64 + d);
                         v = rope4(v, cs);
                     }
                     char* dst = smem + ml * PN + (((nl >> 3) ^ (ml & 7)) << 4) + ((nl >> 2) & 1) * 8;
@@ -1138,9 +1141,12 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
                                 *(uint2*)dst = pack4(amax, yo[0], yo[1], yo[2], yo[3]);
                             }
                         }
-                    else if constexpr (EPI == EPI_GELU_ERF)
-                        *(uint2*)dst = pack4(amax, gelu_erf_f(v[0]), gelu_erf_f(v[1]), gelu_erf_f(v[2]), gelu_erf_f(v[3]));
-                    else
+                    else if constexpr (EPI == EPI_GELU_ERF) {
+                        const float xin[4] = {v[0], v[1], v[2], v[3]};
+                        float yo[4];
+                        gelu_erf_f4(xin, yo);
+                        *(uint2*)dst = pack4(amax, yo[0], yo[1], yo[2], yo[3]);
+                    } else
                         *(uint2*)dst = pack4(amax, v[0], v[1], v[2], v[3]);
                 }
             }
@@ -1335,7 +1341,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FI][F
             } else if constexpr (EPI == EPI_QKV) {
                 if (which < 2) {
                     // interleaved table: (cos, sin) of pair d/2 and of pair d/2+1 in one 16-byte load
-                    const f32x4 cs = *(const f32x4*)(p.rope_cs + tok_pos[j] * 64 + d);
+                    const f32x4 cs = *(const f32x4*)(rope_tab(p, n) + tok_pos[j] * 64 + d);
                     v = rope4(v, cs);
                 }
                 const uint2 pk = pack4(amax, v[0], v[1], v[2], v[3]);
@@ -3409,6 +3415,13 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         else if (fold_p && t12 > 128) wm = 12, narrow_pick = true;
     }
     if (!g_force_wm && splitk == 1 && ((epi_x == EPI_PARTIAL && lp_takes(p.M, p.N, p.K)) || (epi_x == EPI_RESID && gemm_resid_inplace_ok(p.M, p.N, p.K, p.gate ? p.rows_per_gate : 0)))) wm = 31, narrow_pick = true;
+    // Tens of thousands of tokens (the VAE encode of a training batch: M = 46 080): the in-place residual GEMMs on whole rounds of 256 x 256 tiles
+    // (>= 2 rounds, >= 90 % full) beat the persistent 128 x 192 kernel — fc2 453 -> 399 us, attention projection 182 -> 164 us back to back
+    // (profiles/round5/gemm_vae_shapes_M23040_M46080.txt); at M = 23 040 (1.4 rounds) they lose (240 against 223 us) and shape 31 stays
+    if (!g_force_wm && wm == 31 && epi_x == EPI_RESID && p.N % 256 == 0 && p.N <= 1024 && p.K >= 1024) {
+        const int t256 = cdiv(p.M, 256) * (p.N / 256), rounds = cdiv(t256, 256);
+        if (rounds >= 2 && t256 * 10 >= rounds * 256 * 9) wm = 7;
+    }
 #ifdef GTAV_EXPERIMENTS
     if (!g_force_wm && epi_x == EPI_GELU_TANH && (g_debug & 0x600000) && cdiv(p.M, 128) * cdiv(p.N, 256) >= 512) wm = (g_debug & 0x200000) ? 33 : 32;   // A/B of the persistent 128 x 256 / 256 x 128 tiles for fc1 (debug bits 21 / 22)
 #endif

@@ -215,7 +215,11 @@ int launch_adamw(float* p, int ldp, int R, int C, const float* g, float* m, floa
 // Full (non-causal) attention over S tokens per (nb, head), head_dim 64 (model/attention.py:127-129, model/vae.py:101).
 // Q,K [nb][heads][S][64], Vt [nb][heads][64][S] fp16 (layouts written by the QKV GEMM epilogue);
 // O logical [nb*S][heads*64] fp16, TILE-MAJOR (A-operand of the out-projection GEMM).
-int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream);
+// q_prescaled: Q already carries the softmax scale in the exponent's unit, q / 8 * log2 e (written that way by the to_qkv epilogue through
+// GemmParams::rope_cs_q); only sequences that run the flash kernel take it — attn_spatial_wants_prescaled_q(S) says which
+int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream, bool q_prescaled = false);
+bool attn_spatial_wants_prescaled_q(int S);
+constexpr float kAttnQScale = 0.125f * 1.4426950408889634f;   // 1 / sqrt(64) * log2(e)
 // Causal attention over the frames of a window per (b, p, head) (model/attention.py:62-64).
 // q [B*Tq*P][D] row-major for frames t0 .. t0+Tq-1; kv cache [B][Tmax][P][2][D]; O logical like q but TILE-MAJOR.
 int launch_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax,

@@ -93,6 +93,8 @@ SIGNATURES = {
     "gtav_vae_encode": [_p, _p, _f, _f, _p, _i, _p],
     "gtav_vae_decode": [_p, _p, _f, _p, _f, _f, _i, _p],
     "gtav_vae_check": [_p, _p],
+    "gtav_vae_profile": [_p, _i],
+    "gtav_vae_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_clamp_frames": [_p, _i, _i, _i, _i, _f, _f, _p],
     "gtav_ddim_update": [_p, _p, _p, _i, _i, _p, _p, _i, _p],
     "gtav_add_noise": [_p, _p, _p, _p, _i, _i, _f, _p],

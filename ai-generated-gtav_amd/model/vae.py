@@ -155,6 +155,20 @@ class AutoencoderKL(_HipModule):
             with torch.cuda.device(self.device):
                 _lib.check(_lib.load().gtav_vae_check(self._handle, _lib.current_stream()))
 
+    PROFILE_CLASSES = ("ln_affine", "gemm_qkv", "attn_spatial", "attn_temporal", "gemm_proj", "gemm_fc1", "gemm_fc2", "other", "empty_event_pair")
+
+    def profile(self, enable: bool):
+        """In-situ per-kernel-class HIP-event timing of encode / decode (measurement passes only; include/gtav_amd.h gtav_vae_profile)."""
+        self._ensure(1)
+        _lib.check(_lib.load().gtav_vae_profile(self._handle, int(bool(enable))))
+
+    def profile_read(self):
+        import ctypes as C
+        ms = (C.c_double * 9)()
+        n = (C.c_int64 * 9)()
+        _lib.check(_lib.load().gtav_vae_profile_read(self._handle, ms, n))
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.PROFILE_CLASSES)}
+
     def autoencode(self, input, sample_posterior=True):
         """model/vae.py:340-347."""
         posterior = self.encode(input)

@@ -22,6 +22,9 @@ Extra objects in the line:
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py, fp32 torch CPU kernels — the reference's own CPU path) on the host cores, a
                  bounded sample extrapolated to the clip (rank 0, N = 1 only)
   config2/3    — the batch-8 action-conditioned leg: frames/s (window + context-cached), forward time, fc1 in situ, per-class ms
+  config4      — BASELINE configs[4] as specified, at every N: batch 16 per GPU of 5-frame 360x640 clips with `encode_frames` of the 80 frames INSIDE the
+                 timed region; forward + loss, and the whole optimisation step (bucketed RCCL gradient all-reduce when N > 1); its own roofline object
+                 (dominant GEMM class of the VAE-inclusive forward, per-class fractions at M = 46 080 / 11 520) and cpu_baseline
 """
 import argparse
 import hashlib
@@ -142,9 +145,9 @@ def parse_args(argv=None):
     ap.add_argument("--batched-clips", type=int, default=2,
                     help="timed clips per algorithm of the bounded batch-8 + actions leg (config2 / config3); 0 disables it")
     ap.add_argument("--batched-batch", type=int, default=8)
-    ap.add_argument("--train-leg-steps", type=int, default=3,
-                    help="timed optimisation steps of the bounded training leg of the default run (SURVEY.md 8(f)1: batch 16, forward + backward "
-                         "+ AdamW on latents resident in HBM; N = 1 only); 0 disables it")
+    ap.add_argument("--config4-steps", "--train-leg-steps", type=int, default=3, dest="config4_steps",
+                    help="timed steps of each timing of the bounded config4 leg of the default run (BASELINE configs[4]: batch 16 per GPU of 5-frame 360x640 "
+                         "clips, VAE encode of the 80 frames inside the timed region; forward + loss, and the whole optimisation step; every N); 0 disables it")
     ap.add_argument("--g256-clips", type=int, default=2,
                     help="timed clips of the bounded g256 leg of the default (native-geometry, N = 1) run: BASELINE.json's literal 256x256 frames through "
                          "the SURVEY.md 8(d) preset, batch 1, window algorithm; 0 disables it")
@@ -231,6 +234,159 @@ def bench_train(args, world, rank, dev, dist, torch):
                        "parallelism": ("data-parallel x%d (one all-reduce of the 2.4 GB fp32 gradient arena per step)" if full else
                                        "data-parallel x%d (forward only; loss all-reduce)") % world},
             "achieved_tflops_per_gpu": round(flops * args.steps / el / 1e12, 1)}))
+
+
+def bench_config4(args, world, rank, dev, dist, torch):
+    """The config4 object of the default line (see the call site).  Roofline object: the GEMM class with the largest time per VAE-inclusive forward, among the
+    VAE encoder's four (M = 80 x 576 = 46 080 tokens, one pass) and the DiT's four (M = 16 x 5 x 144 = 11 520), timed in situ with dispatch-attached HIP
+    events (gtav_vae_profile / gtav_dit_profile); algorithmic FLOPs per launch 2 M N K."""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT_models
+    from gtav_amd.model.vae import VAE_models
+    from gtav_amd.train import encode_frames, forward_loss, training_step
+    TB, NF = 16, 80
+    n = args.config4_steps
+    tdit = DiT_models["DiT-S/2"](init_weights=False, max_batch=TB, trainable=True)
+    tdit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
+    vae4 = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=NF)
+    vae4.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
+    g = torch.Generator().manual_seed(100 + rank)
+    frames = torch.rand(TB, 5, 3, 360, 640, generator=g).to(dev)
+    tact = torch.zeros(TB, 5, 25, device=dev)
+    tact[:, :, 3] = 1
+    tgt, ctx = torch.randint(1, 51, (TB,), generator=g), torch.randint(1, 41, (TB,), generator=g)
+    cn, nz = torch.randn(TB, 4, 16, 18, 32, generator=g).to(dev), torch.randn(TB, 1, 16, 18, 32, generator=g).to(dev)
+
+    def fwd():
+        lat = encode_frames(vae4, frames)
+        loss, _, _ = forward_loss(tdit, lat, tact, tgt, ctx, cn, nz)
+        if world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+            loss /= world
+        return loss
+
+    def step():
+        lat = encode_frames(vae4, frames)
+        return training_step(tdit, lat, tact, tgt, ctx, cn, nz, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, world_size=world)
+
+    def enc():
+        return encode_frames(vae4, frames)
+
+    def timed(fn, k):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el / k, out
+
+    fwd()
+    step()                                   # warm-up of both paths (workspaces, RCCL buckets)
+    t_fwd, loss_f = timed(fwd, n)
+    t_step, loss_s = timed(step, n)
+    t_enc, _ = timed(enc, n)
+    applied, skipped, gnorm = tdit.train_stats()
+    fl_dit = TB * dit_forward_flops(5 * P_TOK, 5, 15, 1)
+    fl_vae = NF * GEOM["native"]["vae_gflop"][0] * 1e9
+    # ---- in-situ per-class kernel times: two profiled encodes + two profiled forwards (outside the timed regions) ----
+    vae4.profile(True)
+    for _ in range(2):
+        enc()
+    vprof = vae4.profile_read()
+    vae4.profile(False)
+    tdit.profile(True)
+    for _ in range(2):
+        forward_loss(tdit, enc(), tact, tgt, ctx, cn, nz)
+    dprof = tdit.profile_read()
+    tdit.profile(False)
+    Mv, Md = NF * 576, TB * 5 * P_TOK
+    gf = {"vae_qkv": (vprof["gemm_qkv"], 2.0 * Mv * 3072 * 1024, "VAE qkv GEMM + bias / partial-RoPE / head-layout epilogue (N=3072 K=1024)"),
+          "vae_proj": (vprof["gemm_proj"], 2.0 * Mv * 1024 * 1024, "VAE attention projection, in-place residual epilogue (N=1024 K=1024)"),
+          "vae_fc1": (vprof["gemm_fc1"], 2.0 * Mv * 4096 * 1024, "VAE fc1 GEMM + erf-GELU epilogue (N=4096 K=1024)"),
+          "vae_fc2": (vprof["gemm_fc2"], 2.0 * Mv * 1024 * 4096, "VAE fc2 GEMM, in-place residual epilogue (N=1024 K=4096)"),
+          "dit_qkv": (dprof["gemm_qkv"], 2.0 * Md * 3072 * 1024, "DiT to_qkv GEMM + RoPE / head-layout epilogue (N=3072 K=1024)"),
+          "dit_out": (dprof["gemm_out"], 2.0 * Md * 1024 * 1024, "DiT out-proj GEMM (N=1024 K=1024)"),
+          "dit_fc1": (dprof["gemm_fc1"], 2.0 * Md * 4096 * 1024, "DiT fc1 GEMM + GELU-tanh epilogue (N=4096 K=1024)"),
+          "dit_fc2": (dprof["gemm_fc2"], 2.0 * Md * 1024 * 4096, "DiT fc2 GEMM (N=1024 K=4096)")}
+    per_class, tot_fl, tot_ms = {}, 0.0, 0.0
+    for k, ((ms, cnt), fl, _) in gf.items():
+        if cnt:
+            us = ms / cnt * 1e3
+            per_class[k] = {"us_per_launch": round(us, 2), "launches_per_forward": int(cnt // 2), "ms_per_forward": round(ms / 2, 3),
+                            "frac_of_mfma_peak": round(fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+            tot_fl += fl * cnt
+            tot_ms += ms
+    att_ms, att_n = vprof["attn_spatial"]
+    att_fl = 4.0 * 576 * 576 * 64 * 16 * NF
+    other = {"vae_attn_spatial_S576": {"us_per_launch": round(att_ms / max(att_n, 1) * 1e3, 2), "launches_per_forward": int(att_n // 2),
+                                       "frac_of_mfma_peak": round(att_fl / (att_ms / max(att_n, 1) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if att_n else None},
+             "vae_ln_affine": {"us_per_launch": round(vprof["ln_affine"][0] / max(vprof["ln_affine"][1], 1) * 1e3, 2), "launches_per_forward": int(vprof["ln_affine"][1] // 2)},
+             "dit_ln_modulate": {"us_per_launch": round(dprof["ln_modulate"][0] / max(dprof["ln_modulate"][1], 1) * 1e3, 2), "launches_per_forward": int(dprof["ln_modulate"][1] // 2)},
+             "vae_patchify_embed_quant_ms_per_forward": round(vprof["other"][0] / 2, 3)}
+    dom = max(per_class, key=lambda k: per_class[k]["ms_per_forward"])
+    (ms_d, n_d), fl_d, desc = gf[dom]
+    ach = fl_d / (ms_d / n_d * 1e-3) / 1e12
+    roofline = {"kernel": "%s, csrc/gemm.hip, M=%d, fp16 MFMA (the GEMM class with the largest time per VAE-inclusive forward)" % (desc, Mv if dom.startswith("vae") else Md),
+                "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(ms_d / n_d * 1e3, 2), "launches_timed": int(n_d), "flops_per_launch": fl_d,
+                "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
+                "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,
+                "per_class": per_class, "other_classes": other}
+    out = {"workload": "BASELINE configs[4] as specified: train_dit.py forward + loss (configs/train_dit_actions.yaml: batch %d per GPU x %d GPU(s), 5-frame 360x640 clips, "
+                       "ddim_noise_steps 50, ctx_max_noise_idx 40, clamp_min 1e-6), encode_frames of the %d frames per GPU INSIDE the timed region; second timing: the "
+                       "whole optimisation step (that forward, backward, gradient all-reduce, clip_grad_norm 1.0, AdamW)" % (TB, world, NF),
+           "steps_timed": n, "world_size": world,
+           "forward_loss": {"ms_per_step": round(t_fwd * 1e3, 2), "samples_per_s": round(world * TB / t_fwd, 2), "loss": float(loss_f),
+                            "executed_tflop_per_gpu_step": round((fl_dit + fl_vae) / 1e12, 3), "achieved_tflops_per_gpu": round((fl_dit + fl_vae) / t_fwd / 1e12, 1),
+                            "frac_of_mfma_peak": round((fl_dit + fl_vae) / t_fwd / 1e12 / MFMA_PEAK_TFLOPS, 4)},
+           "train_step": {"ms_per_step": round(t_step * 1e3, 2), "samples_per_s": round(world * TB / t_step, 2), "loss": float(loss_s),
+                          "achieved_tflops_per_gpu": round((3 * fl_dit + fl_vae) / t_step / 1e12, 1), "last_step_applied": bool(applied), "skipped_steps": skipped,
+                          "grad_norm": round(gnorm, 4),
+                          "gradient_all_reduce": ("RCCL, world size %d: bucketed all-reduce of the 2.4 GB fp32 gradient arena, overlapped with the backward pass" % world)
+                          if world > 1 else "none (one rank)",
+                          "dtype": "fp16 operands, fp32 accumulate / master weights / gradients / AdamW state, loss scale %g" % tdit.loss_scale},
+           "vae_encode_80_frames": {"ms": round(t_enc * 1e3, 3), "tflops": round(fl_vae / t_enc / 1e12, 1), "frac_of_mfma_peak": round(fl_vae / t_enc / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                    "frames_per_call": NF},
+           "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the reference's CPU path for the same step, ONE sample: VAE encode of its 5 frames + DiT forward (B = 1, T = 5) + loss; and autograd + AdamW for the step
+        from oracle import ref_cpu as O
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        sd, vsd = tdit.state_dict(), vae4.state_dict()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            lat1 = O.vae_encode_frames(vsd, O.vit_l_20_shallow_encoder(), frames[:1].cpu())
+            t_e = time.perf_counter() - t0
+            t1 = torch.tensor([[19, 19, 19, 19, 500]])
+            t0 = time.perf_counter()
+            O.dit_forward(sd, O.dit_s_2(), lat1, t1, tact[:1].cpu())
+            t_f = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, _, grads = O.dit_loss_and_grads(sd, O.dit_s_2(), lat1, t1, tact[:1].cpu(), nz[:1].cpu())
+        t_b = time.perf_counter() - t0
+        params = {k: v for k, v in sd.items() if not k.endswith("freqs")}
+        t0 = time.perf_counter()
+        O.adamw_reference(params, grads, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, steps=1)
+        t_o = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / (t_e + t_f), 4), "unit": "samples/s (forward + loss)", "cores": cores, "kind": "port",
+                               "train_step_samples_per_s": round(1.0 / (t_e + t_b + t_o), 4),
+                               "sample": "oracle/ref_cpu.py (fp32 torch CPU), ONE 5-frame sample: VAE encode of its 5 frames %.2f s + DiT forward %.2f s; for the step: "
+                                         "autograd forward + backward %.2f s + clip_grad_norm_ + AdamW over the 608 M parameters %.2f s" % (t_e, t_f, t_b, t_o)}
+        del grads, params, sd, vsd
+    del tdit, vae4, frames, cn, nz
+    torch.cuda.empty_cache()
+    return out
 
 
 def rank_main(args):
@@ -544,64 +700,13 @@ def bench_generate(args, world, rank, dev, dist, torch):
                 sys.stderr.write("bench.py: SHARD SELF-CHECK FAILED: the gathered latents of rank %d differ from rank 0's recomputation\n" % other)
         dist.barrier()       # (the other ranks only took part in the gather)
 
-    # ---- bounded training leg (N = 1): the optimisation step of SURVEY.md 8(f)1 on latents already in HBM (the VAE encode of the trainer
-    # is measured by --mode train / train_step) ----
-    train_leg = None
-    if world == 1 and args.train_leg_steps > 0 and args.geometry == "native":
-        from gtav_amd.train import training_step, forward_loss
-        TB = 16
-        tdit = DiT_models["DiT-S/2"](init_weights=False, max_batch=TB, trainable=True)
-        tdit.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
-        g = torch.Generator().manual_seed(77)
-        lat = (torch.randn(TB, 5, 16, LH, LW, generator=g) * 0.5).to(dev)
-        tact = torch.zeros(TB, 5, 25, device=dev)
-        tact[:, :, 3] = 1
-        tgt, ctx = torch.randint(1, 51, (TB,), generator=g), torch.randint(1, 41, (TB,), generator=g)
-        cn, nz = torch.randn(TB, 4, 16, LH, LW, generator=g).to(dev), torch.randn(TB, 1, 16, LH, LW, generator=g).to(dev)
-        tstep = lambda: training_step(tdit, lat, tact, tgt, ctx, cn, nz, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0)
-        tstep()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.train_leg_steps):
-            tloss = tstep()
-        torch.cuda.synchronize()
-        t_step = (time.perf_counter() - t0) / args.train_leg_steps
-        for _ in range(2):
-            forward_loss(tdit, lat, tact, tgt, ctx, cn, nz)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            forward_loss(tdit, lat, tact, tgt, ctx, cn, nz)
-        torch.cuda.synchronize()
-        t_fwd = (time.perf_counter() - t0) / 5
-        applied, skipped, gnorm = tdit.train_stats()
-        fl = TB * dit_forward_flops(5 * P_TOK, 5, 15, 1)
-        train_leg = {"workload": "SURVEY.md 8(f)1: DiT-S/2 optimisation step on 5-frame latent clips, batch %d, action-conditioned "
-                                 "(train_dit.py:590-680, 965-970: forward + loss, backward, clip_grad_norm 1.0, AdamW)" % TB,
-                     "steps_timed": args.train_leg_steps, "ms_per_step": round(t_step * 1e3, 2), "samples_per_s": round(TB / t_step, 2),
-                     "achieved_tflops": round(3 * fl / t_step / 1e12, 1), "forward_loss_ms": round(t_fwd * 1e3, 2),
-                     "loss": float(tloss), "last_step_applied": bool(applied), "skipped_steps": skipped, "grad_norm": round(gnorm, 4),
-                     "dtype": "fp16 operands, fp32 accumulate / master weights / gradients / AdamW state, loss scale %g" % tdit.loss_scale}
-        if rank == 0 and not args.no_cpu_baseline:
-            # the reference's CPU path for the same step: torch autograd + torch.optim.AdamW on the oracle, ONE sample (B = 1, T = 5)
-            from oracle import ref_cpu as O
-            cores = host_cores()
-            torch.set_num_threads(cores)
-            sd = {k: v for k, v in tdit.state_dict().items()}
-            x1, t1, a1, v1 = lat[:1].cpu(), torch.tensor([[15, 15, 15, 15, 500]]), tact[:1].cpu(), nz[:1].cpu()
-            t0 = time.perf_counter()
-            _, _, grads = O.dit_loss_and_grads(sd, O.dit_s_2(), x1, t1, a1, v1)
-            t_bwd = time.perf_counter() - t0
-            params = {k: v for k, v in sd.items() if not k.endswith("freqs")}
-            t0 = time.perf_counter()
-            O.adamw_reference(params, grads, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, steps=1)
-            t_opt = time.perf_counter() - t0
-            train_leg["cpu_baseline"] = {"value": round(1.0 / (t_bwd + t_opt), 4), "unit": "samples/s", "cores": cores, "kind": "port",
-                                         "sample": "oracle/ref_cpu.py: torch autograd forward + backward of ONE 5-frame sample (%.2f s) + clip_grad_norm_ "
-                                                   "+ torch.optim.AdamW over the 608 M parameters (%.2f s)" % (t_bwd, t_opt)}
-            del grads, params, sd
-        del tdit, lat, cn, nz
-        torch.cuda.empty_cache()
+    # ---- bounded config4 leg (every N): BASELINE configs[4] AS SPECIFIED — batch 16 per GPU of 5-frame 360x640 clips, `encode_frames` of the 80 frames
+    # INSIDE the timed region (train_dit.py:329-351,570), then forward + loss (train_dit.py:590-650) and, as a second timing, the whole optimisation step
+    # (backward, bucketed gradient all-reduce over RCCL when N > 1 — overlapped with the backward pass —, clip, AdamW: SURVEY.md 8(f)1).  Frames are
+    # resident in HBM before the region starts; barrier + synchronize on both sides, maximum over ranks ----
+    config4 = None
+    if args.config4_steps > 0 and args.geometry == "native":
+        config4 = bench_config4(args, world, rank, dev, dist, torch)
 
     # ---- bounded g256 leg (N = 1, native default run only): BASELINE.json's literal "[B, 32 frames, 256x256]" through the SURVEY.md 8(d) preset
     # (VAE patch 16 -> 16x16x16 latents, 64 DiT tokens per frame, DiT-S / ViT-L widths), batch 1, no actions, window algorithm, VAE in the timed region ----
@@ -698,8 +803,8 @@ def bench_generate(args, world, rank, dev, dist, torch):
         line.update(algo_report(B, results, args.steps))
         if batched is not None:
             line["config2" if world == 1 else "config3"] = batched
-        if train_leg is not None:
-            line["train_step"] = train_leg
+        if config4 is not None:
+            line["config4"] = config4
         if g256_leg is not None:
             line["g256"] = g256_leg
         if shard_check is not None:

@@ -239,6 +239,11 @@ int gtav_vae_decode(gtav_vae* h, const float* z_dev, float z_scale, float* img_d
 
 /* Same as gtav_dit_check for the VAE handle (NaN/inf input pixels, fp16 saturation). */
 int gtav_vae_check(gtav_vae* h, void* stream);
+/* In-situ kernel timing of encode / decode, as gtav_dit_profile (same GTAV_PROFILE_CLASSES order; class 3, temporal attention, stays empty; 4 = the
+ * attention projection, 7 = patchify / patch embedding / quant_conv / post_quant_conv / predictor / unpatchify): bench.py's config4 roofline object.
+ * With it enabled every encode / decode call synchronises `stream` at its end. */
+int gtav_vae_profile(gtav_vae* h, int32_t enable);
+int gtav_vae_profile_read(gtav_vae* h, double* ms_by_class, int64_t* launches_by_class);
 
 /* ------------------------------------------------------------------------------------------------
  * Sampler / training elementwise math on caller-owned buffers

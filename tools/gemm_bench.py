@@ -28,6 +28,8 @@ def main():
     shapes = [("qkv", 3072, 1024, 5), ("qkvt", 3072, 1024, 7), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]   # epi 7 here = temporal QKV
     if "train" in a.only:   # GEMMs of the training step without an activation: fc1 forward / fc2 dX (fp16 tile-major out, code 70 = EPI_F16_TILED), fc1 dX / to_qkv dX (fp32 out)
         shapes += [("train_f16t", 4096, 1024, 70), ("train_f32_k4096", 1024, 4096, 0), ("train_f32_k3072", 1024, 3072, 0)]
+    if "vae" in a.only:     # the ViT-VAE's GEMMs (model/vae.py:115-157): erf-GELU fc1, un-gated in-place residual proj / fc2 (code 40 = EPI_RESID without a gate), QKV at S = 576
+        shapes += [("vae_qkv", 3072, 1024, 55), ("vae_fc1", 4096, 1024, 3), ("vae_proj", 1024, 1024, 40), ("vae_fc2", 1024, 4096, 40)]
     if "floor" in a.only:   # one K-step only: launch + first tile + epilogue (the per-launch floor of each epilogue)
         shapes += [("floor_gelu", 4096, 64, 2), ("floor_f32", 4096, 64, 0), ("floor_part", 1024, 64, 6), ("floor_n128", 128, 64, 0)]
     print(f"{'shape':>5} {'M':>6} {'N':>5} {'K':>5} {'ns':>3} {'split':>5} {'us':>9} {'TFLOP/s':>9}")
@@ -42,7 +44,9 @@ def main():
             sk = (a.splitk or lib.gtav_op_gemm_choose_splitk(M, N, K)) if epi == 6 else 1
             # fp32 row-major for epilogues 0 / 6, fp16 (tile-major, rows padded to 128) otherwise; sized for the padded M
             Mp = (M + 127) // 128 * 128
-            out = torch.empty((max(sk, 1) * Mp, N), device=dev, dtype=torch.float32 if epi in (0, 6) else torch.float16)
+            out = torch.zeros((max(sk, 1) * Mp, N), device=dev, dtype=torch.float32 if epi in (0, 6, 40) else torch.float16)
+            vq = torch.empty(3, Mp, 1024, device=dev, dtype=torch.float16) if epi == 55 else None
+            vcs = torch.ones(576, 64, device=dev) if epi == 55 else None
             q = torch.empty(3, M, 1024, device=dev, dtype=torch.float16)
             cs = torch.ones(144, 64, device=dev)
             sn = torch.zeros(144, 64, device=dev)
@@ -58,6 +62,12 @@ def main():
                         Mq = (M // 144) * 144
                         L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Mq, 1024, 0, q[0].data_ptr(), q[1].data_ptr(),
                                                      q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), st))
+                    elif epi == 55:     # VAE: S = 576 tokens per attention item
+                        Mq = (M // 576) * 576
+                        L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), Mq, 1024, 0, vq[0].data_ptr(), vq[1].data_ptr(),
+                                                     vq[2].data_ptr(), 576, 0, 0, 0, vcs.data_ptr(), st))
+                    elif epi == 40:     # in-place residual without a gate
+                        L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), out.data_ptr(), N, M, N, K, 4, 0, 0, 0, st))
                     elif epi == 7:      # temporal layout: q [M][D], k/v into a [B][Tmax][P][2][D] cache (B = 1 here, Tq = M / 144 frames)
                         Tq = M // 144
                         Bq = max(1, Tq // 5)
