@@ -47,3 +47,16 @@ def gemm(x16, w16, bias, M, N, K, epi, out, ldo, gate=None, gate_stride=0, rows_
     L.check(L.load().gtav_op_gemm_f16(x16.data_ptr(), K, w16.data_ptr(), L.ptr(bias), out.data_ptr(), ldo, M, N, K,
                                       epi, L.ptr(gate), gate_stride, rows_per_gate, stream()))
     return out
+
+
+def resize_probe_image(H, W):
+    """The deterministic uint8 probe image (H, W, 3) of fixture G11 (tools/make_golden.py resize_probe_image: integer arithmetic only)."""
+    import torch
+    y = torch.arange(H).view(H, 1, 1)
+    x = torch.arange(W).view(1, W, 1)
+    c = torch.arange(3).view(1, 1, 3)
+    return ((x * 7 + y * 13 + c * 29 + (x * y) % 11 + ((x // 3) * (y // 5)) % 17 * 9) % 256).to(torch.uint8)
+
+
+G11_ROWS = (0, 1, 100, 179, 180, 358, 359)
+G11_SIZES = {"500x333": (333, 500), "480x270": (270, 480), "1280x720": (720, 1280)}

@@ -521,7 +521,7 @@ def test_harness_config1_vs_reference_golden(full_vae):
     print(f"harness: encode {e_enc:.2e} latents {e_lat:.2e} frames {e_img:.2e} (max |err| {dmax:.3f} of 255); "
           f"{nbad} of {diff.numel()} bytes differ from the reference, all by 1")
     assert e_enc < TOL_FULL and e_lat < TOL_SMALL and e_img < TOL_SMALL
-    assert diff.max().item() <= 1 and bool(near[diff > 0].all()) and nbad < 0.2 * diff.numel()
+    assert diff.max().item() <= 1 and bool(near[diff > 0].all()) and nbad < 0.08 * diff.numel()   # measured 4.2 % (7 180 of 172 800)
     assert (u8.cpu()[:, :, 100].int() - g["frames_u8_row100"].int()).abs().max().item() <= 1     # a full-width row (every column phase)
 
 
@@ -536,6 +536,33 @@ def test_encode_frames_training_leg(full_vae):
     out = encode_frames(v, frames.to(dev()))
     assert out.shape == ref.shape == (1, 2, 16, 18, 32)
     assert rel_l2(out, ref) < 1e-3
+
+
+@pytest.mark.parametrize("per_call", [40, 80])
+def test_encode_frames_at_the_trainer_batch(full_vae, per_call):
+    """BASELINE configs[4]'s encode leg at ITS size (train_dit.py:329-351,570: 16 clips x 5 frames = 80 frames of 360x640 per step): one call of 80 frames
+    (M = 46 080 tokens: 256 x 256 in-place residual tiles, 3 840-block flash attention grids, q in the exponent's unit) and two of 40 (M = 23 040: the
+    persistent 128 x 192 kernel).  Frames never interact in the VAE (model/vae.py:306-322), so the oracle runs on three of them — first, last, one across the
+    40-frame seam — and every frame must also agree with its own 2-frame call (same kernels on other tile shapes: fp32 summation order only)."""
+    from gtav_amd.train import encode_frames
+    _, sd, cfg = full_vae
+    v = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=per_call)
+    v.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(33)
+    frames = torch.rand(16, 5, 3, 360, 640, generator=gen)
+    fd = frames.to(dev())
+    out = encode_frames(v, fd).cpu()                                   # (16, 5, 16, 18, 32)
+    v.check()
+    assert out.shape == (16, 5, 16, 18, 32) and torch.isfinite(out).all()
+    for (b, t) in ((0, 0), (8, 0), (15, 4)):                           # frames 0, 40, 79
+        with torch.no_grad():
+            ref = O.vae_encode_frames(sd, cfg, frames[b:b + 1, t:t + 1])
+        assert rel_l2(out[b:b + 1, t:t + 1], ref) < TOL_FULL
+    small = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=2)
+    small.load_state_dict(sd)
+    for b in (3, 7, 12):
+        two = encode_frames(small, fd[b:b + 1, 1:3]).cpu()
+        assert rel_l2(out[b:b + 1, 1:3], two) < 3e-4
 
 
 def test_full_dit_batch8_production_shapes():
@@ -710,6 +737,22 @@ def test_dataset_step_and_prompt_resize():
         assert (got.cpu() - want).abs().max().item() < 2e-6, (H, W_)
 
 
+def test_prompt_resize_against_the_committed_fixture():
+    """§8(f)2 pinned: the HIP resize kernel (data.resize_frames) against fixture G11 — committed output rows of `transforms.Resize((360, 640))` as the reference
+    applies it (generate.py:150-153, web_dataset.py:105-107), generated by tools/make_golden.py — on the 500 x 333 probe (down- and up-scaling at once),
+    the dataset's 480 x 270 frames and a 1280 x 720 image; no oracle call at run time."""
+    from safetensors.torch import load_file
+    from helpers import G11_ROWS, G11_SIZES, resize_probe_image
+    from gtav_amd.data import resize_frames
+    g = load_file(os.path.join(os.path.dirname(__file__), "golden", "g11_resize.safetensors"))
+    for tag, (H, W_) in G11_SIZES.items():
+        img = resize_probe_image(H, W_).permute(2, 0, 1)[None].float() / 255.0
+        y = resize_frames(img.to(dev())).cpu()[0]
+        assert y.shape == (3, 360, 640)
+        assert (y[:, list(G11_ROWS)] - g[f"{tag}.rows"]).abs().max().item() < 2e-6, tag
+        assert (y[:, ::8, ::8] - g[f"{tag}.stride8"]).abs().max().item() < 2e-6, tag
+
+
 def test_read_prompt_frame_and_video_out(tmp_path):
     """generate.py:150-153 + 244-246 around the path: a PNG start frame -> prompt tensor; generated uint8 frames -> a video file."""
     from PIL import Image
@@ -758,7 +801,7 @@ def test_config0_production_size_vs_reference_golden(full_dit, full_vae):
     # 33 chained full-size forwards: per-forward error 6-9e-4 (TOL_FULL), accumulated over the rollout
     # (measured: latents 3.7e-4, frames 4.5e-4, byte differences of at most 1 — profiles/round3/test_margins_pytest_s.txt)
     assert e_enc < TOL_FULL and e_lat < 1.5e-3 and e_img < 1.5e-3 and rel_l2(lat_c, lat) < 1e-4
-    assert diff.max().item() <= 1 and int((diff > 0).sum()) < 0.3 * diff.numel()
+    assert diff.max().item() <= 1 and int((diff > 0).sum()) < 0.08 * diff.numel()   # measured 4.4 % (7 622 of 172 800)
 
 
 def test_full_size_checkpoint_in_the_reference_writers_convention(tmp_path, full_dit):

@@ -20,7 +20,7 @@ def rel_l2(a, b):
 
 pytestmark = pytest.mark.gpu
 
-GRAD_TOL = 6e-3   # relative L2 per gradient tensor; measured worst 3.5e-3 (toy model, B = 5) / 3.3e-3 (full size), pytest -s prints every margin
+GRAD_TOL = 4.5e-3   # relative L2 per gradient tensor; measured worst 3.5e-3 (toy model, B = 5) / 3.3e-3 (full size), pytest -s prints every margin
 
 KW = dict(input_h=8, input_w=16, patch_size=2, in_channels=16, hidden_size=256, depth=2, num_heads=4, external_cond_dim=25)
 

@@ -375,3 +375,16 @@ def test_g8_training_oracle_matches_reference_autograd_and_adamw():
         # first Adam step: |update| ~ lr per element, sign(g): elements whose reference gradient is ~0 may flip; compare where it is not
         big = _g8_sel(grads[k]).abs() > 1e-3 * _g8_sel(grads[k]).abs().max()
         assert rel(upd[big], upd_ref[big]) < 1e-3, k
+
+
+def test_oracle_resize_against_g11():
+    """Fixture G11 (tools/make_golden.py g11_resize): `transforms.Resize((360, 640))` of generate.py:150-153 / web_dataset.py:105-107 restated against torch —
+    the oracle's resize_frames must reproduce the committed output rows of the three probe images."""
+    from safetensors.torch import load_file
+    from helpers import G11_ROWS, G11_SIZES, resize_probe_image
+    g = load_file(os.path.join(GOLD, "g11_resize.safetensors"))
+    for tag, (H, W_) in G11_SIZES.items():
+        img = resize_probe_image(H, W_).permute(2, 0, 1)[None].float() / 255.0
+        y = O.resize_frames(img)[0]
+        assert (y[:, list(G11_ROWS)] - g[f"{tag}.rows"]).abs().max().item() < 1e-6, tag
+        assert (y[:, ::8, ::8] - g[f"{tag}.stride8"]).abs().max().item() < 1e-6, tag

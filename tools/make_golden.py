@@ -244,9 +244,41 @@ def g10_frame_loop(rd, ref_schedule):
     save("g10_frame_loop.safetensors", out)
 
 
+def resize_probe_image(H, W):
+    """A deterministic uint8 image (H, W, 3) from integer arithmetic only (no RNG: the tests rebuild it bit for bit): smooth ramps + a fine texture."""
+    y = torch.arange(H).view(H, 1, 1)
+    x = torch.arange(W).view(1, W, 1)
+    c = torch.arange(3).view(1, 1, 3)
+    return ((x * 7 + y * 13 + c * 29 + (x * y) % 11 + ((x // 3) * (y // 5)) % 17 * 9) % 256).to(torch.uint8)
+
+
+G11_ROWS = (0, 1, 100, 179, 180, 358, 359)
+
+
+@torch.no_grad()
+def g11_resize():
+    """G11: frame I/O on either side of the path — `transforms.Resize((360, 640))` as generate.py:150-153 applies it to the --start_frame
+    image and web_dataset.py:105-107 / hf_dataset.py:30-33 to every dataset frame.  torchvision is absent from the image, so its semantics are restated
+    against torch: transforms.Resize on a float tensor is torchvision.transforms.functional.resize -> torch.nn.functional.interpolate(mode="bilinear",
+    align_corners=False, antialias=True) (torchvision >= 0.17 default; README.md:65 installs the newest).  Two probes: a 500 x 333 (W x H) image
+    (mixed up- / down-scaling: the antialias filter is live along x... and y) and the dataset's own 480 x 270 frame size (pure up-scaling).
+    Stored: seven full-width output rows and a stride-8 subsample of each result (the input is rebuilt in the tests from resize_probe_image)."""
+    import torch.nn.functional as F
+    out = {}
+    for tag, (H, W_) in (("500x333", (333, 500)), ("480x270", (270, 480)), ("1280x720", (720, 1280))):
+        img = resize_probe_image(H, W_).permute(2, 0, 1)[None].float() / 255.0          # ToTensor()
+        y = F.interpolate(img, size=(360, 640), mode="bilinear", align_corners=False, antialias=True)
+        out[f"{tag}.rows"] = y[0][:, list(G11_ROWS)].clone()
+        out[f"{tag}.stride8"] = y[0][:, ::8, ::8].clone()
+    save("g11_resize.safetensors", out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-g11" in sys.argv:
+        return g11_resize()
     rd, rv, ref_denoise_step, ref_schedule = ref_shim.import_reference()
+    g11_resize()
     if "--only-g9-g10" in sys.argv:
         g10_frame_loop(rd, ref_schedule)
         return g7_harness(rd, rv, ref_denoise_step, ref_schedule, full_dit=True)
