@@ -11,7 +11,6 @@
 //   gemm256_kernel  256 x 256 tile, K-tile in four quadrant phases                             mainloop256
 //   gemm_l_kernel   loader-wave tiles (small and medium M: 128 x 96, 64 x 48 / 96, 128 x 144)   mainloop_l
 //   gemm_lp_kernel  persistent loader-wave kernel, 128 x 192 tiles (large-M residual GEMMs, in-place residual epilogue)
-//   gemm_p256_kernel persistent 192 x 256 tiles with a K split of the remainder (round 4: a tested alternative, not selected)
 // launch_gemm() picks the shape per launch from a cost model / measured thresholds (bottom of this file).  Kernels, launchers and block shapes that only
 // ever measured slower live in gemm_experiments.inc, which only `build.sh exp` compiles.
 //
@@ -2480,407 +2479,7 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
     if constexpr (EPI != EPI_PARTIAL) sat_report(amax, p.err_flag);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent 256-token tiles for large M (shape 40 / 41, round 4).
-//
-// mainloop256's K-tile (four quadrant phases of FI x 2 MFMAs, half-tile fills interleaved, two barriers) is the most efficient K-step of this file —
-// 1.39 us for 8.4 MFLOP per CU = 0.62 of the MFMA peak in steady state, against 0.47 for the 128 x 192 loader-wave tile — but as a one-shot kernel it
-// paid a prologue per tile and a whole round for any remainder of tiles (360 tiles on 256 CUs at M = 5760: 2 rounds for 1.41 rounds of work).  Here:
-//   * ONE block of 8 waves per CU walks a sequence of work units; the two-parity LDS ring never drains — the W half-tiles of the next unit's first K-tile and
-//     the X half-tiles of its first two are issued during the last K-tiles of the current unit, so only the first unit of a block pays a prologue;
-//   * the epilogue runs straight from the accumulators (pairs of lanes exchange halves: every store is 16 bytes; bias through a 1 KiB LDS slice), the ring
-//     is not touched, and the stores drain under the next unit's K loop;
-//   * tiles are dealt in whole rounds (tile t on block t % grid); a remainder of r <= grid / 2 tiles is split in two K halves over 2 r blocks.  Block
-//     2 i + 1 runs the K TAIL of tile dp + i FIRST in its sequence and hands its partial sums over (fp32, register layout, sk_ws); block 2 i runs the K HEAD
-//     LAST, adds the partial tile and owns the epilogue — by then the partial has been waiting for a whole round, nobody spins in practice.  Hand-off:
-//     plain stores -> every wave vmcnt(0) -> barrier -> one agent-scope release -> flag; relaxed poll -> one agent-scope acquire -> barrier -> plain loads
-//     (MI355X_MICROARCH.md, inter-workgroup visibility); the flag is reset by its consumer, so it is zero between launches (graph replays included).
-// FI = feature groups of 16 per wave: 8 -> 256-feature tiles, 6 -> 192 (3072 = 16 x 192: 368 instead of 276 tile slots at M = 5760).
-// Fill addresses are wave-uniform (SGPR) bases + one per-lane offset (glds16_s): the kernel sits at the 256-register limit like gemm256_kernel.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int FI>
-struct P256 {
-    static constexpr int TNB = 32 * FI, NWP = TNB / 8, NWQ = NWP / 8, NWQ0 = (NWQ + 1) / 2;   // W pieces (1 KiB = 8 rows) per K-tile, per wave, in phase 1
-    static constexpr int WREG = NWP * 1024, PAR = WREG + 32 * 1024;                            // LDS bytes of the W region / of one parity (W + 256 X rows)
-    static constexpr int BIAS_OFF = 2 * PAR, LDS = 2 * PAR + TNB * 4 + 16 * 8 * 4;   // ring, bias slice, unit list
-};
-struct P256Unit { int n0, m0, kt0, nkt, kind, slot; };   // kind 0: whole tile; 1: K tail of a split tile (partial sums out); 2: K head (partial sums in, owns the epilogue)
-
-template <int FI>
-__device__ __forceinline__ P256Unit p256_unit(const GemmParams& p, int u, int tiles_m, int tiles_n, int nktot) {
-    const int G = gridDim.x, b = blockIdx.x;
-    const bool split = b < 2 * p.sk_r, helper = split && (b & 1);
-    const int n_dp = b < p.sk_dp ? (p.sk_dp - b + G - 1) / G : 0;
-    const int d = u - (helper ? 1 : 0);
-    P256Unit r;
-    r.kt0 = 0; r.nkt = nktot; r.kind = 0; r.slot = 0;
-    int v;
-    const int kh = (nktot >> 1) & ~1;   // split point: both halves hold an even number of K-tiles (the K loop advances by pairs)
-    if (helper && u == 0) { v = p.sk_dp + (b >> 1); r.kind = 1; r.slot = b >> 1; r.kt0 = kh; r.nkt = nktot - kh; }
-    else if (d < n_dp) v = b + d * G;
-    else { v = p.sk_dp + (b >> 1); r.kind = 2; r.slot = b >> 1; r.nkt = kh; }
-    lp_tile_of(p, v, tiles_m, tiles_n, 32 * FI, 256, r.n0, r.m0);
-    return r;
-}
-
-constexpr int P256_MAXU = 16;   // work units per block (whole rounds + one split piece): host-checked
-template <int EPI, int FI>
-__global__ __launch_bounds__(512, 1) void gemm_p256_kernel(GemmParams p) {
-    using C = P256<FI>;
-    constexpr int FIH = FI / 2, NWQ = C::NWQ, NWQ0 = C::NWQ0, TNB = C::TNB;
-    static_assert(FI == 8 || FI == 6, "256- or 192-feature tiles");
-    static_assert(EPI == EPI_F32 || EPI == EPI_PARTIAL || EPI == EPI_GELU_TANH || EPI == EPI_F16_TILED, "epilogues of the persistent 256-token-tile kernel");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = w & 1, wm = w >> 1;
-    const int nktot = p.K / TK;
-    const int G = gridDim.x, b = blockIdx.x;
-    const bool split = b < 2 * p.sk_r;
-    const int n_dp = b < p.sk_dp ? (p.sk_dp - b + G - 1) / G : 0;
-    const int nunits = n_dp + (split ? 1 : 0);
-    if (nunits == 0) return;
-#ifdef GTAV_EXPERIMENTS   // per-block timeline of the FIRST unit (tools/gemm_stamps.py): entry, first K-tile landed, main loop done, epilogue done; slot 7 = block end
-#define P256_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    if (p.stamps && tid == 0) { p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memtime(); }
-#else
-#define P256_STAMP(i) do { } while (0)
-#endif
-    P256_STAMP(0);
-    const int S = n_dp * nktot + (split ? ((b & 1) ? nktot - ((nktot >> 1) & ~1) : ((nktot >> 1) & ~1)) : 0);   // K-tiles of this block (even)
-    const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
-    const unsigned voff = (unsigned)lane * 16u, smem0 = lds_offset(smem);
-    // ---- the block's unit list, decoded ONCE (one unit per thread: the tile map's integer divisions stay out of the K loop) into LDS ----
-    int* const ut = (int*)(smem + C::BIAS_OFF + TNB * 4);
-    if (tid < nunits) {
-        const P256Unit un = p256_unit<FI>(p, tid, (p.M + 255) >> 8, (p.N + TNB - 1) / TNB, nktot);
-        int* q = ut + 8 * tid;
-        q[0] = un.n0; q[1] = un.m0; q[2] = un.kt0; q[3] = un.nkt; q[4] = un.kind; q[5] = un.slot;
-    }
-    __syncthreads();
-    auto unit_field = [&](int u, int f) { return __builtin_amdgcn_readfirstlane(ut[8 * u + f]); };
-
-    // ---- fill cursors: the next W K-tile / X K-tile to issue (they run one / two K-tiles ahead of the MFMAs, across unit boundaries) ----
-    int wu = 0, wk = 0, wi = 0, wnk, xu = 0, xk = 0, xi = 0, xnk;
-    // piece sources as 32-bit byte offsets from the operand's base (host-checked: both operands are smaller than 4 GiB): one SGPR per piece, and the
-    // fill address is SGPR base + (per-lane offset + wave-uniform offset) — eight 64-bit bases did not fit the scalar file beside the rest of the kernel
-    unsigned wso[NWQ], xso[4];
-    auto setW = [&](int u) {
-        const int n0 = unit_field(u, 0), kt0 = unit_field(u, 2);
-        wnk = unit_field(u, 3);
-#pragma unroll
-        for (int i = 0; i < NWQ; ++i) {
-            const int row = n0 + 8 * (w + 8 * i);
-            int rt = row >> 7;
-            rt = rt < last_wt ? rt : last_wt;                 // ragged edges re-read a valid tile (results are masked)
-            wso[i] = (unsigned)(rt * nktot + kt0) * (unsigned)TILE_BYTES + (unsigned)(((row & 127) >> 3) * 1024);
-        }
-    };
-    auto setX = [&](int u) {
-        const int m0 = unit_field(u, 1), kt0 = unit_field(u, 2);
-        xnk = unit_field(u, 3);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + 8 * (w + 8 * i);
-            int rt = row >> 7;
-            rt = rt < last_rt ? rt : last_rt;
-            xso[i] = (unsigned)(rt * nktot + kt0) * (unsigned)TILE_BYTES + (unsigned)(((row & 127) >> 3) * 1024);
-        }
-    };
-    auto issueW = [&](auto first) {      // pieces [0, NWQ0) (phase 1) or [NWQ0, NWQ) (phase 2) of W K-tile wi
-        constexpr bool F = decltype(first)::value;
-        const unsigned d = smem0 + (unsigned)(wi & 1) * C::PAR + (unsigned)w * 1024u;
-        const unsigned go = (unsigned)wk * (unsigned)TILE_BYTES;
-#pragma unroll
-        for (int i = F ? 0 : NWQ0; i < (F ? NWQ0 : NWQ); ++i) glds16_s(p.W, voff + (wso[i] + go), d + i * 8192);
-    };
-    auto advW = [&]() {
-        ++wi;
-        if (++wk == wnk) {
-            wk = 0;
-            if (++wu < nunits) setW(wu);
-        }
-    };
-    auto issueX = [&](auto first) {      // pieces 0, 1 (phase 3) or 2, 3 (phase 4) of X K-tile xi
-        constexpr bool F = decltype(first)::value;
-        const unsigned d = smem0 + (unsigned)(xi & 1) * C::PAR + C::WREG + (unsigned)w * 1024u;
-        const unsigned go = (unsigned)xk * (unsigned)TILE_BYTES;
-#pragma unroll
-        for (int i = F ? 0 : 2; i < (F ? 2 : 4); ++i) glds16_s(p.X, voff + (xso[i] + go), d + i * 8192);
-    };
-    auto advX = [&]() {
-        ++xi;
-        if (++xk == xnk) {
-            xk = 0;
-            if (++xu < nunits) setX(xu);
-        }
-    };
-    constexpr std::true_type FIRST{};
-    constexpr std::false_type SECOND{};
-    setW(0);
-    setX(0);
-    // K-tiles 0 and 1 are issued completely (X before W: the K loop's counted waits rely on that order), K-tile 0 is awaited with K-tile 1 in flight
-    issueX(FIRST); issueX(SECOND); advX();
-    issueW(FIRST); issueW(SECOND); advW();
-    if (S > 1) {
-        issueX(FIRST); issueX(SECOND); advX();
-        issueW(FIRST); issueW(SECOND); advW();
-        if constexpr (NWQ == 3) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-
-    P256_STAMP(1);
-    const int li = lane & 15, g4 = lane >> 4;
-    f32x4 acc[FI][4];
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0); };
-
-    // the unit being computed; its bias slice (TNB floats, one 16-byte chunk per thread) is requested at its head and goes through LDS in the epilogue
-    int cu = 0, ck = 0, cnk = unit_field(0, 3);
-    auto bias_chunk = [&](int u) {
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int n = unit_field(u, 0) + 4 * tid;
-        if (EPI != EPI_PARTIAL && p.bias && unit_field(u, 4) != 1 && tid < TNB / 4 && n < p.N) v = *(const f32x4*)(p.bias + n);
-        return v;
-    };
-    f32x4 bias4 = bias_chunk(0);
-    float amax = 0.f;
-
-    // Fragment offsets from an opaque copy of the lane number (see the loop): used by the prologue read here
-    auto frag_offsets = [&](int lo, int (&woff)[2], int (&xoff)[2]) {
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-            const int l15 = lo & 15, ch = ((4 * sh + (lo >> 4)) ^ (l15 & 7)) << 4;
-            woff[sh] = (16 * FI * wn + l15) * 128 + ch;
-            xoff[sh] = C::WREG + (64 * wm + l15) * 128 + ch;
-        }
-    };
-    // K-tile schedule (round 4, second form).  Every MFMA phase finds its fragments in registers, read ONE PHASE EARLIER — the first form read them at the head
-    // of the phase that used them and its K-tile was the SUM of the LDS round trips (0.82 us of reads + barriers) and the MFMAs (0.64 us), tools/gemm_stamps.py:
-    //   phase 1: MFMA W[0:h] x X[0:2]   | read X[2:4] and the first half of W[h:2h] of this K-tile
-    //   phase 2: MFMA W[0:h] x X[2:4]   | read the rest of W[h:2h]
-    //   -- lgkmcnt(0), barrier (b): every wave has read this parity -> it is free --
-    //   phase 3: MFMA W[h:2h] x X[2:4]  | issue X(g + 2) into this parity
-    //   -- vmcnt(4): everything older than X(g + 2) has landed = K-tile g + 1 complete; barrier (a) --
-    //   phase 4: MFMA W[h:2h] x X[0:2]  | read W[0:h], X[0:2] of K-tile g + 1 (other parity) for the next phase 1; issue W(g + 2) into this parity
-    // Fill order per K-tile is X then W, so the four youngest operations at (a) are exactly X(g + 2); K-tile g + 1 was issued during phases 3 / 4 of K-tile
-    // g - 1: one whole K-tile of latency budget for every piece (the first form gave W half of that).
-    // Two named fragment sets (A, B) alternate between consecutive K-tiles — no register copies, no conditional reads (the last K-tile of a block reads
-    // its "next" fragments from whatever the other parity holds and nobody uses them) — so the K loop advances by PAIRS of K-tiles: every unit has an even
-    // number of K-tiles (host-checked: K / 64 even, the split point is even).
-    f16x8 wA[2][FIH], xA[2][2], wB[2][FIH], xB[2][2];
-    {
-        int lo = lane;
-        asm volatile("" : "+v"(lo));
-        int woff[2], xoff[2];
-        frag_offsets(lo, woff, xoff);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-#pragma unroll
-            for (int i = 0; i < FIH; ++i) wA[sh][i] = *(const f16x8*)(smem + woff[sh] + i * 16 * 128);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) xA[sh][j] = *(const f16x8*)(smem + xoff[sh] + j * 16 * 128);
-        }
-    }
-    const bool late = w >= 4;
-    auto ktile = [&](int g, const f16x8 (&wa)[2][FIH], const f16x8 (&xa)[2][2], f16x8 (&wnx)[2][FIH], f16x8 (&xnx)[2][2]) {
-        const char* bb = smem + (g & 1) * C::PAR;
-        const char* bn = smem + ((g + 1) & 1) * C::PAR;
-        const bool n2 = g + 2 < S && !GTAV_DBG(p, 1);   // (experiments build, debug bit 0: no refills — timing only)
-        f16x8 wb[2][FIH], xb[2][2];
-        // The per-lane fragment offsets are RECOMPUTED every K-tile from the lane number (a dozen VALU operations beside 48-64 MFMAs): kept in registers across
-        // the loop they were spilled around the epilogue and reloaded in front of the loop's back edge — and hipcc's wait-count pass, which does not see the
-        // inline-asm fills, then put an `s_waitcnt vmcnt(0)` at the head of EVERY K-tile (the fills in flight drained each step).  The empty asm makes the lane
-        // number opaque so that the computation is not hoisted out of the loop again.
-        int lo = lane;
-        asm volatile("" : "+v"(lo));
-        int woff[2], xoff[2];
-        frag_offsets(lo, woff, xoff);
-        // Third form: NOTHING is issued in a clump.  The second form put a phase's fragment reads (up to 10 per wave) and its fills (3-4 per wave) in front of
-        // its MFMAs: eight waves then queue at the LDS (4 cycles per read) and at the address pipe (16 cycles per 1 KiB piece) at the same moment and none of
-        // them feeds the matrix pipe meanwhile.  Here every MFMA of a phase carries at most one read in its issue shadow, and a wave's pieces are spread
-        // over the phase, one per three or four MFMAs (waves 0-3 in front of the group, their SIMD partners 4-7 behind it).
-        auto mm1 = [&](const f16x8 (&wf)[2][FIH], const f16x8 (&xf)[2][2], int m, int io, int jo) {   // the m-th of a phase's 4 FIH MFMAs
-            const int sh = m / (2 * FIH), i = (m >> 1) % FIH, j = m & 1;
-            mma(wf[sh][i], xf[sh][j], acc[io + i][jo + j]);
-        };
-        constexpr int NM = 4 * FIH;
-        // ---- phase 1 ----
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            mm1(wa, xa, m, 0, 0);
-            if (m < 4) xb[m >> 1][m & 1] = *(const f16x8*)(bb + xoff[m >> 1] + (2 + (m & 1)) * 16 * 128);
-            else if (m < 4 + FIH) wb[0][m - 4] = *(const f16x8*)(bb + woff[0] + (FIH + m - 4) * 16 * 128);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- phase 2 ----
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            mm1(wa, xb, m, 0, 2);
-            if (m < FIH) wb[1][m] = *(const f16x8*)(bb + woff[1] + (FIH + m) * 16 * 128);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (b): every wave has read this parity's fragments
-        // ---- phase 3: the four X pieces of K-tile g + 2 go into this parity ----
-        {
-            const unsigned d = smem0 + (unsigned)(xi & 1) * C::PAR + C::WREG + (unsigned)w * 1024u;
-            const unsigned go = (unsigned)xk * (unsigned)TILE_BYTES;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                constexpr int PER = NM / 4;
-                if (m % PER == 0 && n2 && !late) glds16_s(p.X, voff + (xso[m / PER] + go), d + (m / PER) * 8192);
-                mm1(wb, xb, m, FIH, 2);
-                if (m % PER == PER - 1 && n2 && late) glds16_s(p.X, voff + (xso[m / PER] + go), d + (m / PER) * 8192);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (n2) advX();
-        }
-        if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a): everything but X(g + 2) has landed = K-tile g + 1 complete
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- phase 4: next K-tile's first fragments from the other parity; the W pieces of K-tile g + 2 into this one ----
-        {
-            const unsigned d = smem0 + (unsigned)(wi & 1) * C::PAR + (unsigned)w * 1024u;
-            const unsigned go = (unsigned)wk * (unsigned)TILE_BYTES;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                constexpr int PER = NM / NWQ;
-                if (m % PER == 0 && m / PER < NWQ && n2 && !late) glds16_s(p.W, voff + (wso[m / PER] + go), d + (m / PER) * 8192);
-                mm1(wb, xa, m, FIH, 0);
-                if (m < 2 * (FIH + 2)) {   // in the order phase 1 consumes them: the first K half's X and W fragments, then the second half's
-                    const int sh = m / (FIH + 2), q = m % (FIH + 2);
-                    if (q < 2) xnx[sh][q] = *(const f16x8*)(bn + xoff[sh] + q * 16 * 128);
-                    else wnx[sh][q - 2] = *(const f16x8*)(bn + woff[sh] + (q - 2) * 16 * 128);
-                }
-                if (m % PER == PER - 1 && m / PER < NWQ && n2 && late) glds16_s(p.W, voff + (wso[m / PER] + go), d + (m / PER) * 8192);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (n2) advW();
-        }
-    };
-    for (int g = 0; g < S; g += 2) {
-        ktile(g, wA, xA, wB, xB);
-        ktile(g + 1, wB, xB, wA, xA);
-        ck += 2;
-        if (ck < cnk) continue;
-
-        if (cu == 0) P256_STAMP(2);
-        // ================= the unit is complete: epilogue straight from the accumulators =================
-        const int kind = unit_field(cu, 4), slot = unit_field(cu, 5);
-        const size_t slot_off = (size_t)slot * (TNB * 256);
-        if (kind == 1) {
-            // K tail of a split tile: partial sums out in register layout (1 KiB per wave-instruction), then publish
-            float* dst = p.sk_ws + slot_off + (size_t)(w * FI * 4) * 256 + lane * 4;
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *(f32x4*)(dst + (i * 4 + j) * 256) = acc[i][j];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(p.sk_flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            if (kind == 2) {
-                if (tid == 0) {
-                    int spins = 0;
-                    while (__hip_atomic_load(p.sk_flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (spins >= (1 << 22) && p.err_flag) atomicOr(p.err_flag, ERR_NONFINITE);   // (never seen: every block is resident and the helper runs its piece first)
-                }
-                __builtin_amdgcn_s_barrier();
-                const float* src = p.sk_ws + slot_off + (size_t)(w * FI * 4) * 256 + lane * 4;
-#pragma unroll
-                for (int i = 0; i < FI; ++i) {
-                    f32x4 t[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) t[j] = *(const f32x4*)(src + (i * 4 + j) * 256);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = acc[i][j] + t[j];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_s_barrier();       // every wave has its partial sums in registers: the slot may be reused by the next launch
-                if (tid == 0) __hip_atomic_store(p.sk_flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            float* bl = (float*)(smem + C::BIAS_OFF);
-            if constexpr (EPI != EPI_PARTIAL) {
-                if (tid < TNB / 4) *(f32x4*)(bl + 4 * tid) = bias4;
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-            const int n0 = unit_field(cu, 0), m0 = unit_field(cu, 1);
-#pragma unroll
-            for (int i = 0; i < FI; ++i) {
-                const int nl = 16 * FI * wn + 16 * i + 4 * g4, n = n0 + nl;
-                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (EPI != EPI_PARTIAL) bv = *(const f32x4*)(bl + nl);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = m0 + 64 * wm + 16 * j + li;
-                    const bool ok = n < p.N && m < p.M;
-                    const f32x4 v = acc[i][j] + bv;
-                    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_F32) {
-                        if (ok) *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = v;
-                    } else {
-                        const float xin[4] = {v[0], v[1], v[2], v[3]};
-                        float yo[4];
-                        if constexpr (EPI == EPI_GELU_TANH) gelu_tanh_f4(xin, yo);
-                        else { yo[0] = xin[0]; yo[1] = xin[1]; yo[2] = xin[2]; yo[3] = xin[3]; }
-                        const uint2 mine = pack4(amax, yo[0], yo[1], yo[2], yo[3]);
-                        // lanes (li, g) and (li, g ^ 1) hold adjacent 4-feature groups of one token: one 16-byte store per pair
-                        const unsigned o0 = __shfl_xor(mine.x, 16, 64), o1 = __shfl_xor(mine.y, 16, 64);
-                        if (ok && !(lane & 16)) *(uint4*)((f16*)p.out + tiled_off(m, n, p.ldo)) = uint4{mine.x, mine.y, o0, o1};
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one feature group (four token groups) per scheduling region: every accumulator is live here
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < FI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        ck = 0;
-#ifdef GTAV_EXPERIMENTS
-        if (cu == 0 && p.stamps && tid == 0) {
-            p.stamps[(size_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memtime();
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            p.stamps[(size_t)blockIdx.x * 8 + 6] = xcc & 0xF;
-        }
-#endif
-        if (++cu < nunits) {
-            cnk = unit_field(cu, 3);
-            bias4 = bias_chunk(cu);
-            // the next unit's first fragments are read (again) HERE, not carried through the epilogue from phase 4 of the K-tile before it: 40 registers
-            // that the epilogue needs (all accumulators are live there) for one exposed LDS round trip per unit
-            int lo = lane;
-            asm volatile("" : "+v"(lo));
-            int woff[2], xoff[2];
-            frag_offsets(lo, woff, xoff);
-            const char* bn = smem + (g & 1) * C::PAR;        // K-tile g + 2: landed and visible since barrier (a) of K-tile g + 1
-#pragma unroll
-            for (int sh = 0; sh < 2; ++sh) {
-#pragma unroll
-                for (int i = 0; i < FIH; ++i) wA[sh][i] = *(const f16x8*)(bn + woff[sh] + i * 16 * 128);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) xA[sh][j] = *(const f16x8*)(bn + xoff[sh] + j * 16 * 128);
-            }
-        }
-    }
-    P256_STAMP(7);
-#undef P256_STAMP
-    if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_F16_TILED) sat_report(amax, p.err_flag);
-}
-
+// (the persistent 256-token-tile kernel of round 4, shapes 40 / 41 — correct, race-screened, slower than shape 12 at every size tried — lives in gemm_experiments.inc)
 // (the persistent ping-pong kernel of round 2, shape 16 — measured slower than shape 12 — lives in gemm_experiments.inc: experiments build only)
 
 }  // namespace
@@ -3067,39 +2666,6 @@ static int launch_lp(const GemmParams& p, hipStream_t stream) {
     return 0;
 }
 
-// persistent 256-token-tile kernel (shapes 40 / 41): one block per CU; whole rounds of tiles + a two-way K split of a remainder of <= grid / 2 tiles
-template <int EPI, int FI>
-static int launch_p256(const GemmParams& p, hipStream_t stream) {
-    using C = P256<FI>;
-    static unsigned long long attr_devs = 0;
-    int dev = 0;
-    const int cus = device_cus(&dev);
-    GTAV_REQUIRE(cus > 0, "gemm: no current device");
-    if (!(attr_devs >> (dev & 63) & 1)) {
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_p256_kernel<EPI, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr_devs |= 1ull << (dev & 63);
-    }
-    GemmParams q = p;
-    GTAV_REQUIRE((size_t)round_up(p.M, 128) * p.K * 2 < (1ull << 32) && (size_t)round_up(p.N, 128) * p.K * 2 < (1ull << 32),
-                 "gemm: the persistent 256-token-tile kernel addresses its operands with 32-bit offsets (M=%d N=%d K=%d)", p.M, p.N, p.K);
-    const int T = cdiv(p.M, 256) * cdiv(p.N, C::TNB), nkt = p.K / TK;
-    GTAV_REQUIRE(nkt % 2 == 0, "gemm: the persistent 256-token-tile kernel walks K in pairs of K-tiles (K = %d is not a multiple of 128)", p.K);
-    GTAV_REQUIRE(cdiv(T, cus) + 1 <= P256_MAXU, "gemm: %d tiles are more than %d rounds of the persistent 256-token-tile kernel", T, P256_MAXU - 1);
-    const int full = T / cus, rem = T - full * cus;
-    int grid = T < cus ? T : cus;
-    q.sk_dp = T;
-    q.sk_r = 0;
-    if (rem > 0 && 2 * rem <= cus && rem <= GEMM_SK_MAX_SPLIT && q.sk_ws && q.sk_flags && nkt >= 4) {
-        q.sk_dp = T - rem;
-        q.sk_r = rem;
-        if (full == 0) grid = 2 * rem;
-    }
-    q.tm.gn = choose_gn(p.M, p.N, p.K, 256, C::TNB, 1);
-    GTAV_LAUNCH((gemm_p256_kernel<EPI, FI>), dim3(grid), dim3(512), C::LDS, stream, q);
-    GTAV_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 #ifdef GTAV_EXPERIMENTS
 #include "gemm_experiments.inc"   // laboratory: kernels, launchers and block shapes that measured slower than what the heuristic picks (tools/ only)
 #endif
@@ -3116,24 +2682,16 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if (shape == 24) return launch_l<EPI, 4, 2, 1, 2, 3, 2>(p, splitk, stream);   // 64 x 48, 6 compute + 2 loader waves (the skinny shape 11 on the loader-wave kernel)
     if (shape == 26) return launch_l<EPI, 4, 2, 2, 2, 3, 2>(p, splitk, stream);   // 64 x 96, 6 compute + 2 loader waves (shape 14 likewise)
 #ifdef GTAV_EXPERIMENTS
-    {   // shapes that exist only in the experiments build (8, 9, 16, 21, 23, 25, 27, 28, 30, 32, 33, 40, 42): gemm_experiments.inc
+    {   // shapes that exist only in the experiments build (8, 9, 16, 21, 23, 25, 27, 28, 30, 32, 33, 40, 41, 42): gemm_experiments.inc
         bool handled = false;
         const int rc_ = launch_experiment_shape<EPI>(p, ns, shape, splitk, stream, handled);
         if (handled) return rc_;
     }
 #else
     GTAV_REQUIRE(shape != 8 && shape != 9 && shape != 16 && shape != 21 && shape != 23 && shape != 25 && shape != 27 && shape != 28 && shape != 30 && shape != 32 &&
-                 shape != 33 && shape != 40 && shape != 42, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
+                 shape != 33 && shape != 40 && shape != 41 && shape != 42, "gemm: block shape %d exists only in the experiments build (csrc/build.sh exp)", shape);
 #endif
-    GTAV_REQUIRE(!p.out2 || (EPI == EPI_F16_TILED && shape != 31 && shape != 41), "gemm: a second output image (out2) exists for EPI_F16_TILED on the staged epilogue only (epilogue %d, block shape %d)", (int)EPI, shape);
-    if (shape == 41) {   // persistent 256-token tiles (round 4): 192 x 256 (N x M)
-        if constexpr (EPI == EPI_F32 || EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED) {
-            GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent 256-token-tile kernel splits K itself (one slab, N %% 8 == 0)");
-            return launch_p256<EPI, 6>(p, stream);   // (40, the 256 x 256 form, spills inside the K loop at the 256-register cap: experiments build)
-        } else {
-            GTAV_REQUIRE(false, "gemm: the persistent 256-token-tile kernel (shape %d) has no epilogue %d", shape, (int)EPI);
-        }
-    }
+    GTAV_REQUIRE(!p.out2 || (EPI == EPI_F16_TILED && shape != 31), "gemm: a second output image (out2) exists for EPI_F16_TILED on the staged epilogue only (epilogue %d, block shape %d)", (int)EPI, shape);
     if (shape == 31) {   // persistent loader-wave kernel: 128 x 192 tiles, 3-stage ring
         if constexpr (EPI == EPI_GELU_TANH || EPI == EPI_PARTIAL || EPI == EPI_F16_TILED || EPI == EPI_RESID) {
             GTAV_REQUIRE(splitk == 1 && p.N % 8 == 0, "gemm: the persistent loader-wave kernel runs the whole K in one slice (N %% 8 == 0)");
@@ -3443,10 +3001,15 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
         GTAV_REQUIRE(p.f_P >= span, "gemm/fold: frames of %d tokens are shorter than the token span (%d) of a wave of block shape %d", p.f_P, span, wm);
     }
     switch (epi_x) {
+#ifdef GTAV_EXPERIMENTS   // the LayerNorm fold (round 3: correct, measured slower at every size) is compiled into the experiments build only
         case EPI_RESID_FOLD: return launch_epi<EPI_RESID_FOLD>(p, ns, wm, splitk, stream);
         case EPI_QKV_FOLD: return launch_epi<EPI_QKV_FOLD>(p, ns, wm, splitk, stream);
         case EPI_GELU_TANH_FOLD: return launch_epi<EPI_GELU_TANH_FOLD>(p, ns, wm, splitk, stream);
         case EPI_F32_FOLD: return launch_epi<EPI_F32_FOLD>(p, ns, wm, splitk, stream);
+#else
+        case EPI_RESID_FOLD: case EPI_QKV_FOLD: case EPI_GELU_TANH_FOLD: case EPI_F32_FOLD:
+            GTAV_REQUIRE(false, "gemm: the LayerNorm-fold epilogues exist only in the experiments build (csrc/build.sh exp)");
+#endif
         case EPI_F32: return launch_epi<EPI_F32>(p, ns, wm, splitk, stream);
         case EPI_F16: return launch_epi<EPI_F16>(p, ns, wm, splitk, stream);
         case EPI_GELU_TANH: return launch_epi<EPI_GELU_TANH>(p, ns, wm, splitk, stream);

@@ -77,7 +77,6 @@ SIGNATURES = {
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_set_fused_temporal": [_p, _i],
     "gtav_dit_set_weight_prefetch": [_p, _i],
-    "gtav_dit_set_fold": [_p, _i, _i, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_comm_unique_id": [_p],
@@ -121,8 +120,6 @@ SIGNATURES = {
     "gtav_op_gemm_qkvt_attn": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
     "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _i, _p],
     "gtav_op_gemm_splitk_ln": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
-    "gtav_op_gemm_fold_producer": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p],
-    "gtav_op_gemm_fold_consumer": [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],
     "gtav_op_gemm_resid_inplace": [_i, _i, _i],
     "gtav_op_gemm_set_stages": [_i],
@@ -152,6 +149,12 @@ def load() -> C.CDLL:
 
 
 EXP_LIB_PATH = os.path.join(_HERE, "libgtav_amd_exp.so")
+# entry points of the experiments build only (csrc/experiments.h): the LayerNorm fold
+EXP_SIGNATURES = {
+    "gtav_dit_set_fold": [_p, _i, _i, _i],
+    "gtav_op_gemm_fold_producer": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p, _p, _p],
+    "gtav_op_gemm_fold_consumer": [_p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
+}
 
 
 def load_experiments(build_if_missing: bool = True) -> C.CDLL:
@@ -170,6 +173,10 @@ def load_experiments(build_if_missing: bool = True) -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    for name, argtypes in EXP_SIGNATURES.items():     # csrc/experiments.h
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
     lib.gtav_op_gemm_set_debug.argtypes = [_i]
     lib.gtav_op_gemm_set_debug.restype = None
     lib.gtav_op_gemm_set_stamps.argtypes = [_p, _i]

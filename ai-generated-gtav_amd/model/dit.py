@@ -489,8 +489,11 @@ class DiT(_HipModule):
             _lib.check(_lib.load().gtav_dit_set_weight_prefetch(self._handle, int(self._weight_prefetch)))
 
     def set_fold(self, mode: int, min_tokens_a: int = -1, min_tokens_b: int = -1):
-        """LayerNorm fold (gtav_dit_set_fold): 0 = separate LayerNorm launches everywhere, 1 = folded into the GEMM epilogues where that is
-        measured faster (default), 2 = every seam at every size.  min_tokens_* < 0 keep the thresholds of mode 1."""
+        """EXPERIMENTS BUILD ONLY (gtav_amd.lib.load_experiments(), tools/fold_bench.py): the LayerNorm fold of round 3 (gtav_dit_set_fold, csrc/experiments.h) —
+        0 = separate LayerNorm launches everywhere, 1 = folded into the GEMM epilogues from min_tokens_* tokens on, 2 = every seam at every size.
+        Correct, and measured slower than the LayerNorm launches at every size: the product library does not carry it."""
+        if not getattr(_lib.load(), "_gtav_experiments", False):
+            raise _lib.GtavError("set_fold: the LayerNorm fold exists only in the experiments build (gtav_amd.lib.load_experiments())")
         self._fold = (int(mode), int(min_tokens_a), int(min_tokens_b))
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fold(self._handle, *self._fold))

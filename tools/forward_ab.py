@@ -24,7 +24,7 @@ def main():
                     "3 = seam A only, 4 = seam B only); the PRODUCT library unless --exp")
     ap.add_argument("--exp", action="store_true")
     a = ap.parse_args()
-    lib = L.load_experiments() if (a.exp or not a.fold_ab) else L.load()
+    lib = L.load_experiments()   # (the LayerNorm fold and the A/B knobs exist in the experiments build only)
     import gtav_amd.weights as W
     from gtav_amd.model.dit import DiT_models
     dev = torch.device("cuda", 0)
