@@ -285,7 +285,7 @@ struct gtav_dit {
     bool fuse_tattn = false;
     bool w_prefetch = true;   // L2 prefetch of the next GEMM's weight at small M (gemm.h pf_next)
     int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
-    // ---- LayerNorm fold (gemm.h EPI_*_FOLD): the LayerNorm + modulate between a residual GEMM and its consumer runs inside the
+    // ---- LayerNorm fold (docs/LABNOTES.md 4.7; gemm.h EPI_*_FOLD): the LayerNorm + modulate between a residual GEMM and its consumer runs inside the
     // two GEMM epilogues.  Seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection.  Per-frame c1 / c2 tables for every
     // consumer: ctab [max_rows][CTW] (built next to the modulation table, one grouped GEMM), ctab_cur [maxB * maxT][CTW] = the rows of the
     // current sampler step (gathered with mod_cur).  Groups are ordered fc1 seams, to_qkv seams, final: a launch over the first n covers a prefix.
@@ -295,7 +295,7 @@ struct gtav_dit {
         int mode = 1;                 // 0 = never, 1 = heuristic (min_m_a / min_m_b), 2 = every seam at every M (tests)
         // Measured (profiles/round3/fold_v*_ab_B{1,8}.txt, one process per A/B): the folded path is CORRECT (tests/test_gpu_fold.py) but not
         // faster on MI355X at any size tried — B = 8 forward 8.11 ms unfolded, 8.36 ms with seam A folded, 9.03 ms with both; B = 1 2.33 /
-        // 2.47 ms — so the default thresholds never fold; gtav_dit_set_fold(h, 1, a, b) / (h, 2, ..) select it (DESIGN.md 4.7 has the why:
+        // 2.47 ms — so the default thresholds never fold; gtav_dit_set_fold(h, 1, a, b) / (h, 2, ..) select it (docs/LABNOTES.md 4.7 has the why:
         // the LayerNorm's bytes move into GEMM tails that every resident block reaches at the same time).
         int min_m_a = 1 << 30, min_m_b = 1 << 30;
         int CTW = 0, n_groups = 0, n_groups_a = 0, Rp = 0;
@@ -501,7 +501,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
         set_pf(q, Wn, Nn, Kn, 1);
         q.splitk = gemm_choose_splitk(M, D, K);
-        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || (!h->tr.on && gemm_resid_inplace_ok(M, D, K, P))) {
+        if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || gemm_resid_inplace_ok(M, D, K, P)) {   // (also on training handles: this plain forward keeps no activations)
             // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
             // read-modify-write hides under the other wave group's main loop, and without split-K slabs the next LayerNorm only
             // reads resid.  (With the one-shot kernels the same epilogue was a loss: B = 8 out-proj 0.77 -> 1.26 ms per forward;

@@ -80,7 +80,7 @@ __host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
            (size_t)(((((k >> 3) & 7) ^ (r & 7)) << 3) + (k & 7));
 }
 
-// ---- L2 prefetch of a weight the NEXT launch will stream ---------------------------------------------
+// ---- L2 prefetch of a weight the NEXT launch will stream (docs/LABNOTES.md 4.10) ---------------------------------------------
 // A batch-1 step streams all 1.2 GB of weights from HBM, so every GEMM launch starts on a cold W.  The launch in front of it (whose own memory
 // traffic is small) touches ONE dword per 128-byte line of the slice of W that the blocks of each XCD will stream: blocks with equal
 // blockIdx % 8 share an XCD and its L2 (tools/xcd_start.hip), clean lines survive a kernel boundary (tools/l2_persist.hip: 0.56 us per 32 KiB

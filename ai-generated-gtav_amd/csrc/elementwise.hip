@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void ln_row_block_kernel(float* __restrict__ x
     float* xr = x + (size_t)m * ldx;
     const bool act = c < D;
     const bool nt = PEND && (pd.flags & 4);   // the row and the slabs are read ONCE: non-temporal loads keep them from pushing the next GEMM's prefetched
-                                              // weight slice out of the 4 MiB L2
+                                              // weight slice (docs/LABNOTES.md 4.10) out of the 4 MiB L2
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f}, av = v, bv = v;
     if (act) v = nt ? __builtin_nontemporal_load((const f32x4*)(xr + c)) : *(const f32x4*)(xr + c);
     f32x4 sl[8];

@@ -17,7 +17,7 @@ enum GemmEpi : int {
                         // reduces the slabs and applies bias + gate + residual (ops.h: LnPending)
     EPI_F16_TILED = 7,  // out_f16 = acc + bias, TILE-MAJOR like the GELU epilogues (no activation): training keeps the MLP's
                         // pre-activation, and the backward pass's activation gradients are GEMM operands themselves
-    // ---- LayerNorm fold: the LayerNorm + adaLN modulate between a residual GEMM and the GEMM that consumes its
+    // ---- LayerNorm fold (docs/LABNOTES.md 4.7): the LayerNorm + adaLN modulate between a residual GEMM and the GEMM that consumes its
     // output is split over the two epilogues instead of being a launch of its own (model/dit.py:19-27,200-225) ----
     EPI_RESID_FOLD = 8,      // producer (out-proj, fc2; full K): x = resid[m][n] += gate (acc + bias) in place, AND the next GEMM's operand
                              // A[m][n] = fp16(x (1 + scale_next + 1e-6)) tile-major, AND per-row partial sums (sum x, sum x^2) per 64-feature slot
@@ -86,9 +86,9 @@ struct GemmParams {
     float* f_stats_out;     // [M][N / 64][2]
     const float* f_scale;   // scale vectors of the NEXT LayerNorm: row r at f_scale + r * gate_stride
     f16* f_a;               // tile-major [round_up(M, 128)][N]
-    // ---- L2 prefetch of the NEXT GEMM's weight by the compute waves of the loader-wave kernels at small M (common.h PrefetchDesc) ----
+    // ---- L2 prefetch of the NEXT GEMM's weight by the compute waves of the loader-wave kernels at small M (common.h PrefetchDesc; docs/LABNOTES.md 4.10) ----
     PrefetchDesc pf;
-    // ---- persistent 256-token-tile kernel (gemm_p256_kernel, shape 40).  sk_ws / sk_flags: the caller's split workspace — fp32 partial
+    // ---- persistent 256-token-tile kernel (gemm_p256_kernel, shape 40; docs/LABNOTES.md 4.11).  sk_ws / sk_flags: the caller's split workspace — fp32 partial
     // tiles (GEMM_SK_MAX_SPLIT tiles of 256 x 256 floats) and one int per split tile, ZERO between launches (the kernel resets what it sets); null = whole
     // tiles only.  sk_dp / sk_r are filled by the launcher: tiles [0, sk_dp) run whole (tile t on block t % grid), each of the sk_r remainder tiles is split
     // in two K halves — block 2 i + 1 runs the K tail FIRST in its sequence and hands its partial sums over, block 2 i runs the K head LAST and owns the epilogue ----

@@ -689,7 +689,7 @@ __device__ __forceinline__ void tile_map_fast(const GemmParams& p, int& n0, int&
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LayerNorm fold, consumer side (EPI_*_FOLD).  The X operand is A[m][k] = x[m][k] (1 + scale[f][k]) of the residual row x
+// LayerNorm fold, consumer side (EPI_*_FOLD; docs/LABNOTES.md 4.7).  The X operand is A[m][k] = x[m][k] (1 + scale[f][k]) of the residual row x
 // the LayerNorm would have normalised (f = frame of token m), so with mean / rstd of the row and the per-frame tables
 //   c1[f][n] = sum_k (1 + scale[f][k]) W[n][k],   c2[f][n] = sum_k shift[f][k] W[n][k] + bias[n]
 // the GEMM of the modulated LayerNorm output is   y[m][n] = (acc[m][n] - mean_m c1[f][n]) rstd_m + c2[f][n]   (model/dit.py:19-27).
@@ -2245,7 +2245,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent loader-wave GEMM for large M (shape 30, round 3).
 //
-// What the round-3 measurements say about the large-M launches: the 512 resident blocks of a launch are in the same phase, so
+// What the round-3 measurements say about the large-M launches (docs/LABNOTES.md 4.7 / 4.8): the 512 resident blocks of a launch are in the same phase, so
 // the prologue (first tiles from HBM: 2.2 us) and the epilogue (24 MB of stores in one burst: 5.7 us) of every tile are exposed — 31 % of a residency
 // round — and nothing of it can hide under the NEXT tile of the same block while the waves that store are the waves that wait for fills: vmcnt retires in
 // issue order, so a wave with stores in flight cannot see its younger fills land.  Here the roles are split for good:
@@ -2760,7 +2760,8 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
 // temporal K/V cache, out = the attention output (f16, tile-major, logical row length D).
 static int fill_tile_map(GemmParams::TileMap& tm, int M, int N, int K, int tmb, int tnb, int splitk);
 bool gemm_qkvt_attn_ok(int M, int D, int S, int Tq, int t0) {
-    return Tq == 5 && t0 == 0 && S % 16 == 0 && D % 64 == 0 && M % (Tq * S) == 0 && (M / 80) * (D / 64) <= 256;
+    static const int max_blocks = GTAV_ENV_INT("GTAV_QKVT_MAX_BLOCKS", 256);   // experiments build: A/B of the fused kernel on larger grids (batch 8: 1152 blocks)
+    return Tq == 5 && t0 == 0 && S % 16 == 0 && D % 64 == 0 && M % (Tq * S) == 0 && (M / 80) * (D / 64) <= max_blocks;
 }
 int launch_gemm_qkvt_attn(const GemmParams& p_in, hipStream_t stream) {
     GemmParams q = p_in;

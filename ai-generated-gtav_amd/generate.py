@@ -90,7 +90,7 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
 @torch.inference_mode()
 def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps: int = 24, rounds: int = 2, use_actions: bool = False,
                          latent_hw=None) -> dict:
-    """Times the captured full-window sampler step of batch B with the next-weight L2 prefetch on and off — the results are
+    """Times the captured full-window sampler step of batch B with the next-weight L2 prefetch (docs/LABNOTES.md 4.10) on and off — the results are
     bit-identical, only the speed differs, and the gain is box-dependent (-7 % on some MI355X boxes, nothing on others) — and leaves the model on
     the faster setting.  Alternates the two settings `rounds` times in this process (a fresh capture per switch), `steps` replays each; synthetic
     latents; about 0.2 s at batch 1.  Returns {"on_ms", "off_ms", "chosen"} (milliseconds per step, best round of each)."""

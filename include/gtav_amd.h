@@ -117,7 +117,7 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
  * synchronises the device; every call drops the captured graphs of the handle.  Ignored on handles with training enabled. */
 int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
 
-/* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (default ON for steps of 256 ... 1536 tokens).  It changes no
+/* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (docs/LABNOTES.md 4.10; default ON for steps of 256 ... 1536 tokens).  It changes no
  * arithmetic — results are bit-identical either way — and pays on some MI355X boxes (-7 % per batch-1 step) and not on others, so a harness may
  * time a few captured steps with each setting and keep the faster one (gtav_amd.generate.tune_weight_prefetch does; bench.py reports the choice).
  * Every call that changes the setting drops the captured graphs of the handle. */

@@ -2,7 +2,7 @@
 pinned to the reference by tests/golden) on identical seeded inputs and weights.
 
 Tolerance: the north-star bound is 1e-3 relative L2 per forward at full size (fp16 MFMA operands, fp32 accumulate /
-residual / LN / softmax, exact-fp32 conditioning path; DESIGN.md "Precision").  Small configs get 2e-3 headroom."""
+residual / LN / softmax, exact-fp32 conditioning path).  Small configs get 2e-3 headroom."""
 import os
 
 import pytest

@@ -1,4 +1,4 @@
-"""Does splitting a batch-B forward into S independent sub-batches on S HIP streams beat one launch chain?  
+"""Does splitting a batch-B forward into S independent sub-batches on S HIP streams beat one launch chain?  (docs/LABNOTES.md 4.8)
 
 At large M the 512 resident blocks of a GEMM run in lockstep: everybody streams operands, then everybody computes, then everybody
 stores — HBM idles during the main loops and the matrix pipes idle during the prologues / epilogues and the LayerNorm launches.

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""CPU emulation of the LayerNorm fold on the full-size DiT: which fp16 operand policy keeps the forward
+"""CPU emulation of the LayerNorm fold (docs/LABNOTES.md 4.7) on the full-size DiT: which fp16 operand policy keeps the forward
 within 1e-3 relative L2 of the fp32 oracle?
 
   base   : today's kernels — xn = fp16(LN(x) (1 + s) + sh) is the GEMM operand

@@ -1,4 +1,4 @@
-// Does an XCD's L2 keep clean lines across a kernel boundary?  (The next-weight prefetch of csrc/gemm.hip relies on it)
+// Does an XCD's L2 keep clean lines across a kernel boundary?  (The next-weight prefetch of csrc/gemm.hip relies on it; docs/LABNOTES.md 4.10.)
 // Launch A: the 32 blocks of XCD x (blockIdx % 8 == x) read slice x (1 MiB) of a buffer.  Launch B reads it again and times the read per block:
 //   same  = slice x again (L2 hits if the lines survived the boundary), cross = slice (x + 1) % 8 (another XCD's L2 has them: Infinity Cache at best),
 //   cold  = a slice of a second buffer nobody touched since a 512 MiB sweep (HBM).

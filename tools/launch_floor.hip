@@ -1,4 +1,4 @@
-// Measures what a dependent step costs on this GPU: (a) a captured hipGraph of N dependent kernels
+// Measures what a dependent step costs on this GPU (docs/LABNOTES.md 9): (a) a captured hipGraph of N dependent kernels
 // (256 blocks x 256 threads, each block stores one word) against (b) ONE persistent launch of 256 blocks that meets at N grid-wide
 // barriers (one device-scope counter per barrier: every block's thread 0 adds 1 and polls with sc1 loads until all 256 arrived) and
 // (c) the same barrier between TWO byte-moving phases (each block writes 4 KiB with write-through stores, the next phase reads another

@@ -1,6 +1,6 @@
 """A/B: ONE handle stepping a batch of B clips against TWO handles of B / 2 clips each on two HIP streams (same weights, same inputs).
 The kernels of a launch are bulk-synchronous — every block is in its prologue, its MFMA loop or its store burst at the same time — so memory
-phases and matrix phases of a step add up.  Two half-batches on two streams put different kernels on the chip at the same time.
+phases and matrix phases of a step add up (docs/LABNOTES.md 4.7).  Two half-batches on two streams put different kernels on the chip at the same time.
 Product library.  Usage (GPU box): python tools/two_stream_ab.py [--batch 8] [--cached] [--steps 30] [--rounds 3]"""
 import argparse
 import json
