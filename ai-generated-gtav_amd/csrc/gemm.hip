@@ -2363,7 +2363,11 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
         const int gfirst = RES ? m0 / p.rows_per_gate : 0;
         float* const garea = (float*)(smem + NS * STAGE_BYTES) + (ti & 1) * (LP_MAXF + 1) * TNB;
         if constexpr (RES) {
-            const int ct = 64 * w + lane;                                   // compute-thread index, 0 .. 511
+            // (the lane number is re-derived here and in the epilogue — v_mbcnt, opaque to CSE — instead of living across the K loop: at the 168-register
+            // budget of a 12-wave block hipcc spilled it to scratch and reloaded it once per tile behind a vmcnt(0))
+            int lane_s = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(lane_s));
+            const int ct = 64 * w + lane_s;                                 // compute-thread index, 0 .. 511
             if (ct < (LP_MAXF + 1) * (TNB / 4)) {
                 const int r = ct / (TNB / 4), cq = ct - r * (TNB / 4);     // staged row (frame slot, LP_MAXF = bias), 4-feature chunk
                 int n = n0 + 4 * cq;
@@ -2426,28 +2430,31 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
         }
         mmh(wb, xb);
         // ---- epilogue straight from the accumulators (no LDS, no barrier): the stores drain under the next tile's K loop ----
+        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // re-derived (see the staging above): li / g4 of the prologue die with the K loop's offsets
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 15, g4_e = lane_e >> 4;
         int gslot[RES ? FJ : 1];   // EPI_RESID: staged gate row (frame slot) of this lane's token in each of its FJ token groups
         if constexpr (RES) {
 #pragma unroll
             for (int j = 0; j < FJ; ++j) {
-                int mm = m0 + 16 * FJ * wm + 16 * j + li;
+                int mm = m0 + 16 * FJ * wm + 16 * j + li_e;
                 mm = mm < p.M ? mm : p.M - 1;
                 gslot[j] = mm / p.rows_per_gate - gfirst;
             }
 #pragma unroll
-            for (int i = 0; i < FI; ++i) pbias[i] = *(const f32x4*)(garea + LP_MAXF * TNB + 16 * FI * wn + 16 * i + 4 * g4);
+            for (int i = 0; i < FI; ++i) pbias[i] = *(const f32x4*)(garea + LP_MAXF * TNB + 16 * FI * wn + 16 * i + 4 * g4_e);
         }
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
-            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4;
+            const int n = n0 + 16 * FI * wn + 16 * i + 4 * g4_e;
 #pragma unroll
             for (int j = 0; j < FJ; ++j) {
-                const int m = m0 + 16 * FJ * wm + 16 * j + li;
+                const int m = m0 + 16 * FJ * wm + 16 * j + li_e;
                 const bool ok = n < p.N && m < p.M;
                 const f32x4 v = acc[i][j] + pbias[i];
                 if constexpr (RES) {
                     if (ok) {
-                        const f32x4 gq = *(const f32x4*)(garea + gslot[j] * TNB + 16 * FI * wn + 16 * i + 4 * g4);
+                        const f32x4 gq = *(const f32x4*)(garea + gslot[j] * TNB + 16 * FI * wn + 16 * i + 4 * g4_e);
                         const f32x4 r = xres[i][j] + gq * v;
                         float* dst = (float*)p.out + (size_t)m * p.ldo + n;
                         if (p.out_sc1) store16_sc1(dst, r);
@@ -2467,7 +2474,7 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
                     const uint2 mine = pack4(amax, yo[0], yo[1], yo[2], yo[3]);
                     // lanes (li, g) and (li, g ^ 1) hold adjacent 4-feature groups of one token: one 16-byte store per pair
                     const unsigned o0 = __shfl_xor(mine.x, 16, 64), o1 = __shfl_xor(mine.y, 16, 64);
-                    if (ok && !(lane & 16)) {
+                    if (ok && !(lane_e & 16)) {
                         f16* dst = (f16*)p.out + tiled_off(m, n, p.ldo);
                         if (p.out_sc1) store16_sc1(dst, u32x4{mine.x, mine.y, o0, o1});
                         else *(uint4*)dst = uint4{mine.x, mine.y, o0, o1};
@@ -2736,6 +2743,10 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
 #endif
         if constexpr (!FOLDISH) {
             set_gn(256, 256);
+            // A narrow output with far more activations than weights (the VAE's fc2 at M = 46 080: X 377 MB, W 8 MB): keep ALL n-tiles of an m-tile on one XCD,
+            // beyond choose_gn's 2 MiB cap — X then crosses the fabric once and W, which stays in the Infinity Cache, is what gets re-read: 1.94 GB -> less per
+            // launch by the PMC counters (profiles/traffic.json vae_fc2), 426 -> 408 us (profiles/round5/gemm_tile_group_width_large_M.txt)
+            if (!g_force_gn && splitk == 1 && p.N <= 1024 && (size_t)p.M >= 8 * (size_t)p.N) p.tm.gn = cdiv(p.N, 256);
             const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
             GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
         }

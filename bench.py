@@ -336,8 +336,11 @@ def bench_config4(args, world, rank, dev, dist, torch):
     dom = max(per_class, key=lambda k: per_class[k]["ms_per_forward"])
     (ms_d, n_d), fl_d, desc = gf[dom]
     ach = fl_d / (ms_d / n_d * 1e-3) / 1e12
+    # HBM bytes per launch of that class from the committed rocprofv3 --pmc passes (profiles/traffic.json: the DiT's classes at M = 11 520, the VAE's at M = 46 080)
+    traffic, mfma_busy, tsrc = traffic_for(dom if dom.startswith("vae") else dom.replace("dit_", ""), Mv if dom.startswith("vae") else Md)
     roofline = {"kernel": "%s, csrc/gemm.hip, M=%d, fp16 MFMA (the GEMM class with the largest time per VAE-inclusive forward)" % (desc, Mv if dom.startswith("vae") else Md),
-                "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "mfma_busy_pmc": mfma_busy, "traffic_source": tsrc,
                 "avg_launch_us": round(ms_d / n_d * 1e3, 2), "launches_timed": int(n_d), "flops_per_launch": fl_d,
                 "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
                 "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,

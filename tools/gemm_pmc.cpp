@@ -1,7 +1,9 @@
 // Torch-free driver for rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on the four GEMM classes of a DiT half-block, through the
 // C-ABI exactly as the model launches them: to_qkv (spatial layout + RoPE epilogue), out-proj and fc2 (split-K slabs, the model's K-slice
-// heuristic), fc1 (GELU epilogue); M = 720 (batch-1 window step), M = 1152 (batch-8 context-cached step) and M = 5760 (batch-8 window step); rotating weight
-// buffers.  Dispatch order is fixed — for M in {720, 1152, 5760}: qkv, out, fc1, fc2, `iters` launches each — and tools/gemm_traffic.py segments the counter rows by that order.
+// heuristic), fc1 (GELU epilogue); M = 720 (batch-1 window step), M = 1152 (batch-8 context-cached step), M = 5760 (batch-8 window step) and M = 11 520 (the training batch);
+// then the ViT-VAE's four at M = 46 080 (encode of the trainer's 80 frames: qkv with bias at S = 576, un-gated in-place projection / fc2, erf-GELU fc1); rotating weight
+// buffers.  Dispatch order is fixed — for M in {720, 1152, 5760, 11520}: qkv, out, fc1, fc2, then the VAE's qkv, proj, fc1, fc2, `iters` launches each — and
+// tools/gemm_traffic.py segments the counter rows by that order.
 //   hipcc -O2 tools/gemm_pmc.cpp -Iinclude -L ai-generated-gtav_amd -lgtav_amd -Wl,-rpath,'$ORIGIN/../ai-generated-gtav_amd' -o tools/gemm_pmc
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- ./tools/gemm_pmc 16
 #include <hip/hip_runtime.h>
@@ -15,7 +17,8 @@
 
 int main(int argc, char** argv) {
     const int D = 1024, H = 4096, copies = 8, iters = argc > 1 ? atoi(argv[1]) : 16;
-    const int Ms[3] = {720, 1152, 5760};
+    const int NM = 4;
+    const int Ms[NM] = {720, 1152, 5760, 11520};   // 11 520: the training batch's window (config4)
     std::vector<unsigned short> host((size_t)H * D);
     for (size_t i = 0; i < host.size(); ++i) host[i] = 0x2000 + (unsigned short)((i * 2654435761u) >> 20 & 0x3ff);  // small fp16 values
     std::vector<void*> w(copies);
@@ -32,7 +35,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < one.size(); ++i) one[i] = (i & 1) ? 0.f : 1.f;     // (cos, sin) = (1, 0): identity rotation
         CK(hipMemcpy(cs, one.data(), one.size() * 4, hipMemcpyHostToDevice));
     }
-    for (int mi = 0; mi < 3; ++mi) {
+    for (int mi = 0; mi < NM; ++mi) {
         const int M = Ms[mi], Mp = (M + 127) / 128 * 128;
         void *x, *xh, *q, *k, *v, *hb, *parts;
         CK(hipMalloc(&x, (size_t)Mp * D * 2));
@@ -60,6 +63,28 @@ int main(int argc, char** argv) {
                ip_out ? 0 : sk_out, ip_fc2 ? 0 : sk_fc2);
         CK(hipFree(gate));
         CK(hipFree(x)); CK(hipFree(xh)); CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(v)); CK(hipFree(hb)); CK(hipFree(parts));
+    }
+    {   // ---- the ViT-VAE encoder's GEMMs at the trainer's batch (80 frames x 576 tokens) ----
+        const int M = 46080, Mp = M;
+        void *x, *xh, *q, *k, *v, *hb;
+        float *res, *cs576;
+        CK(hipMalloc(&x, (size_t)Mp * D * 2)); CK(hipMalloc(&xh, (size_t)Mp * H * 2));
+        CK(hipMemset(x, 0x20, (size_t)Mp * D * 2)); CK(hipMemset(xh, 0, (size_t)Mp * H * 2));
+        CK(hipMalloc(&q, (size_t)Mp * D * 2)); CK(hipMalloc(&k, (size_t)Mp * D * 2)); CK(hipMalloc(&v, (size_t)Mp * D * 2));
+        CK(hipMalloc(&hb, (size_t)Mp * H * 2));
+        CK(hipMalloc((void**)&res, (size_t)Mp * D * 4)); CK(hipMemset(res, 0, (size_t)Mp * D * 4));
+        CK(hipMalloc((void**)&cs576, 576 * 64 * 4));
+        {
+            std::vector<float> one(576 * 64);
+            for (size_t i = 0; i < one.size(); ++i) one[i] = (i & 1) ? 0.f : 1.f;
+            CK(hipMemcpy(cs576, one.data(), one.size() * 4, hipMemcpyHostToDevice));
+        }
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_qkv(x, D, w[it % copies], bias, M, D, 0, q, k, v, 576, 0, 0, 0, cs576, nullptr));
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(x, D, w[it % copies], bias, res, D, M, D, D, 4, nullptr, 0, 0, nullptr));
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(x, D, w[it % copies], bias, hb, H, M, H, D, 3, nullptr, 0, 1, nullptr));
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_f16(xh, H, w[it % copies], bias, res, D, M, D, H, 4, nullptr, 0, 0, nullptr));
+        CK(hipDeviceSynchronize());
+        printf("VAE M=%d: %d launches each of qkv, proj (in place), fc1 (erf-GELU), fc2 (in place)\n", M, iters);
     }
     return 0;
 }

@@ -10,7 +10,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ITERS = 16
 CLASSES = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
-MS = (720, 1152, 5760)
+MS = (720, 1152, 5760, 11520)
+VAE_M = 46080
+VAE_CLASSES = [("vae_qkv", 3072, 1024), ("vae_proj", 1024, 1024), ("vae_fc1", 4096, 1024), ("vae_fc2", 1024, 4096)]
 
 
 def rows_by_dispatch(outdir, sub, counters):
@@ -28,7 +30,8 @@ def rows_by_dispatch(outdir, sub, counters):
 
 
 def segments(rows):
-    assert len(rows) == ITERS * len(CLASSES) * len(MS), f"expected {ITERS * len(CLASSES) * len(MS)} GEMM dispatches, found {len(rows)}"
+    nexp = ITERS * (len(CLASSES) * len(MS) + len(VAE_CLASSES))
+    assert len(rows) == nexp, f"expected {nexp} GEMM dispatches, found {len(rows)}"
     seg = {}
     i = 0
     for M in MS:
@@ -37,6 +40,11 @@ def segments(rows):
             i += ITERS
             assert len({r[1] for r in chunk}) == 1, f"{name} M={M}: mixed kernels in one segment"
             seg[(name, M)] = (sum(r[3] for r in chunk) / ITERS, chunk[0][1], chunk[0][2])
+    for name, N, K in VAE_CLASSES:
+        chunk = rows[i: i + ITERS]
+        i += ITERS
+        assert len({r[1] for r in chunk}) == 1, f"{name}: mixed kernels in one segment"
+        seg[(name, VAE_M)] = (sum(r[3] for r in chunk) / ITERS, chunk[0][1], chunk[0][2])
     return seg
 
 
@@ -52,17 +60,17 @@ def main():
                      "MI355X_MICROARCH.md HBM section); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of the "
                      "launch's shader-clock cycles in which a SIMD's matrix pipe was busy",
            "gemm_hip_sha16": sha}
-    for M in MS:
-        for name, N, K in CLASSES:
+    for M, name, N, K in [(M_, n_, N_, K_) for M_ in MS for (n_, N_, K_) in CLASSES] + [(VAE_M, n_, N_, K_) for (n_, N_, K_) in VAE_CLASSES]:
+        if True:
             f_kb, kern, grid = fetch[(name, M)]
             w_kb = write[(name, M)][0]
             cyc = gui[(name, M)][0] / 8.0
             splitk = 1
-            out_bytes = M * N * (2 if name in ("qkv", "fc1") else 4)
+            out_bytes = M * N * (2 if name in ("qkv", "fc1", "vae_qkv", "vae_fc1") else 4)
             res[f"{name}_M{M}"] = {"hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "fetch_size_kb": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
                                    "launches": ITERS, "kernel": kern, "grid_threads": grid,
                                    # (the in-place residual epilogue of the large-M out-proj / fc2 — EPI_RESID, gemm_lp_kernel<4, ..> — also READS its fp32 output tile)
-                                   "algorithmic_bytes": N * K * 2 + M * K * 2 + out_bytes * (2 if name in ("out", "fc2") and "gemm_lp_kernel<4" in kern else 1),
+                                   "algorithmic_bytes": N * K * 2 + M * K * 2 + out_bytes * (2 if (name in ("out", "fc2") and "gemm_lp_kernel<4" in kern) or name in ("vae_proj", "vae_fc2") else 1),
                                    "mfma_busy_cycles": round(mfma[(name, M)][0]), "sq_busy_cycles": round(sqb[(name, M)][0]),
                                    "shader_cycles": round(cyc), "mfma_busy": round(mfma[(name, M)][0] / (1024.0 * cyc), 4) if cyc > 0 else None}
     json.dump(res, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
