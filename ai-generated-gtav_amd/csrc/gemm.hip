@@ -2712,6 +2712,9 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     // step at batch 8, is 8 x 32 = 256 tiles for fc1 / 4-slice fc2 where the 128 x 128 grid has 288 (1.1 rounds)
     if (shape == 29) return launch_l<EPI, 4, 2, 3, 4, 3, 4>(p, splitk, stream);
     }
+    // (round 5: a 128 x 144 two-blocks-per-CU tile — shape 12 with three token groups, 6 waves — to turn to_qkv's 720 tiles at M = 5760 (2 rounds at 70 %) into
+    // 960 (94 %): correct, race-clean and 40 % SLOWER at every M from 2880 to 11 520 (66 against 47 us; six-wave blocks do not pair up on the SIMDs):
+    // profiles/round5/gemm_128x144_two_blocks_per_cu.txt; removed again)
     // (a 128 x 128 loader-wave tile — 8 compute waves of 32 x 64 — was 12 % faster than shape 3 back to back and equal in the training step's
     // weight-gradient GEMMs, which are bound by the fabric traffic of their 118 MB of operands: not kept)
     // (Round 2 also measured one-block-per-CU large tiles on mainloop_g's half-K-step pipeline — 256 x 192, 192 x 192 and
