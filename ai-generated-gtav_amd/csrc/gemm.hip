@@ -2714,7 +2714,7 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     }
     // (round 5: a 128 x 144 two-blocks-per-CU tile — shape 12 with three token groups, 6 waves — to turn to_qkv's 720 tiles at M = 5760 (2 rounds at 70 %) into
     // 960 (94 %): correct, race-clean and 40 % SLOWER at every M from 2880 to 11 520 (66 against 47 us; six-wave blocks do not pair up on the SIMDs):
-    // profiles/round5/gemm_128x144_two_blocks_per_cu.txt; removed again)
+    // profiles/round5/gemm_128x144_two_blocks_per_cu.txt; a 128 x 160 tile of 4 waves of 64 x 80 (864 tiles): 61.5 against 56-58 us on another box; both removed again)
     // (a 128 x 128 loader-wave tile — 8 compute waves of 32 x 64 — was 12 % faster than shape 3 back to back and equal in the training step's
     // weight-gradient GEMMs, which are bound by the fabric traffic of their 118 MB of operands: not kept)
     // (Round 2 also measured one-block-per-CU large tiles on mainloop_g's half-K-step pipeline — 256 x 192, 192 x 192 and
