@@ -128,6 +128,10 @@ __device__ __forceinline__ void kstep_sync_ring(int rem) {
 // s_memrealtime (100 MHz, one counter for the whole chip) orders the phases of different blocks; s_memtime (shader cycles) is
 // a per-XCD counter with unrelated offsets and only gives this block's own cycle count (-> its clock)
 #define GTAV_STAMP(var) do { if (p.stamps) var = __builtin_amdgcn_s_memrealtime(); } while (0)
+// one lane's stamp straight into its block's row of the stamp buffer (the loader-wave kernels' per-wave / per-K-step timeline: 8 slots per block, 64 with debug bit 5)
+#define GTAV_STAMP_ROW(p) ((p).stamps + (size_t)blockIdx.x * (((p).debug & 32) ? 64 : 8))
+#define GTAV_STAMP_SLOT(cond, slot) do { if ((cond) && p.stamps) GTAV_STAMP_ROW(p)[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GTAV_STAMP_SLOT_HI(cond, slot) do { if ((cond) && p.stamps) GTAV_STAMP_ROW(p)[slot] |= (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFFFull) << 8; } while (0)
 struct BlockStamps {
     unsigned long long t[4] = {0, 0, 0, 0}, c0 = 0;
     unsigned pf_sink = 0;   // destination register of l2_prefetch_next's loads: stays allocated until end()
@@ -150,6 +154,8 @@ struct BlockStamps {
 };
 #else
 #define GTAV_STAMP(var) do { } while (0)
+#define GTAV_STAMP_SLOT(cond, slot) do { } while (0)
+#define GTAV_STAMP_SLOT_HI(cond, slot) do { } while (0)
 struct BlockStamps {
     unsigned long long t[4];
     unsigned pf_sink = 0;   // destination register of l2_prefetch_next's loads: stays allocated until end()
@@ -1899,21 +1905,14 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
             for (int i = 0; i < G; ++i) glds16_s(sb[i] + go, voff, ldso[i] + so);
         };
         const int npro = nkt < NS - 1 ? nkt : NS - 1;
-#ifdef GTAV_EXPERIMENTS
-        if (p.stamps && lw == 0 && lane == 0) p.stamps[(size_t)blockIdx.x * ((p.debug & 32) ? 64 : 8) + 7] = __builtin_amdgcn_s_memrealtime();   // first loader: first fill issued now
-#endif
+        GTAV_STAMP_SLOT(lw == 0 && lane == 0, 7);   // first loader: first fill issued now
         for (int t = 0; t < npro; ++t) stage(t);
         for (int t = 0; t < nkt; ++t) {
             wait_vm_ring<NS, G>(nkt - 1 - t);                // this wave's share of tile t has landed
-#ifdef GTAV_EXPERIMENTS
-            if (t == 0 && p.stamps && lw == 0 && lane == 0) p.stamps[(size_t)blockIdx.x * ((p.debug & 32) ? 64 : 8) + 6] |= (__builtin_amdgcn_s_memrealtime() & 0xFFFFFFFFFFFFull) << 8;   // its tile-0 share landed
-#endif
+            GTAV_STAMP_SLOT_HI(t == 0 && lw == 0 && lane == 0, 6);   // its tile-0 share landed
             wg_barrier();
             if (t == 0) GTAV_STAMP(bs.t[1]);
-#ifdef GTAV_EXPERIMENTS
-            // detailed mode (debug bit 5; the tool then gives every block 64 slots): slot 8 + t = loader 0 past barrier t
-            if ((p.debug & 32) && p.stamps && lw == 0 && lane == 0 && t < 24) p.stamps[(size_t)blockIdx.x * 64 + 8 + t] = __builtin_amdgcn_s_memrealtime();
-#endif
+            GTAV_STAMP_SLOT(GTAV_DBG(p, 32) && lw == 0 && lane == 0 && t < 24, 8 + t);   // detailed mode (debug bit 5: 64 slots per block): loader 0 past barrier t
             if (t + NS - 1 < nkt && !GTAV_DBG(p, 1)) stage(t + NS - 1);
         }
         return;
@@ -2001,9 +2000,7 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
     } else {
         f16x8 wA[2][FI], xA[2][FJ], wB[2][FI], xB[2][FJ];
         auto step = [&](int t, f16x8 (&wr)[2][FI], f16x8 (&xr)[2][FJ], const f16x8 (&wm_)[2][FI], const f16x8 (&xm_)[2][FJ]) {
-#ifdef GTAV_EXPERIMENTS
-            if ((p.debug & 32) && p.stamps && w == 0 && lane == 0 && t < 24) p.stamps[(size_t)blockIdx.x * 64 + 32 + t] = __builtin_amdgcn_s_memrealtime();   // compute wave 0 arrives at barrier t
-#endif
+            GTAV_STAMP_SLOT(GTAV_DBG(p, 32) && w == 0 && lane == 0 && t < 24, 32 + t);   // compute wave 0 arrives at barrier t
             wait_lgkm0();
             wg_barrier();
             if (t == 0) GTAV_STAMP(bs.t[1]);
