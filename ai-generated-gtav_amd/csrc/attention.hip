@@ -1,14 +1,12 @@
 // Attention kernels for gfx950.
 //
-// attn_spatial: non-causal attention over S tokens (S = 144 DiT frame tokens, 576 VAE tokens) per
-// (frame, head), head_dim 64.  One block per (frame, head, q-split): K [S][64] and Vt [64][S] of the
-// head are staged once in LDS (K rows XOR-swizzled for conflict-free ds_read_b128, Vt rows padded so
-// ds_read_b64 is conflict-free), every wave then walks 16-query tiles:
-//     S^T = K . Q^T          (v_mfma_f32_16x16x32_f16; keys on accumulator ROWS, queries on lanes)
-//     online softmax         (row max/sum = in-lane over 4..16 values + two xor-shuffles)
-//     O^T += Vt . P^T        (P^T is taken straight from the S^T accumulators: the k-slot -> key map
-//                             key = 32 s + 16 (j >> 2) + 4 g + (j & 3) is applied to the Vt read instead)
-// so P never moves between lanes or through LDS.
+// attn_spatial: non-causal attention over S tokens per (frame, head), head_dim 64, on v_mfma_f32_16x16x32_f16:
+//     S^T = K . Q^T          (keys on accumulator ROWS, queries on lanes)
+//     softmax                (row max / sum = in-lane + two cross-lane steps)
+//     O^T += Vt . P^T        (P^T is taken straight from the S^T accumulators: the k-slot -> key map is applied to the Vt read instead,
+//                             so P never moves between lanes or through LDS)
+//   attn_spatial_1p_kernel   S <= 160 (the DiT's 144 frame tokens): K / Vt of the head resident in LDS, one pass per query tile
+//   attn_flash_kernel        longer sequences (the VAE's 576 tokens): K / Vt streamed through an LDS ring, flash form (round 5)
 //
 // attn_temporal: causal attention over the <= 8 frames of the sliding window per (b, position, head);
 // 25 dot products of length 64 per head: VALU + 16-lane xor-shuffle reductions, everything in registers.
@@ -22,189 +20,12 @@ namespace {
 
 constexpr float kScaleLog2e = kAttnQScale;  // 1/sqrt(64) * log2(e)
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void attn_spatial_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
-                                                           const f16* __restrict__ Vt, f16* __restrict__ O, int heads, int S,
-                                                           int S_pad, int qsplit, int sc1) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                              // [S_pad][128 B], 16-B chunk c of row r stored at c ^ (r & 7)
-    const int vstride = (S_pad + 8) * 2;          // bytes per Vt row
-    char* Vs = smem + (size_t)S_pad * 128;        // [64][S_pad + 8] halves
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int li = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.x;                    // nb * heads + head
-    const int nb = bh / heads, head = bh - nb * heads;
-    const f16* Kg = K + (size_t)bh * S * 64;
-    const f16* Vg = Vt + (size_t)bh * 64 * S;
-    const f16* Qg = Q + (size_t)bh * S * 64;
-
-    // the wave's first query tile is fetched together with K / Vt (one memory round trip instead of two)
-    const int nqt = (S + 15) >> 4;
-    constexpr int NT = 64 * NW;
-    const int qt_first = blockIdx.y * NW + w;
-    f16x8 qpre[2] = {};
-    if (qt_first < nqt) {
-        int qr = qt_first * 16 + li;
-        qr = qr < S ? qr : S - 1;
-        qpre[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
-        qpre[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
-    }
-
-    // ---- stage K (swizzled) and Vt (padded), zero the padding.  K and Vt loads of a batch (6 + 6 per thread) are all issued
-    // before the first LDS write, so a block pays ONE memory round trip for S = 144 (K then Vt cost two) ----
-    {
-        const int nk = S_pad * 8;
-        const int vchunks = (S_pad + 8) / 8;  // 16-B chunks per padded Vt row
-        const int nv = 64 * vchunks;
-        const int nmax = nk > nv ? nk : nv;
-        for (int base = tid; base < nmax; base += NT * 6) {
-            uint4 kv[6], vv[6];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * NT;
-                kv[u] = make_uint4(0, 0, 0, 0);
-                if (idx < nk && (idx >> 3) < S) kv[u] = *(const uint4*)(Kg + (size_t)(idx >> 3) * 64 + (idx & 7) * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * NT;
-                vv[u] = make_uint4(0, 0, 0, 0);
-                if (idx < nv) {
-                    const int d = idx / vchunks, c = idx - d * vchunks;
-                    if (c * 8 < S) vv[u] = *(const uint4*)(Vg + (size_t)d * S + c * 8);  // S % 8 == 0
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * NT;
-                if (idx < nk) {
-                    const int r = idx >> 3, c = idx & 7;
-                    *(uint4*)(Ks + r * 128 + ((c ^ (r & 7)) << 4)) = kv[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int idx = base + u * NT;
-                if (idx < nv) {
-                    const int d = idx / vchunks, c = idx - d * vchunks;
-                    *(uint4*)(Vs + d * vstride + c * 16) = vv[u];
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    const int nkb = (S_pad + 63) >> 6;
-    const int Dm = heads * 64;
-    for (int qt = qt_first; qt < nqt; qt += NW * qsplit) {
-        const int q0 = qt * 16;
-        f16x8 qf[2];
-        if (qt == qt_first) {
-            qf[0] = qpre[0];
-            qf[1] = qpre[1];
-        } else {
-            int qr = q0 + li;
-            qr = qr < S ? qr : S - 1;
-            qf[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
-            qf[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
-        }
-
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float mrun = -INFINITY, lrun = 0.f;
-
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int key0 = kb * 64;
-            const int nkt = (S_pad - key0) >= 64 ? 4 : 2;  // S_pad % 32 == 0
-            f32x4 sc[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (kt < nkt) {
-                    const int key = key0 + kt * 16 + li;
-                    const char* kr = Ks + key * 128;
-                    const f16x8 k0 = *(const f16x8*)(kr + (((0 + g) ^ (key & 7)) << 4));
-                    const f16x8 k1 = *(const f16x8*)(kr + (((4 + g) ^ (key & 7)) << 4));
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], sc[kt], 0, 0, 0);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], sc[kt], 0, 0, 0);
-                }
-            }
-            // mask padded keys (only the last key block has any: wave-uniform branch), block max
-            if (key0 + 64 > S) {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + kt * 16 + 4 * g + r;
-                        if (!(kt < nkt && key < S)) sc[kt][r] = -INFINITY;
-                    }
-            }
-            float bmax = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bmax = fmaxf(bmax, sc[kt][r]);
-            bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
-            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-            const float mnew = fmaxf(mrun, bmax);
-            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * kScaleLog2e);   // raw v_exp_f32: argument <= 0
-            mrun = mnew;
-            float psum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f((sc[kt][r] - mnew) * kScaleLog2e);
-                    sc[kt][r] = pv;
-                    psum += pv;
-                }
-            lrun = lrun * alpha + psum;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = o[dt] * alpha;
-            // O^T += Vt . P^T, two 32-key steps
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                if (2 * s2 < nkt) {
-                    f16x8 pf;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pf[r] = (f16)sc[2 * s2][r];
-                        pf[4 + r] = (f16)sc[2 * s2 + 1][r];
-                    }
-                    const int kcol = (key0 + 32 * s2 + 4 * g) * 2;
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        const char* vr = Vs + (dt * 16 + li) * vstride + kcol;
-                        union { f16x8 v8; f16x4 v4[2]; } vf;
-                        vf.v4[0] = *(const f16x4*)(vr);
-                        vf.v4[1] = *(const f16x4*)(vr + 32);
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v8, pf, o[dt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        float lt = lrun + __shfl_xor(lrun, 16, 64);
-        lt = lt + __shfl_xor(lt, 32, 64);
-        const float inv = 1.0f / lt;
-        if (q0 + li < S) {
-            const int mrow = nb * S + q0 + li;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f16x4 h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (f16)(o[dt][r] * inv);
-                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1);
-            }
-        }
-    }
-}
-
-// The same attention for SHORT sequences (S_pad = 16 NK <= 160 keys: the DiT's 144 patch tokens per frame; round 4) in ONE pass per query tile: the scores of
-// all NK key tiles live in registers (4 NK floats per lane), one row maximum, one exponential per score, then the PV products — no online-softmax rescale
-// and no dependency between key blocks.  The online kernel above walks a query tile as three serial (QK^T -> max -> exp -> rescale -> PV) rounds of ~1 800 cycles
-// each, and with 2.5 four-wave blocks per CU at batch 8 nothing hides that chain: 17.7 us per launch against a 9.4 us traffic floor.  Same staging, same MFMA
-// operand maps; softmax(QK^T / 8) V is computed with one fp32 rounding order for every batch size and both sampling algorithms (the kernel is chosen by S alone).
+// SHORT sequences (S_pad = 16 NK <= 160 keys: the DiT's 144 patch tokens per frame; round 4): one block per (frame, head[, q-split]); K [S][64] (rows XOR-swizzled
+// for conflict-free ds_read_b128) and Vt [64][S] (rows padded) of the head are staged once in LDS, every wave then walks 16-query tiles in ONE pass: the scores
+// of all NK key tiles live in registers (4 NK floats per lane), one row maximum, one exponential per score, then the PV products — no online-softmax rescale and
+// no dependency between key blocks (the online-softmax kernel of round 1 walked a query tile as three serial QK^T -> max -> exp -> rescale -> PV rounds: 17.7 us
+// per launch at batch 8 against a 9.4 us traffic floor).  softmax(QK^T / 8) V is computed with one fp32 rounding order for every batch size and both sampling
+// algorithms (the kernel is chosen by S alone).
 template <int NW, int NK>
 __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __restrict__ Q, const f16* __restrict__ K,
                                                               const f16* __restrict__ Vt, f16* __restrict__ O, int heads, int S,
@@ -353,10 +174,10 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __r
 }
 
 // ---- long sequences (S_pad > 160: the VAE's 576 tokens per frame; round 5) ---------------------------------------------------------------
-// attn_spatial_kernel above keeps ALL of K / Vt of a (frame, head) in LDS (148 KB at S = 576: one 4-wave block per CU, whose 144 KB prologue load
-// nothing hides) and walks 16-query tiles one at a time, so every K / Vt fragment read from LDS feeds ONE MFMA (64 B/clk/SIMD = the whole LDS
-// bandwidth at the MFMA issue rate) and every 64-key block pays the online-softmax rescale: 0.106 of the MFMA peak at 40 frames x 16 heads
-// (profiles/round4/train_step_kernel_stats.csv).  This kernel is the flash form of the same arithmetic:
+// The kernel of rounds 1-4 kept ALL of K / Vt of a (frame, head) in LDS (148 KB at S = 576: one 4-wave block per CU, whose 144 KB prologue load nothing hid)
+// and walked 16-query tiles one at a time with an online softmax, so every K / Vt fragment read from LDS fed ONE MFMA (64 B/clk/SIMD = the whole LDS bandwidth
+// at the MFMA issue rate) and every 64-key block paid the rescale: 0.106-0.117 of the MFMA peak at 40-80 frames x 16 heads
+// (profiles/round4/train_step_kernel_stats.csv, profiles/round5/attn_flash_S576_ab_first_version.txt; removed in round 5).  This kernel is the flash form of the same arithmetic:
 //   * a block = 4 waves x NQT 16-query tiles (NQT = 3: 192 queries; S = 576 is three blocks per (frame, head), whose ids are 8 apart = one XCD's L2
 //     under round-robin placement, speed only); several blocks per CU (48 KiB of LDS, <= 168 registers)
 //   * K / Vt arrive in 64-key blocks by LDS-DMA (global_load_lds_dwordx4, 4 pieces per wave and block) into a 3-slot ring: counted vmcnt, ONE barrier
@@ -697,46 +518,35 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 
 }  // namespace
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: one "already raised" bit per device ordinal, so a
-// second model on another GPU of the same process (model.to("cuda:1")) gets its opt-in too
-static unsigned long long g_attn_attr_devs = 0;
 // output as paired 16-byte write-through stores (common.h store_f16x4_paired); experiments build: GTAV_ATTN_SC1=1 enables it
 static int g_attn_sc1 = GTAV_ENV_INT("GTAV_ATTN_SC1", 0) | (GTAV_ENV_INT("GTAV_ATTN_DBG_FORCE", 0) ? 2 : 0);   // measured neutral at B = 1 (attention re-reads nothing, writes little)
 
-bool attn_spatial_wants_prescaled_q(int S) { return S > 0 && S % 8 == 0 && round_up(S, 32) > 160 && GTAV_ENV_INT("GTAV_ATTN_FLASH", 1) != 0; }
+bool attn_spatial_wants_prescaled_q(int S) { return S > 0 && S % 8 == 0 && round_up(S, 32) > 160; }
 
 int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream, bool q_prescaled) {
     GTAV_REQUIRE(S > 0 && S % 8 == 0, "attn_spatial: S=%d must be a positive multiple of 8", S);
+    GTAV_REQUIRE(!q_prescaled || attn_spatial_wants_prescaled_q(S), "attn_spatial: S=%d runs a kernel that takes plain q", S);
     const int S_pad = round_up(S, 32);
-    const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
-    GTAV_REQUIRE(lds <= 160 * 1024, "attn_spatial: S=%d needs %zu B of LDS (> 160 KiB)", S, lds);
-    int devid = 0;
-    GTAV_CHECK_HIP(hipGetDevice(&devid));
-    if (!(g_attn_attr_devs >> (devid & 63) & 1)) {
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attn_attr_devs |= 1ull << (devid & 63);
-    }
     const int nqt = cdiv(S, 16);
-    // enough blocks to fill 256 CUs when there are few (frame, head) pairs; each block re-stages K/Vt from L2
-    int qsplit = 1;
-    const int max_split = cdiv(nqt, 4);
-    static const int blocks_target = GTAV_ENV_INT("GTAV_ATTN_S_BLOCKS", 512);
-    while (NB * heads * qsplit < blocks_target && qsplit < max_split) ++qsplit;
-    // experiment (GTAV_ATTN_S_WIDE=1): with more than 4 query tiles per block nine waves walk them side by side (S = 144,
-    // many frames: 9 tiles in one round instead of 4 + 4 + 1) — each wave is a serial QK^T -> softmax -> PV chain
-    static const int wide = GTAV_ENV_INT("GTAV_ATTN_S_WIDE", 0);   // measured neutral at B = 8 (0.41 vs 0.42 ms per forward): off
-    dim3 grid(NB * heads, qsplit);
     if (S_pad <= 160) {   // short sequences (the DiT's frames): one pass per query tile, scores in registers
+        const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
+        int devid = 0;
+        GTAV_CHECK_HIP(hipGetDevice(&devid));
+        // enough blocks to fill 256 CUs when there are few (frame, head) pairs; each block re-stages K / Vt from L2
+        int qsplit = 1;
+        const int max_split = cdiv(nqt, 4);
+        static const int blocks_target = GTAV_ENV_INT("GTAV_ATTN_S_BLOCKS", 512);
+        while (NB * heads * qsplit < blocks_target && qsplit < max_split) ++qsplit;
+        const dim3 grid(NB * heads, qsplit);
         const int nk = S_pad / 16;
 #define GTAV_ATTN_1P(NK_)                                                                                                               \
         do {                                                                                                                          \
-            static unsigned long long devs_ = 0;                                                                                      \
+            static unsigned long long devs_ = 0;   /* hipFuncAttributeMaxDynamicSharedMemorySize is per device: one "raised" bit per ordinal */ \
             if (!(devs_ >> (devid & 63) & 1)) {                                                                                       \
                 GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_1p_kernel<4, NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
                 devs_ |= 1ull << (devid & 63);                                                                                        \
             }                                                                                                                         \
-            GTAV_LAUNCH((attn_spatial_1p_kernel<4, NK_>), grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, qsplit, g_attn_sc1);   \
+            GTAV_LAUNCH((attn_spatial_1p_kernel<4, NK_>), grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, qsplit, g_attn_sc1 & 1);   \
         } while (0)
         if (nk == 2) GTAV_ATTN_1P(2);
         else if (nk == 4) GTAV_ATTN_1P(4);
@@ -747,39 +557,31 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
         GTAV_CHECK_HIP(hipGetLastError());
         return 0;
     }
-    GTAV_REQUIRE(!q_prescaled || attn_spatial_wants_prescaled_q(S), "attn_spatial: S=%d runs a kernel that takes plain q", S);
-    static const int use_flash = GTAV_ENV_INT("GTAV_ATTN_FLASH", 1);   // experiments build: 0 = the round-1 kernel (all of K / Vt in LDS), for A/B runs
-    if (use_flash) {   // long sequences (the VAE's 576 tokens): flash form, K / Vt streamed through a 3-slot LDS ring, 4 waves x NQT query tiles per block
-        // NQT by the fewest padded query tiles; on a tie the larger tile once the grid fills the chip, else the smaller (more blocks)
-        int best = 0, best_pad = 1 << 30, best_nqb = 0;
-        for (int c = 2; c <= 4; ++c) {
-            const int nqb_c = cdiv(nqt, 4 * c), pad = nqb_c * c;
-            const bool better = pad < best_pad || (pad == best_pad && NB * heads * best_nqb >= 512);
-            if (better) best = c, best_pad = pad, best_nqb = nqb_c;
-        }
-        static const int force_nqt = GTAV_ENV_INT("GTAV_ATTN_FLASH_NQT", 0), occ3 = GTAV_ENV_INT("GTAV_ATTN_FLASH_OCC3", 1);   // experiments build: A/B runs
-        if (force_nqt >= 2 && force_nqt <= 4) best = force_nqt, best_nqb = cdiv(nqt, 4 * force_nqt);
-        const int nfh = NB * heads;
-        const dim3 fgrid(nfh * best_nqb);
+    // long sequences (the VAE's 576 tokens): flash form, K / Vt streamed through a 3-slot LDS ring (48 KiB whatever S is), 4 waves x NQT query tiles per block.
+    // NQT by the fewest padded query tiles; on a tie the larger tile once the grid fills the chip, else the smaller (more blocks)
+    int best = 0, best_pad = 1 << 30, best_nqb = 0;
+    for (int c = 2; c <= 4; ++c) {
+        const int nqb_c = cdiv(nqt, 4 * c), pad = nqb_c * c;
+        const bool better = pad < best_pad || (pad == best_pad && NB * heads * best_nqb >= 512);
+        if (better) best = c, best_pad = pad, best_nqb = nqb_c;
+    }
+    static const int force_nqt = GTAV_ENV_INT("GTAV_ATTN_FLASH_NQT", 0), occ3 = GTAV_ENV_INT("GTAV_ATTN_FLASH_OCC3", 1);   // experiments build: A/B runs
+    if (force_nqt >= 2 && force_nqt <= 4) best = force_nqt, best_nqb = cdiv(nqt, 4 * force_nqt);
+    const int nfh = NB * heads;
+    GTAV_REQUIRE((long long)nfh * best_nqb < (1ll << 31) && (long long)S * 64 * 2 < (1ll << 31), "attn_spatial: grid / sequence too large");
+    const dim3 fgrid(nfh * best_nqb);
 #define GTAV_ATTN_FLASH_(NQT_, OCC_, RG_, PS_) GTAV_LAUNCH((attn_flash_kernel<NQT_, OCC_, RG_, PS_>), fgrid, dim3(256), 0, stream, Q, K, Vt, O, heads, S, nfh, best_nqb, g_attn_sc1)
 #define GTAV_ATTN_FLASH(NQT_, OCC_)                                                                    \
-        do {                                                                                           \
-            if (S % 64 != 0) { if (q_prescaled) GTAV_ATTN_FLASH_(NQT_, OCC_, true, true); else GTAV_ATTN_FLASH_(NQT_, OCC_, true, false); }   \
-            else { if (q_prescaled) GTAV_ATTN_FLASH_(NQT_, OCC_, false, true); else GTAV_ATTN_FLASH_(NQT_, OCC_, false, false); }             \
-        } while (0)
-        if (best == 2) GTAV_ATTN_FLASH(2, 3);
-        else if (best == 3 && occ3) GTAV_ATTN_FLASH(3, 3);
-        else if (best == 3) GTAV_ATTN_FLASH(3, 2);
-        else GTAV_ATTN_FLASH(4, 2);
+    do {                                                                                               \
+        if (S % 64 != 0) { if (q_prescaled) GTAV_ATTN_FLASH_(NQT_, OCC_, true, true); else GTAV_ATTN_FLASH_(NQT_, OCC_, true, false); }   \
+        else { if (q_prescaled) GTAV_ATTN_FLASH_(NQT_, OCC_, false, true); else GTAV_ATTN_FLASH_(NQT_, OCC_, false, false); }             \
+    } while (0)
+    if (best == 2) GTAV_ATTN_FLASH(2, 3);
+    else if (best == 3 && occ3) GTAV_ATTN_FLASH(3, 3);
+    else if (best == 3) GTAV_ATTN_FLASH(3, 2);
+    else GTAV_ATTN_FLASH(4, 2);
 #undef GTAV_ATTN_FLASH
 #undef GTAV_ATTN_FLASH_
-        GTAV_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
-    if (wide && cdiv(nqt, qsplit) > 4)
-        GTAV_LAUNCH(attn_spatial_kernel<9>, grid, dim3(576), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
-    else
-        GTAV_LAUNCH(attn_spatial_kernel<4>, grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, S_pad, qsplit, g_attn_sc1);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

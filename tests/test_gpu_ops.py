@@ -163,7 +163,7 @@ def test_layernorm_kernels(D, M):
     assert rel_l2(untile(out, M, D).float(), torch.nn.functional.layer_norm(x, (D,), g, b, eps=1e-6)) < 5e-4
 
 
-@pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72), (1, 2, 200), (3, 8, 256), (1, 3, 328), (5, 16, 576)])
+@pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72), (1, 2, 200), (3, 8, 256), (1, 3, 328), (5, 16, 576), (1, 2, 1152)])
 def test_attention_spatial(NB, heads, S):
     q, k, v = (_rand(NB, heads, S, 64, seed=i).half() for i in (1, 2, 3))
     q = q * 1.5

@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--s", type=int, default=144)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--exp", action="store_true", help="experiments build (libgtav_amd_exp.so): honours GTAV_ATTN_FLASH / GTAV_ATTN_FLASH_NQT / GTAV_ATTN_FLASH_OCC3")
+    ap.add_argument("--exp", action="store_true", help="experiments build (libgtav_amd_exp.so): honours GTAV_ATTN_FLASH_NQT / GTAV_ATTN_FLASH_OCC3")
     a = ap.parse_args()
     lib = L.load_experiments() if a.exp else L.load()
     dev = torch.device("cuda", 0)
