@@ -148,7 +148,7 @@ def load() -> C.CDLL:
     return lib
 
 
-EXP_LIB_PATH = os.path.join(_HERE, "libgtav_amd_exp.so")
+EXP_LIB_PATH = os.environ.get("GTAV_EXP_LIB") or os.path.join(_HERE, "libgtav_amd_exp.so")    # the override: A/B of two experiment builds (tools/ only)
 # entry points of the experiments build only (csrc/experiments.h): the LayerNorm fold
 EXP_SIGNATURES = {
     "gtav_dit_set_fold": [_p, _i, _i, _i],
