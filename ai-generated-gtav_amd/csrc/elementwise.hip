@@ -13,40 +13,32 @@ namespace gtav {
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm (eps 1e-6) over D: ONE WAVE PER ROW (4 rows per 256-thread block), the row lives in registers
-// (NV float4 per lane, D <= 256 NV), two-pass fp32 statistics by wave shuffles — no LDS, no block barrier.
-// Every global load of a lane (row, split-K slabs, bias, gate, modulation vectors) is independent and issued
-// before the first reduction: one memory round trip per row.  Optional deferred residual update first (LnPending).
+// LayerNorm (eps 1e-6) over D, fp32 statistics, output fp16 tile-major (GEMM A-operand).
 // MODE 0: adaLN modulate  y = xhat * (1 + (scale + 1e-6)) + shift     (model/dit.py:19-27)
 // MODE 1: affine          y = xhat * gamma + beta                     (nn.LayerNorm, model/vae.py:174)
-// Output: fp16, tile-major (GEMM A-operand).
+//
+// ONE WAVE PER ROW (4 rows per 256-thread block) for the thousands of rows of the batched paths without a pending update (B = 8 window 5 760 rows,
+// batched VAE 23 040 / 46 080): the row lives in registers (NV float4 per lane, D = 256 NV), the statistics are the same shifted one-pass sums as in
+// ln_row_block_kernel below (shift K = the row's first element, here lane 0's register: no extra load) reduced by DPP moves only — no LDS, no barrier.
+// Why not one block per row there: at these sizes that kernel is VALU-bound, not memory-bound — every thread of its four waves repeats the row-uniform
+// tail (three IEEE divisions, a square root, the LDS sum: ~150 instructions) for FOUR elements, 46 080 rows x 256 threads x 150 instructions = 51 us of the
+// chip's vector issue where a copy kernel moves the same 283 MB in 42 us.  A wave per row amortises the tail over 16 elements per lane and keeps
+// 4 KiB per wave in flight (tools/ln_stream_probe.hip, profiles/round5/layernorm_large_m.txt: 68 -> 46 us at 46 080 rows).
+// The sums are added in another order than in the row-block kernel: the two kernels agree to rounding, not to the bit.
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool PEND, int NV>
-__global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
-                                                 const float* __restrict__ p0, const float* __restrict__ p1, int mod_stride,
-                                                 const int* __restrict__ rows, int rows_per_mod, LnPending pd) {
+// (With a pending update the same layout was measured too — slabs, gate and write-back per lane: 5.1 -> 7.5 us per launch at 720 rows in the batch-1
+// forward, 22.4 -> 20-21 us at 5 760 rows, 32.0 -> 31.6 at 11 520: not kept, those launches stay on the row-block kernel.)
+template <int MODE, int NV>
+__global__ __launch_bounds__(256) void ln_wave_row_kernel(const float* __restrict__ x, int ldx, f16* __restrict__ out, int M, int D,
+                                                          const float* __restrict__ p0, const float* __restrict__ p1, int mod_stride,
+                                                          const int* __restrict__ rows, int rows_per_mod, int flags, int* err_flag) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
-    float* xr = x + (size_t)m * ldx;
-    // loads that do not depend on the (optional) row indirection go first: the row itself and the split-K slabs
-    f32x4 v[NV], y[NV], av[NV], bv[NV];
+    const float* xr = x + (size_t)m * ldx;
+    f32x4 v[NV], av[NV], bv[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        y[i] = v[i];
-        if (c < D) {
-            v[i] = *(const f32x4*)(xr + c);
-            if (PEND) {
-                if (pd.bias) y[i] = *(const f32x4*)(pd.bias + c);
-                const float* pp = pd.parts + (size_t)m * pd.ld + c;
-#pragma unroll
-                for (int sp = 0; sp < 8; ++sp)
-                    if (sp < pd.nsplit) y[i] = y[i] + *(const f32x4*)(pp + (size_t)sp * pd.slab_stride);
-            }
-        }
-    }
+    for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
     const float *a, *b;  // MODE 0: a = scale row, b = shift row; MODE 1: a = gamma, b = beta
     if (MODE == 0) {
         int row = m / rows_per_mod;
@@ -57,69 +49,45 @@ __global__ __launch_bounds__(256) void ln_kernel(float* __restrict__ x, int ldx,
         a = p0;
         b = p1;
     }
-    const float* grow = nullptr;
-    if (PEND && pd.gate) {
-        int gr = m / pd.rows_per_gate;
-        if (pd.gate_rows) gr = pd.gate_rows[gr];
-        grow = pd.gate + (size_t)gr * pd.gate_stride;
-    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bv[i] = av[i];
-        if (c < D) {
-            av[i] = *(const f32x4*)(a + c);
-            bv[i] = *(const f32x4*)(b + c);
-            if (PEND) {
-                if (grow) y[i] = y[i] * *(const f32x4*)(grow + c);
-                v[i] = v[i] + y[i];
-                if (pd.flags & 1) store16_sc1(xr + c, v[i]);
-                else *(f32x4*)(xr + c) = v[i];
-            }
-        }
+        av[i] = *(const f32x4*)(a + i * 256 + lane * 4);
+        bv[i] = *(const f32x4*)(b + i * 256 + lane * 4);
     }
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);   // idle chunks are zero
-    const float mean = wave_sum(sum) / (float)D;
-    float sq = 0.f;
+    const float kshift = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v[0][0])));
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        if (i * 256 + lane * 4 < D) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
-            }
-        }
+        const float a0 = v[i][0] - kshift, a1 = v[i][1] - kshift, a2 = v[i][2] - kshift, a3 = v[i][3] - kshift;
+        s1 += (a0 + a1) + (a2 + a3);
+        s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)D + 1e-6f);
+    const float t1 = wave_sum_dpp(s1), t2 = wave_sum_dpp(s2);
+    const float m1 = t1 / (float)D, mean = kshift + m1;
+    const float var = fmaxf(t2 / (float)D - m1 * m1, 0.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-            float yv[4];
+        float yv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (v[i][e] - mean) * rstd;
-                if (MODE == 0) {
-                    const float sc = av[i][e] + 1e-6f;
-                    yv[e] = xh * (1.0f + sc) + bv[i][e];
-                } else {
-                    yv[e] = xh * av[i][e] + bv[i][e];
-                }
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (v[i][e] - mean) * rstd;
+            if (MODE == 0) {
+                const float sc = av[i][e] + 1e-6f;
+                yv[e] = xh * (1.0f + sc) + bv[i][e];
+            } else {
+                yv[e] = xh * av[i][e] + bv[i][e];
             }
-            store_f16x4_paired<1>(out + tiled_off(m, c, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, pd.flags & 2);
         }
+        store_f16x4_paired<1>(out + tiled_off(m, i * 256 + lane * 4, D), sat4(yv[0], yv[1], yv[2], yv[3], amax), lane, flags & 2);
     }
-    sat_report(amax, pd.err_flag);
+    sat_report(amax, err_flag);
 }
 
-// ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS: the default at every M.  With a few hundred rows
-// the wave-per-row kernel leaves most CUs idle (720 rows: 8.5 us vs 14.7); at thousands of rows the 4x larger number of
-// independent blocks still keeps more loads in flight (5760 rows: 22 us vs 26).
+// ONE BLOCK PER ROW (D/4 threads, one float4 each), statistics through LDS: every launch with a pending update (split-K slabs, gate, residual
+// write-back) and every launch of a few hundred rows, where a wave per row leaves most CUs idle (720 rows: 8.5 us vs 14.7) and the launch is
+// latency-bound.  Optional deferred residual update first (LnPending).
 #ifdef GTAV_EXPERIMENTS   // timing experiments (WRONG results): GTAV_LN_FLAGS bits 8.. switch pieces of the row-block kernel off (tools/ln_bench.py)
 #define LN_DBG(pd, b) ((pd).flags & (b))
 #else
@@ -684,15 +652,13 @@ __global__ void qkv_head_major_kernel(const f16* __restrict__ src, f16* __restri
 // -DGTAV_EXPERIMENTS builds: GTAV_LN_FLAGS (see LnPending::flags)
 static int g_ln_flags = GTAV_ENV_INT("GTAV_LN_FLAGS", 7);   // default: all stores written through (B = 1: LN 0.57 -> 0.54 ms per forward)
 
-// One block per row at every M since the write-through stores: B = 8 (M = 5760) LN 1.71 -> 1.43 ms per forward against the
-// wave-per-row kernel, M = 11 520 / 46 080 neutral.  GTAV_LN_ROWBLOCK_MAX restores a threshold for experiments.
-static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
-// (Round 2 tried one wave per row with no LDS and no barrier for a few hundred rows — bit-identical statistics, a quarter of the
-// waves to start: 5.2-5.3 us per launch against 4.9 for the row-block kernel at M = 720 in a one-process A/B, profiles/round2/
-// forward_ab_B1_ln_wave_row.txt: the 16 dependent DPP reductions of one wave cost more than the barriers they replace.  Removed.)
+// ln_wave_row_kernel from this many rows on when there is no pending update (every such launch: 3.4 vs 3.6 us at 720 rows, 7.1 vs 8.9 at 5 760, 45 vs 67 at 46 080)
+static int g_ln_wave_row_min = GTAV_ENV_INT("GTAV_LN_WAVE_ROW_MIN", 0);
+// (Round 2 had tried one wave per row for the batch-1 forward's launches WITH a pending update: 5.2-5.3 us per launch against 4.9 for the row-block
+// kernel at M = 720 in a one-process A/B, profiles/round2/forward_ab_B1_ln_wave_row.txt; round 5 measured the same again, see above.)
 
-#define LN_LAUNCH_(MODE, PEND, NV, P0, P1, STRIDE, ROWS, RPM) \
-    GTAV_LAUNCH((ln_kernel<MODE, PEND, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_)   /* (GTAV_LAUNCH: the profiler's events ride on the dispatch) */
+#define LN_WAVE_ROW_(MODE, NV, P0, P1, STRIDE, ROWS, RPM) \
+    GTAV_LAUNCH((ln_wave_row_kernel<MODE, NV>), dim3(cdiv(M, 4)), dim3(256), 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_.flags, err_flag)   /* (GTAV_LAUNCH: the profiler's events ride on the dispatch) */
 #define LN_DISPATCH(MODE, P0, P1, STRIDE, ROWS, RPM)                                                     \
     do {                                                                                                  \
         LnPending pd_;                                                                                    \
@@ -700,24 +666,16 @@ static int g_ln_rowblock_max = GTAV_ENV_INT("GTAV_LN_ROWBLOCK_MAX", 1 << 30);
         if (pend) pd_ = *pend;                                                                            \
         pd_.flags = g_ln_flags;                                                                           \
         pd_.err_flag = err_flag;                                                                          \
-        const int nv_ = D <= 256 ? 1 : D <= 512 ? 2 : D <= 1024 ? 4 : 8;                                  \
-        GTAV_REQUIRE(pd_.tperm_T == 0 || (M <= g_ln_rowblock_max && pd_.tperm_P % 16 == 0 && M % (pd_.tperm_T * pd_.tperm_P) == 0), "ln: bad output row permutation"); \
-        /* (Round 4 re-measured the wave-per-row kernel for the large-M steps without pending slabs: 10.1 us against 10.2 us per launch at M = 5760 — a tie;   */ \
-        /* a first reading of "4.6 us" was the profiler's empty event pair: that kernel's launch did not carry the events.  profiles/round4/layernorm_*.txt)   */ \
-        if (M <= g_ln_rowblock_max) { /* one block per row */                                                         \
+        GTAV_REQUIRE(pd_.tperm_T == 0 || (pd_.tperm_P % 16 == 0 && M % (pd_.tperm_T * pd_.tperm_P) == 0), "ln: bad output row permutation"); \
+        if (!pend && pd_.tperm_T == 0 && M >= g_ln_wave_row_min && (D == 256 || D == 512 || D == 1024 || D == 2048)) { \
+            if (D == 256) LN_WAVE_ROW_(MODE, 1, P0, P1, STRIDE, ROWS, RPM);                               \
+            else if (D == 512) LN_WAVE_ROW_(MODE, 2, P0, P1, STRIDE, ROWS, RPM);                          \
+            else if (D == 1024) LN_WAVE_ROW_(MODE, 4, P0, P1, STRIDE, ROWS, RPM);                         \
+            else LN_WAVE_ROW_(MODE, 8, P0, P1, STRIDE, ROWS, RPM);                                        \
+        } else { /* one block per row */                                                                  \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
             if (pend) GTAV_LAUNCH((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
             else GTAV_LAUNCH((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
-        } else if (pend) {                                                                                       \
-            if (nv_ == 1) LN_LAUNCH_(MODE, true, 1, P0, P1, STRIDE, ROWS, RPM);                           \
-            else if (nv_ == 2) LN_LAUNCH_(MODE, true, 2, P0, P1, STRIDE, ROWS, RPM);                      \
-            else if (nv_ == 4) LN_LAUNCH_(MODE, true, 4, P0, P1, STRIDE, ROWS, RPM);                      \
-            else LN_LAUNCH_(MODE, true, 8, P0, P1, STRIDE, ROWS, RPM);                                    \
-        } else {                                                                                          \
-            if (nv_ == 1) LN_LAUNCH_(MODE, false, 1, P0, P1, STRIDE, ROWS, RPM);                          \
-            else if (nv_ == 2) LN_LAUNCH_(MODE, false, 2, P0, P1, STRIDE, ROWS, RPM);                     \
-            else if (nv_ == 4) LN_LAUNCH_(MODE, false, 4, P0, P1, STRIDE, ROWS, RPM);                     \
-            else LN_LAUNCH_(MODE, false, 8, P0, P1, STRIDE, ROWS, RPM);                                   \
         }                                                                                                 \
     } while (0)
 
@@ -726,7 +684,6 @@ int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const
     GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && rows_per_mod > 0 && ldo == D, "ln_modulate: D=%d must be %%64, <= 2048, ldo == D", D);
     GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
                  "ln_modulate: bad pending update");
-    GTAV_REQUIRE(!pend || M <= g_ln_rowblock_max || (!pend->x_out && !pend->y_save), "ln_modulate: x_out / y_save need the row-block kernel");
     LN_DISPATCH(0, shift, scale, mod_stride, rows, rows_per_mod);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
@@ -742,7 +699,7 @@ int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const f
     return 0;
 }
 #undef LN_DISPATCH
-#undef LN_LAUNCH_
+#undef LN_WAVE_ROW_
 
 int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo,
                     float a, float b, int* err_flag, hipStream_t stream) {
