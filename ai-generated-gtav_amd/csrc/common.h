@@ -177,6 +177,20 @@ __device__ __forceinline__ void gelu_tanh_f4(const float (&x)[4], float (&y)[4])
     }
 }
 
+// d/dx of gelu_tanh_f for two values (training backward): g = s + x s (1 - s) 2k (1 + 3c x^2) with s = 1 / (1 + 2^(x (a + b x^2))) as above, k = sqrt(2/pi),
+// c = 0.044715.  The same two transcendentals and eight packed fp32 operations per PAIR; with the IEEE division and the scalar arithmetic it had before,
+// gelu_bwd_colsum_kernel needed ~40 issue slots per value and was VALU-bound (57 us for the 283 MB of an fc1 backward at M = 11 520, round 5).
+__device__ __forceinline__ f32x2_ gelu_tanh_grad_f2(f32x2_ v) {
+    const float k = 0.7978845608028654f, c = 0.044715f;
+    const float a = -2.0f * 1.4426950408889634f * k, b = a * c, k2 = 2.0f * k, k6 = 6.0f * k * c;
+    const f32x2_ z = v * v;
+    const f32x2_ arg = v * __builtin_elementwise_fma(z, f32x2_{b, b}, f32x2_{a, a});
+    const f32x2_ d = f32x2_{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])} + f32x2_{1.0f, 1.0f};
+    const f32x2_ s = f32x2_{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2_ t = (v * s) * __builtin_elementwise_fma(z, f32x2_{k6, k6}, f32x2_{k2, k2});
+    return __builtin_elementwise_fma(t, f32x2_{1.0f, 1.0f} - s, s);
+}
+
 // exact (erf) GELU: 0.5 x (1 + erf(x / sqrt(2)))  (model/vae.py:128, torch.nn.GELU()) through libm's erff: ~36 VALU instructions per value
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 

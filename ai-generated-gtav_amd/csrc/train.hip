@@ -83,14 +83,11 @@ __global__ void gelu_bwd_tiled_kernel(const f16* __restrict__ dh, const f16* __r
         a.q = ((const uint4*)dh)[i];
         b.q = ((const uint4*)u)[i];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = (float)b.e[j];
-            const float k = 0.7978845608028654f, c = 0.044715f;
-            const float s = 1.0f / (1.0f + __expf(-2.0f * k * x * (1.0f + c * x * x)));
-            const float g = s + x * s * (1.0f - s) * 2.0f * k * (1.0f + 3.0f * c * x * x);
-            const float v = (float)a.e[j] * g;
-            amax = fmaxf(amax, fabsf(v));
-            o.e[j] = (f16)__builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2_ v = f32x2_{(float)a.e[j], (float)a.e[j + 1]} * gelu_tanh_grad_f2(f32x2_{(float)b.e[j], (float)b.e[j + 1]});
+            amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+            o.e[j] = (f16)__builtin_amdgcn_fmed3f(v[0], -F16_MAX, F16_MAX);
+            o.e[j + 1] = (f16)__builtin_amdgcn_fmed3f(v[1], -F16_MAX, F16_MAX);
         }
         ((uint4*)du)[i] = o.q;
     }
@@ -295,15 +292,13 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const f16* __restr
         b.q = *(const uint4*)(u + off);
         const bool real = r < M;   // (pad rows of the 128-row image are transformed like the others but must not reach the sums — they may hold anything, NaN included)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xx = (float)b.e[j];
-            const float k = 0.7978845608028654f, c = 0.044715f;
-            const float s = 1.0f / (1.0f + __expf(-2.0f * k * xx * (1.0f + c * xx * xx)));
-            const float g = s + xx * s * (1.0f - s) * 2.0f * k * (1.0f + 3.0f * c * xx * xx);
-            const float v = (float)x.e[j] * g;
-            amax = fmaxf(amax, fabsf(v));
-            o.e[j] = (f16)__builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
-            a[j] += real ? v : 0.f;
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2_ v = f32x2_{(float)x.e[j], (float)x.e[j + 1]} * gelu_tanh_grad_f2(f32x2_{(float)b.e[j], (float)b.e[j + 1]});
+            amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+            o.e[j] = (f16)__builtin_amdgcn_fmed3f(v[0], -F16_MAX, F16_MAX);
+            o.e[j + 1] = (f16)__builtin_amdgcn_fmed3f(v[1], -F16_MAX, F16_MAX);
+            a[j] += real ? v[0] : 0.f;
+            a[j + 1] += real ? v[1] : 0.f;
         }
         *(uint4*)(du + off) = o.q;
     }
