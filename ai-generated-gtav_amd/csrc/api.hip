@@ -284,6 +284,7 @@ struct gtav_dit {
     // handles with training enabled keep the split path (the copies are not refreshed by the optimizer).
     bool fuse_tattn = false;
     bool w_prefetch = true;   // L2 prefetch of the next GEMM's weight at small M (gemm.h pf_next)
+    int w_prefetch_cls[4] = {1, 1, 1, 1};   // per consumer class (0 out-proj, 1 fc1, 2 fc2, 3 to_qkv): 0 skip, 1 the whole slice, k >= 2 the first k K tiles (PrefetchDesc::kt_limit)
     int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
     // ---- LayerNorm fold (docs/LABNOTES.md 4.7; gemm.h EPI_*_FOLD): the LayerNorm + modulate between a residual GEMM and its consumer runs inside the
     // two GEMM epilogues.  Seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection.  Per-frame c1 / c2 tables for every
@@ -489,17 +490,18 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // 0.6-0.9 us for its prefetch, the consumer gains 1.5-2 us.)
     static const int pf_min_m = GTAV_ENV_INT("GTAV_PF_MIN_M", 256);   // 320 tokens (window step of the 256 x 256-frame preset): -2.1 %; 144 (cached step): +1.5 %; experiments build: A/B
     const bool pf_on = h->w_prefetch && M >= pf_min_m && M <= pf_max_m;
-    auto set_pf = [&](GemmParams& q, const f16* Wn, int Nn, int Kn, int skn) {
-        if (!pf_on || !Wn) return;
+    auto set_pf = [&](GemmParams& q, const f16* Wn, int Nn, int Kn, int skn, int consumer /* 0 out-proj, 1 fc1, 2 fc2, 3 to_qkv */) {
+        const int v = h->w_prefetch_cls[consumer];      // 0 skip, 1 the whole slice, k >= 2: the first k K tiles of every row tile
+        if (!pf_on || !Wn || !v) return;
         const int nkt = Kn / 64;
         if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
-        q.pf = PrefetchDesc{Wn, cdiv(Nn, 128), nkt, skn};
+        q.pf = PrefetchDesc{Wn, cdiv(Nn, 128), nkt, skn, v >= 2 ? v : 0};
     };
     auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const f16* Wn = nullptr, int Nn = 0, int Kn = 0) -> int {
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
-        set_pf(q, Wn, Nn, Kn, 1);
+        set_pf(q, Wn, Nn, Kn, 1, Nn == 3 * D ? 3 : 1);
         q.splitk = gemm_choose_splitk(M, D, K);
         if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || gemm_resid_inplace_ok(M, D, K, P)) {   // (also on training handles: this plain forward keeps no activations)
             // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
@@ -536,7 +538,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
             if (folded_in) fold_consumer(g, 2 * hb, 3 * D);
-            set_pf(g, w.w_out, D, D, gemm_choose_splitk(M, D, D));
+            set_pf(g, w.w_out, D, D, gemm_choose_splitk(M, D, D), 0);
             if (fused_t) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
@@ -557,7 +559,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             folded_in = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
-            set_pf(g, w.w_fc2, D, h->Hm_pad, gemm_choose_splitk(M, D, h->Hm_pad));
+            set_pf(g, w.w_fc2, D, h->Hm_pad, gemm_choose_splitk(M, D, h->Hm_pad), 2);
             if (fold_a) {
                 // seam A: out-proj updates the residual in place and emits fc1's operand + row statistics; fc1 normalises in its epilogue
                 RET_IF(fold_producer(PC_OUT, h->ao, w.w_out, D, w.b_out, mb + 2 * D, mb + 4 * D));
@@ -934,12 +936,19 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable) {
 
 int gtav_dit_set_weight_prefetch(gtav_dit* h, int32_t enable) {
     GTAV_REQUIRE(h, "dit_set_weight_prefetch: null handle");
-    if (h->w_prefetch != (enable != 0)) {   // captured sampler steps carry the other kernel parameters
+    GTAV_REQUIRE(enable == 0 || enable == 1 || (enable >> 16) == 1,
+                 "dit_set_weight_prefetch: mode %d (0 off, 1 on, 0x10000 | per-class nibbles: bits 0-3 out-proj's weight, 4-7 fc1's, 8-11 fc2's, 12-15 to_qkv's; "
+                 "nibble 0 = not prefetched, 1 = the whole slice, k >= 2 = the first k K tiles of every row tile)", enable);
+    int cls[4];
+    for (int c = 0; c < 4; ++c) cls[c] = enable == 0 ? 0 : enable == 1 ? 1 : (enable >> (4 * c)) & 15;
+    const bool on = cls[0] || cls[1] || cls[2] || cls[3];
+    if (h->w_prefetch != on || memcmp(cls, h->w_prefetch_cls, sizeof(cls))) {   // captured sampler steps carry the other kernel parameters
         for (auto& kv : h->graphs)
             if (kv.second) (void)hipGraphExecDestroy(kv.second);
         h->graphs.clear();
     }
-    h->w_prefetch = enable != 0;
+    h->w_prefetch = on;
+    memcpy(h->w_prefetch_cls, cls, sizeof(cls));
     return 0;
 }
 

@@ -90,6 +90,7 @@ __host__ __device__ __forceinline__ size_t tiled_off(int r, int k, int K) {
 struct PrefetchDesc {
     const void* next;     // nullptr = off
     int rt, nkt, splitk;  // splitk >= 1, nkt % splitk == 0, splitk divides 8 or is a multiple of 8
+    int kt_limit;         // > 0: only the first kt_limit K tiles of every (row tile, K slice) — what the consumer's prologue waits for; 0 = the whole slice
 };
 // The caller is thread `t` of the `nt` threads of the j-th of `nb` prefetching blocks of XCD `xcd`.  `sink` receives every load: keep it alive
 // (asm volatile("" :: "v"(sink))) until a later wait proves the loads returned, or until the wave ends.
@@ -103,12 +104,14 @@ __device__ __forceinline__ void l2_prefetch_slice(const PrefetchDesc& d, int xcd
         ks0 = xcd / per; ksn = 1;
         rt0 = part * d.rt / per; rtn = (part + 1) * d.rt / per - rt0;
     }
-    const int kpt = d.nkt / sk, kt0 = ks0 * kpt, ktn = ksn * kpt;
-    const int lines = rtn * ktn * 128;
+    const int kpt = d.nkt / sk;                                                  // K tiles per K slice
+    const int lim = d.kt_limit > 0 && d.kt_limit < kpt ? d.kt_limit : kpt;       // ... of which the first `lim` are touched
+    const int per_rt = ksn * lim;
+    const int lines = rtn * per_rt * 128;
     const int l0 = (int)((long long)lines * j / nb), l1 = (int)((long long)lines * (j + 1) / nb);
     for (int l = l0 + t; l < l1; l += nt) {
-        const int tile = l >> 7, r = tile / ktn;
-        const char* a = (const char*)d.next + ((size_t)(rt0 + r) * d.nkt + kt0 + (tile - r * ktn)) * 16384 + (l & 127) * 128;
+        const int tile = l >> 7, r = tile / per_rt, rem = tile - r * per_rt, sl = rem / lim, k = rem - sl * lim;
+        const char* a = (const char*)d.next + ((size_t)(rt0 + r) * d.nkt + (size_t)(ks0 + sl) * kpt + k) * 16384 + (l & 127) * 128;
         asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(a) : "memory");
     }
 }

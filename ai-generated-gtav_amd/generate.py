@@ -87,13 +87,30 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
     return x
 
 
+PREFETCH_CLASSES = ("out", "fc1", "fc2", "qkv")      # consumer classes of gtav_dit_set_weight_prefetch's per-class mode, nibble order
+
+
+def prefetch_mode(cls) -> int:
+    """(out, fc1, fc2, qkv) values (0 = that weight is not prefetched, 1 = its whole slice, k >= 2 = the first k K tiles of every row tile) -> the mode
+    word of gtav_dit_set_weight_prefetch (include/gtav_amd.h)."""
+    if not any(cls):
+        return 0
+    if all(v == 1 for v in cls):
+        return 1
+    return 0x10000 | cls[0] | cls[1] << 4 | cls[2] << 8 | cls[3] << 12
+
+
 @torch.inference_mode()
 def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps: int = 24, rounds: int = 2, use_actions: bool = False,
-                         latent_hw=None) -> dict:
-    """Times the captured full-window sampler step of batch B with the next-weight L2 prefetch (docs/LABNOTES.md 4.10) on and off — the results are
-    bit-identical, only the speed differs, and the gain is box-dependent (-7 % on some MI355X boxes, nothing on others) — and leaves the model on
-    the faster setting.  Alternates the two settings `rounds` times in this process (a fresh capture per switch), `steps` replays each; synthetic
-    latents; about 0.2 s at batch 1.  Returns {"on_ms", "off_ms", "chosen"} (milliseconds per step, best round of each)."""
+                         latent_hw=None, per_class: bool = True) -> dict:
+    """Times the captured full-window sampler step of batch B under different settings of the next-weight L2 prefetch (docs/LABNOTES.md 4.10) and leaves
+    the model on the fastest.  The results are bit-identical under every setting, only the speed differs, and what pays depends on the GPU: on some
+    MI355X GPUs prefetching every weight takes 7-12 % off the step; on the others that costs 1-8 % (the prefetched lines are gone before their consumer
+    starts and the weight is read twice), but the to_qkv / out-proj weights alone, or the first K tiles of each weight, still take 1-3 % off
+    (profiles/round5/prefetch_box_survey.txt).  First off against on for every weight (`rounds` alternations, `steps` replays each, a fresh capture
+    per switch); then, with `per_class`, one pass over the four weight classes (fc2, fc1, out-proj, to_qkv) trying skip / first 4 K tiles / whole
+    slice for each while the others stay.  About 0.5 s + 2.5 s at batch 1; synthetic latents.
+    Returns {"on_ms", "off_ms", "chosen": "on" | "off" | "per-class", "classes": {...}, "mode", "tuned_ms"} (milliseconds per step)."""
     dev = model.device
     T = int(window or model.max_frames)
     h, w = latent_hw or (model.input_h, model.input_w)
@@ -105,24 +122,41 @@ def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps:
         act[:, :, 3] = 1
     model.set_schedule(_alphas_cumprod(1e-4))
     ts = [999 - 7 * k for k in range(steps + 3)]
-    best = {True: float("inf"), False: float("inf")}
+
+    def timed(cls) -> float:
+        model.set_weight_prefetch(prefetch_mode(cls))
+        x = x0.clone()
+        model.prepare_frame_(B, F, 0, T - 1, 15, ts, act)
+        for k in range(3):                                  # eager warm-up, capture, first replay
+            model.denoise_step_(x, 0, T - 1, 15, ts[k], ts[k + 1], False, act, cond_step=k)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(3, steps + 3):
+            model.denoise_step_(x, 0, T - 1, 15, ts[k], ts[min(k + 1, steps + 2)], False, act, cond_step=k)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    on, off = (1, 1, 1, 1), (0, 0, 0, 0)
+    best = {on: float("inf"), off: float("inf")}
     for _ in range(rounds):
-        for on in (True, False):
-            model.set_weight_prefetch(on)
-            x = x0.clone()
-            model.prepare_frame_(B, F, 0, T - 1, 15, ts, act)
-            for k in range(3):                                  # eager warm-up, capture, first replay
-                model.denoise_step_(x, 0, T - 1, 15, ts[k], ts[k + 1], False, act, cond_step=k)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            for k in range(3, steps + 3):
-                model.denoise_step_(x, 0, T - 1, 15, ts[k], ts[min(k + 1, steps + 2)], False, act, cond_step=k)
-            torch.cuda.synchronize(dev)
-            best[on] = min(best[on], (time.perf_counter() - t0) / steps * 1e3)
-    chosen = best[True] <= best[False]
-    model.set_weight_prefetch(chosen)
+        for cls in (on, off):
+            best[cls] = min(best[cls], timed(cls))
+    cur = on if best[on] <= best[off] else off
+    cur_ms = best[cur]
+    if per_class:
+        for c in (2, 1, 0, 3):
+            for v in (0, 4, 1):
+                if v == cur[c]:
+                    continue
+                cand = cur[:c] + (v,) + cur[c + 1:]
+                ms = min(timed(cand) for _ in range(rounds))
+                if ms < cur_ms * 0.997:                     # a change has to show: 0.3 % is the repeatability of this timing
+                    cur, cur_ms = cand, ms
+    model.set_weight_prefetch(prefetch_mode(cur))
     model.check()
-    return {"on_ms": round(best[True], 4), "off_ms": round(best[False], 4), "chosen": "on" if chosen else "off"}
+    chosen = "on" if cur == on else "off" if cur == off else "per-class"
+    return {"on_ms": round(best[on], 4), "off_ms": round(best[off], 4), "chosen": chosen, "classes": dict(zip(PREFETCH_CLASSES, cur)),
+            "mode": prefetch_mode(cur), "tuned_ms": round(cur_ms, 4)}
 
 
 def sample_inputs(gid: int, n_prompt: int, total_frames: int, frame_hw, latent_hw, latent_ch: int = 16, seed: int = 1000):

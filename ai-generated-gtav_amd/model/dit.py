@@ -482,11 +482,15 @@ class DiT(_HipModule):
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fused_temporal(self._handle, int(self._fused_temporal)))
 
-    def set_weight_prefetch(self, enable: bool):
-        """L2 prefetch of the next GEMM's weight at small token counts (gtav_dit_set_weight_prefetch; on by default, bit-identical results)."""
-        self._weight_prefetch = bool(enable)
+    def set_weight_prefetch(self, mode):
+        """L2 prefetch of the next GEMM's weight at small token counts (gtav_dit_set_weight_prefetch; on by default, bit-identical results under every
+        mode): False / 0 off, True / 1 every weight, or a per-class word from gtav_amd.generate.prefetch_mode."""
+        mode = int(mode)
+        if mode not in (0, 1) and (mode >> 16) != 1:
+            raise ValueError(f"set_weight_prefetch: mode {mode:#x} is neither 0, 1 nor a per-class word (gtav_amd.generate.prefetch_mode)")
+        self._weight_prefetch = mode
         if self._handle:
-            _lib.check(_lib.load().gtav_dit_set_weight_prefetch(self._handle, int(self._weight_prefetch)))
+            _lib.check(_lib.load().gtav_dit_set_weight_prefetch(self._handle, mode))
 
     def set_fold(self, mode: int, min_tokens_a: int = -1, min_tokens_b: int = -1):
         """EXPERIMENTS BUILD ONLY (gtav_amd.lib.load_experiments(), tools/fold_bench.py): the LayerNorm fold of round 3 (gtav_dit_set_fold, csrc/experiments.h) —

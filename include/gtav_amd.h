@@ -118,10 +118,14 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
 int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
 
 /* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (docs/LABNOTES.md 4.10; default ON for steps of 256 ... 1536 tokens).  It changes no
- * arithmetic — results are bit-identical either way — and pays on some MI355X boxes (-7 % per batch-1 step) and not on others, so a harness may
- * time a few captured steps with each setting and keep the faster one (gtav_amd.generate.tune_weight_prefetch does; bench.py reports the choice).
- * Every call that changes the setting drops the captured graphs of the handle. */
-int gtav_dit_set_weight_prefetch(gtav_dit* h, int32_t enable);
+ * arithmetic — results are bit-identical under every setting — and what pays depends on the GPU (profiles/round5/prefetch_box_survey.txt): on some MI355X
+ * GPUs prefetching every weight takes 7-12 % off a batch-1 step, on others that costs 1-8 % while the to_qkv / out-proj weights alone or the first K
+ * tiles of each weight still gain 1-3 %.  So a harness times a few captured steps per setting and keeps the fastest (gtav_amd.generate.tune_weight_prefetch
+ * does; bench.py reports the choice).  mode: 0 = off, 1 = every weight, whole slice; or 0x10000 | one nibble per consumer class — bits 0-3 the
+ * out-projection's weight (prefetched by the to_qkv launch), 4-7 fc1's (by the out-projection), 8-11 fc2's (by fc1), 12-15 to_qkv's (by fc2) — with
+ * nibble 0 = not prefetched, 1 = the whole slice, k >= 2 = the first k K tiles of every row tile.  Every call that changes the setting drops the captured
+ * graphs of the handle. */
+int gtav_dit_set_weight_prefetch(gtav_dit* h, int32_t mode);
 
 /* In-situ kernel timing for bench.py's roofline line: when enabled, every kernel of a forward is bracketed by
  * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).

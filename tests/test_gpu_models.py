@@ -137,9 +137,10 @@ def test_fused_temporal_qkv_attention_is_bit_identical(full_dit):
 
 
 def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
-    """gtav_dit_set_weight_prefetch (round 4): the next-weight L2 prefetch of the small-M GEMMs changes no arithmetic — a captured batch-1 window step with it on
-    and off gives EQUAL latents — and generate.tune_weight_prefetch times both settings, leaves the model on the faster one and reports the choice."""
-    from gtav_amd.generate import tune_weight_prefetch
+    """gtav_dit_set_weight_prefetch (round 4; per-class modes round 5): the next-weight L2 prefetch of the small-M GEMMs changes no arithmetic — a captured
+    batch-1 window step gives EQUAL latents under every mode — and generate.tune_weight_prefetch times the settings, leaves the model on the fastest one and
+    reports the choice."""
+    from gtav_amd.generate import tune_weight_prefetch, prefetch_mode
     from gtav_amd.utils import alphas_cumprod
     m, _, _ = full_dit
     g = torch.Generator().manual_seed(17)
@@ -147,16 +148,19 @@ def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
     m.set_schedule(alphas_cumprod(1e-4))
     outs = []
     try:
-        for on in (True, False):
-            m.set_weight_prefetch(on)
+        for mode in (1, 0, prefetch_mode((1, 0, 4, 1)), prefetch_mode((0, 0, 0, 2))):     # on, off, two per-class settings (round 5)
+            m.set_weight_prefetch(mode)
             x = x0.clone()
             for k in range(4):                       # eager warm-up, capture, two replays
                 m.denoise_step_(x, 0, 4, 15, 900 - 10 * k, 890 - 10 * k, False, None)
             outs.append(x.clone())
-        assert torch.equal(outs[0], outs[1])
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
         r = tune_weight_prefetch(m, 1, steps=6, rounds=1)
-        assert r["chosen"] in ("on", "off") and r["on_ms"] > 0 and r["off_ms"] > 0
-        print("weight prefetch on / off (ms per step):", r)
+        assert r["chosen"] in ("on", "off", "per-class") and r["on_ms"] > 0 and r["off_ms"] > 0 and r["tuned_ms"] <= min(r["on_ms"], r["off_ms"])
+        assert r["mode"] == prefetch_mode(tuple(r["classes"][c] for c in ("out", "fc1", "fc2", "qkv")))
+        print("weight prefetch on / off / tuned (ms per step):", r)
+        with pytest.raises(Exception):
+            m.set_weight_prefetch(7)                 # neither 0, 1 nor a per-class word
     finally:
         m.set_weight_prefetch(True)
     m.check()
