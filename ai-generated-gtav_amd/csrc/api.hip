@@ -284,7 +284,10 @@ struct gtav_dit {
     // handles with training enabled keep the split path (the copies are not refreshed by the optimizer).
     bool fuse_tattn = false;
     bool w_prefetch = true;   // L2 prefetch of the next GEMM's weight at small M (gemm.h pf_next)
-    int w_prefetch_cls[4] = {1, 1, 1, 1};   // per consumer class (0 out-proj, 1 fc1, 2 fc2, 3 to_qkv): 0 skip, 1 the whole slice, k >= 2 the first k K tiles (PrefetchDesc::kt_limit)
+    // per consumer class (0 out-proj, 1 fc1, 2 fc2, 3 to_qkv): 0 skip, 1 the whole slice, k >= 2 the first k K tiles (PrefetchDesc::kt_limit).  The default is the
+    // setting that was never slower than no prefetch on any GPU of the round-5 survey (-2 ... -5 % per batch-1 step on every one of them); prefetching every
+    // weight whole is 7-12 % faster on some GPUs and 2-16 % slower on others: generate.tune_weight_prefetch finds it where it pays.
+    int w_prefetch_cls[4] = {1, 4, 4, 1};
     int resid_inplace_min_m = GTAV_ENV_INT("GTAV_RESID_INPLACE_MIN_M", 1 << 30);   // experiments build only
     // ---- LayerNorm fold (docs/LABNOTES.md 4.7; gemm.h EPI_*_FOLD): the LayerNorm + modulate between a residual GEMM and its consumer runs inside the
     // two GEMM epilogues.  Seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection.  Per-frame c1 / c2 tables for every

@@ -670,6 +670,10 @@ def bench_generate(args, world, rank, dev, dist, torch):
     batched = None
     if Bb > 0 and Bb != B:
         binp = leg_inputs(Bb, True, seed=5000)
+        bpf = None
+        if "cached" in algos and 256 <= Bb * P_TOK <= 1536:      # the context-cached step of this leg (Bb x one frame of tokens) is in the prefetch's range: tune it at that size
+            from gtav_amd.generate import tune_weight_prefetch
+            bpf = tune_weight_prefetch(dit, Bb, window=1, use_actions=True, latent_hw=(LH, LW))
         bres = {algo: timed(binp, algo == "cached", args.batched_clips, 1, short_warm=True) for algo in algos}
         broof, bstep, _ = profile_forward(Bb, binp[2])
         broof_c, bstep_c = profile_cached_step(Bb, binp[2]) if "cached" in bres else (None, None)
@@ -678,7 +682,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
                                "%d noise steps, VAE inside the timed region" % (2 if world == 1 else 3, Bb, world, world * Bb, total, n_prompt, steps),
                    "clips_timed": args.batched_clips, "warmup": "1 clip with 2 noise steps (same shapes and hipGraph keys)",
                    "value": round(world * Bb * (total - n_prompt) * args.batched_clips / bel, 4), "unit": "generated frames/s",
-                   "roofline": broof, "dit_step": bstep, "roofline_cached": broof_c, "dit_step_cached": bstep_c}
+                   "roofline": broof, "dit_step": bstep, "roofline_cached": broof_c, "dit_step_cached": bstep_c, "weight_prefetch_cached_step": bpf}
         batched.update(algo_report(Bb, bres, args.batched_clips))
         del binp
 

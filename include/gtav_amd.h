@@ -117,7 +117,7 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
  * synchronises the device; every call drops the captured graphs of the handle.  Ignored on handles with training enabled. */
 int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
 
-/* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (docs/LABNOTES.md 4.10; default ON for steps of 256 ... 1536 tokens).  It changes no
+/* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (docs/LABNOTES.md 4.10; steps of 256 ... 1536 tokens; default: mode 0x11441).  It changes no
  * arithmetic — results are bit-identical under every setting — and what pays depends on the GPU (profiles/round5/prefetch_box_survey.txt): on some MI355X
  * GPUs prefetching every weight takes 7-12 % off a batch-1 step, on others that costs 1-8 % while the to_qkv / out-proj weights alone or the first K
  * tiles of each weight still gain 1-3 %.  So a harness times a few captured steps per setting and keeps the fastest (gtav_amd.generate.tune_weight_prefetch
