@@ -493,18 +493,35 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // 0.6-0.9 us for its prefetch, the consumer gains 1.5-2 us.)
     static const int pf_min_m = GTAV_ENV_INT("GTAV_PF_MIN_M", 256);   // 320 tokens (window step of the 256 x 256-frame preset): -2.1 %; 144 (cached step): +1.5 %; experiments build: A/B
     const bool pf_on = h->w_prefetch && M >= pf_min_m && M <= pf_max_m;
-    auto set_pf = [&](GemmParams& q, const f16* Wn, int Nn, int Kn, int skn, int consumer /* 0 out-proj, 1 fc1, 2 fc2, 3 to_qkv */) {
-        const int v = h->w_prefetch_cls[consumer];      // 0 skip, 1 the whole slice, k >= 2: the first k K tiles of every row tile
-        if (!pf_on || !Wn || !v) return;
-        const int nkt = Kn / 64;
-        if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
-        q.pf = PrefetchDesc{Wn, cdiv(Nn, 128), nkt, skn, v >= 2 ? v : 0};
+    // what the GEMM launch at position `pos` of half-block `hb` (launch order: 0 to_qkv, 1 out-proj, 2 fc1, 3 fc2) prefetches: the weight of the next GEMM
+    // launch of the step.  (One more launch of lead — the weight of the GEMM after the next — was measured in round 5 and gained nothing on either kind
+    // of GPU: profiles/round5/prefetch_box_survey.txt.)
+    struct PfNext { const f16* W; int N, K, sk, consumer; };
+    auto pf_target = [&](int hb, int pos) -> PfNext {
+        const int q = pos + 1, hb2 = hb + q / 4, p2 = q % 4;
+        if (!pf_on || hb2 >= 2 * h->L) return PfNext{nullptr, 0, 0, 1, 0};
+        const gtav_dit::Half& w2 = h->halves[hb2];
+        if (p2 == 0) {
+            const bool fused2 = (hb2 & 1) && h->fuse_tattn && !h->tr.on && w2.w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
+            return PfNext{fused2 ? w2.w_qkv_hm : w2.w_qkv, 3 * D, D, 1, 3};
+        }
+        if (p2 == 1) return PfNext{w2.w_out, D, D, gemm_choose_splitk(M, D, D), 0};
+        if (p2 == 2) return PfNext{w2.w_fc1, h->Hm, D, 1, 1};
+        return PfNext{w2.w_fc2, D, h->Hm_pad, gemm_choose_splitk(M, D, h->Hm_pad), 2};
     };
-    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const f16* Wn = nullptr, int Nn = 0, int Kn = 0) -> int {
+    auto set_pf = [&](GemmParams& q, const PfNext& t) {
+        const int v = h->w_prefetch_cls[t.consumer];      // 0 skip, 1 the whole slice, k >= 2: the first k K tiles of every row tile
+        if (!pf_on || !t.W || !v) return;
+        const int nkt = t.K / 64;
+        int skn = t.sk;
+        if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
+        q.pf = PrefetchDesc{t.W, cdiv(t.N, 128), nkt, skn, v >= 2 ? v : 0};
+    };
+    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const PfNext& pfn) -> int {
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
-        set_pf(q, Wn, Nn, Kn, 1, Nn == 3 * D ? 3 : 1);
+        set_pf(q, pfn);
         q.splitk = gemm_choose_splitk(M, D, K);
         if (gemm_pp_ok(M, D, K, EPI_RESID) || (q.splitk == 1 && M >= h->resid_inplace_min_m) || gemm_resid_inplace_ok(M, D, K, P)) {   // (also on training handles: this plain forward keeps no activations)
             // Large M: gated residual update x += gate * (acc + bias) in the epilogue of the persistent ping-pong GEMM — its
@@ -541,7 +558,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
             if (folded_in) fold_consumer(g, 2 * hb, 3 * D);
-            set_pf(g, w.w_out, D, D, gemm_choose_splitk(M, D, D), 0);
+            set_pf(g, pf_target(hb, 0));
             if (fused_t) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
@@ -562,14 +579,14 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             folded_in = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
-            set_pf(g, w.w_fc2, D, h->Hm_pad, gemm_choose_splitk(M, D, h->Hm_pad), 2);
+            set_pf(g, pf_target(hb, 2));
             if (fold_a) {
                 // seam A: out-proj updates the residual in place and emits fc1's operand + row statistics; fc1 normalises in its epilogue
                 RET_IF(fold_producer(PC_OUT, h->ao, w.w_out, D, w.b_out, mb + 2 * D, mb + 4 * D));
                 fold_consumer(g, 2 * hb + 1, h->Hm);
                 PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH_FOLD, s));
             } else {
-                RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D, w.w_fc1, h->Hm, D));
+                RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D, pf_target(hb, 1)));
                 PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
                 have_pend = false;
                 PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
@@ -580,9 +597,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                 RET_IF(fold_producer(PC_FC2, h->hbuf, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, next_scale));
                 folded_in = true;
             } else {
-                const gtav_dit::Half* nx = hb + 1 < 2 * h->L ? &h->halves[hb + 1] : nullptr;
-                const f16* wq_next = !nx ? nullptr : (hf == 0 && h->fuse_tattn && !h->tr.on && nx->w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0)) ? nx->w_qkv_hm : nx->w_qkv;
-                RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, wq_next, 3 * D, D));
+                RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, pf_target(hb, 3)));
             }
         }
     }
