@@ -144,9 +144,11 @@ def test_skinny_f32(M, N, K, act):
     assert rel_l2(y, ref) < 2e-6
 
 
-@pytest.mark.parametrize("D,M", [(128, 96), (256, 96), (1024, 96), (1024, 2304)])
+@pytest.mark.parametrize("D,M", [(128, 96), (256, 96), (512, 96), (1024, 96), (2048, 160), (1024, 2304), (1024, 1027), (1024, 46080)])
 def test_layernorm_kernels(D, M):
-    P = 32
+    """No pending update: D = 128 runs the one-block-per-row kernel, the others the one-wave-per-row kernel (NV = D / 256 float4 per lane; round 5) — 1027 rows
+    leave a ragged last block, 46 080 are the batched VAE's rows (80 frames)."""
+    P = 32 if M % 32 == 0 else 1
     x = _rand(M, D, seed=1) * 3 + 0.5
     mod = _rand(M // P, 2 * D, seed=2)
     out = torch.zeros((M + 127) // 128 * 128, D, device=dev(), dtype=torch.float16)
@@ -161,6 +163,20 @@ def test_layernorm_kernels(D, M):
     gd, bd = g.to(dev()), b.to(dev())
     L.check(L.load().gtav_op_ln_affine(xd.data_ptr(), out.data_ptr(), M, D, gd.data_ptr(), bd.data_ptr(), stream()))
     assert rel_l2(untile(out, M, D).float(), torch.nn.functional.layer_norm(x, (D,), g, b, eps=1e-6)) < 5e-4
+
+
+@pytest.mark.parametrize("D", [128, 1024])
+def test_layernorm_statistics_with_a_large_mean(D):
+    """The one-pass statistics subtract the row's first element before squaring (both LayerNorm kernels): a row of 300 +- 0.02 must not lose its variance
+    to cancellation (E[x^2] - E[x]^2 in fp32 would: 9e4 against 4e-4)."""
+    M = 64
+    x = 300.0 + 0.02 * _rand(M, D, seed=5)
+    g, b = _rand(D, seed=3) * 0.1 + 1, _rand(D, seed=4) * 0.1
+    out = torch.zeros(128, D, device=dev(), dtype=torch.float16)
+    xd, gd, bd = x.to(dev()), g.to(dev()), b.to(dev())
+    L.check(L.load().gtav_op_ln_affine(xd.data_ptr(), out.data_ptr(), M, D, gd.data_ptr(), bd.data_ptr(), stream()))
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), eps=1e-6)
+    assert rel_l2(untile(out, M, D).float(), ref) < 1e-3
 
 
 @pytest.mark.parametrize("NB,heads,S", [(5, 16, 144), (2, 16, 576), (3, 4, 32), (1, 2, 72), (1, 2, 200), (3, 8, 256), (1, 3, 328), (5, 16, 576), (1, 2, 1152)])

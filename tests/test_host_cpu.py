@@ -304,3 +304,16 @@ def test_oracle_autograd_matches_finite_difference():
         fd = float((loss_at(sp) - loss_at(sm)) / (2 * eps))
         an = float((grads[k] * d).sum())
         assert abs(fd - an) <= 1e-2 * abs(an) + 1e-6, (k, fd, an)
+
+
+def test_prefetch_mode_words():
+    """gtav_amd.generate.prefetch_mode: the per-class words of gtav_dit_set_weight_prefetch (include/gtav_amd.h) — 0 = off, 1 = every weight whole, otherwise
+    0x10000 | nibbles (out-proj, fc1, fc2, to_qkv from bit 0 up)."""
+    from gtav_amd.generate import prefetch_mode, PREFETCH_CLASSES
+    assert PREFETCH_CLASSES == ("out", "fc1", "fc2", "qkv")
+    assert prefetch_mode((0, 0, 0, 0)) == 0 and prefetch_mode((1, 1, 1, 1)) == 1
+    assert prefetch_mode((1, 4, 4, 1)) == 0x11441           # the library's default
+    assert prefetch_mode((1, 0, 0, 0)) == 0x10001 and prefetch_mode((0, 0, 0, 2)) == 0x12000
+    for cls in [(1, 4, 0, 1), (0, 1, 1, 1), (15, 15, 15, 15)]:
+        w = prefetch_mode(cls)
+        assert (w >> 16) == 1 and tuple((w >> (4 * c)) & 15 for c in range(4)) == cls
