@@ -161,6 +161,9 @@ def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
         print("weight prefetch on / off / tuned (ms per step):", r)
         with pytest.raises(Exception):
             m.set_weight_prefetch(7)                 # neither 0, 1 nor a per-class word
+        # the form bench.py uses for the context-cached step of the batched leg: a one-frame window at batch 2 (288 tokens: inside the prefetch's range)
+        r1 = tune_weight_prefetch(m, 2, window=1, steps=4, rounds=1)
+        assert r1["tuned_ms"] > 0 and set(r1["classes"]) == {"out", "fc1", "fc2", "qkv"}
     finally:
         m.set_weight_prefetch(True)
     m.check()
