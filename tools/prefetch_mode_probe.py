@@ -18,14 +18,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--window", type=int, default=0, help="frames in the window (0 = the model's maximum); 1 = the shape of a context-cached step")
+    ap.add_argument("--exp", action="store_true", help="experiments build (reads GTAV_PF_MIN_M: the smallest token count that prefetches)")
     a = ap.parse_args()
+    if a.exp:
+        from gtav_amd import lib as L
+        L.load_experiments()
     import gtav_amd.weights as W
     from gtav_amd.model.dit import DiT
     from gtav_amd.generate import _alphas_cumprod
     dev = torch.device("cuda", 0)
-    model = DiT(depth=16, init_weights=False, max_batch=1)
+    model = DiT(depth=16, init_weights=False, max_batch=a.batch)
     model.load_state_dict(W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0))
-    B, T = 1, model.max_frames
+    B, T = a.batch, (a.window or model.max_frames)
     x0 = (torch.randn(B, T, model.in_channels, model.input_h, model.input_w, generator=torch.Generator().manual_seed(11)) * 0.5).to(dev)
     model.set_schedule(_alphas_cumprod(1e-4))
     steps = a.steps
@@ -51,7 +57,7 @@ def main():
                 best[mode] = min(best[mode], (time.perf_counter() - t0) / steps * 1e3)
     model.check()
     from gtav_amd.generate import tune_weight_prefetch
-    print(json.dumps({"tuner": tune_weight_prefetch(model, 1)}))
+    print(json.dumps({"tuner": tune_weight_prefetch(model, B, window=T)}))
     print(json.dumps({"uuid": torch.cuda.get_device_properties(0).uuid.__str__() if hasattr(torch.cuda.get_device_properties(0), "uuid") else "",
                       "ms_by_out_fc1_fc2_qkv": {"".join(str(v) for v in c): round(best[PM(c)], 4) for c in combos}}))
 
