@@ -550,10 +550,13 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             const float* mb = mod + (size_t)hb * 6 * D;
             // temporal half of a batch-1 window step: QKV projection and attention in one launch, on LayerNorm rows written in
             // (b, 16 positions, frame) tile order
-            const bool fused_t = hf == 1 && h->fuse_tattn && !h->tr.on && w.w_qkv_hm && have_pend && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
-            if (fused_t) { pend.tperm_T = Tq; pend.tperm_P = P; }
+            const bool fused_t = hf == 1 && h->fuse_tattn && !h->tr.on && w.w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
+            if (fused_t) {
+                if (!have_pend) memset(&pend, 0, sizeof(pend));   // no slabs (the residual GEMM before updated in place): the descriptor carries the row permutation only
+                pend.tperm_T = Tq; pend.tperm_P = P;
+            }
             if (!folded_in)
-                PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
+                PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, (have_pend || fused_t) ? &pend : nullptr, h->err_flag, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;

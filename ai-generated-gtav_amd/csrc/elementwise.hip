@@ -667,14 +667,15 @@ static int g_ln_wave_row_min = GTAV_ENV_INT("GTAV_LN_WAVE_ROW_MIN", 0);
         pd_.flags = g_ln_flags;                                                                           \
         pd_.err_flag = err_flag;                                                                          \
         GTAV_REQUIRE(pd_.tperm_T == 0 || (pd_.tperm_P % 16 == 0 && M % (pd_.tperm_T * pd_.tperm_P) == 0), "ln: bad output row permutation"); \
-        if (!pend && pd_.tperm_T == 0 && M >= g_ln_wave_row_min && (D == 256 || D == 512 || D == 1024 || D == 2048)) { \
+        const bool upd_ = pend && pend->parts;   /* a LnPending without slabs carries the output row permutation only */ \
+        if (!upd_ && pd_.tperm_T == 0 && M >= g_ln_wave_row_min && (D == 256 || D == 512 || D == 1024 || D == 2048)) { \
             if (D == 256) LN_WAVE_ROW_(MODE, 1, P0, P1, STRIDE, ROWS, RPM);                               \
             else if (D == 512) LN_WAVE_ROW_(MODE, 2, P0, P1, STRIDE, ROWS, RPM);                          \
             else if (D == 1024) LN_WAVE_ROW_(MODE, 4, P0, P1, STRIDE, ROWS, RPM);                         \
             else LN_WAVE_ROW_(MODE, 8, P0, P1, STRIDE, ROWS, RPM);                                        \
         } else { /* one block per row */                                                                  \
             const dim3 g_(M), b_(round_up(D / 4, 64));                                                    \
-            if (pend) GTAV_LAUNCH((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
+            if (upd_) GTAV_LAUNCH((ln_row_block_kernel<MODE, true>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_); \
             else GTAV_LAUNCH((ln_row_block_kernel<MODE, false>), g_, b_, 0, stream, x, ldx, out, M, D, P0, P1, STRIDE, ROWS, RPM, pd_);     \
         }                                                                                                 \
     } while (0)
@@ -682,7 +683,7 @@ static int g_ln_wave_row_min = GTAV_ENV_INT("GTAV_LN_WAVE_ROW_MIN", 0);
 int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale,
                        int mod_stride, const int* rows, int rows_per_mod, const LnPending* pend, int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && rows_per_mod > 0 && ldo == D, "ln_modulate: D=%d must be %%64, <= 2048, ldo == D", D);
-    GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
+    GTAV_REQUIRE(!pend || !pend->parts || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
                  "ln_modulate: bad pending update");
     LN_DISPATCH(0, shift, scale, mod_stride, rows, rows_per_mod);
     GTAV_CHECK_HIP(hipGetLastError());
@@ -692,7 +693,7 @@ int launch_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const
 int launch_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta,
                      const LnPending* pend, int* err_flag, hipStream_t stream) {
     GTAV_REQUIRE(D % 64 == 0 && D <= 2048 && ldo == D, "ln_affine: D=%d must be %%64, <= 2048, ldo == D", D);
-    GTAV_REQUIRE(!pend || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
+    GTAV_REQUIRE(!pend || !pend->parts || (pend->nsplit >= 1 && pend->nsplit <= 8 && pend->ld % 4 == 0 && (!pend->gate || pend->rows_per_gate > 0)),
                  "ln_affine: bad pending update");
     LN_DISPATCH(1, gamma, beta, 0, (const int*)nullptr, 1);
     GTAV_CHECK_HIP(hipGetLastError());
