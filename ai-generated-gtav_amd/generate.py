@@ -107,8 +107,8 @@ def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps:
     the model on the fastest.  The results are bit-identical under every setting, only the speed differs, and what pays depends on the GPU: on some
     MI355X GPUs prefetching every weight takes 7-12 % off the step; on the others that costs 1-8 % (the prefetched lines are gone before their consumer
     starts and the weight is read twice), but the to_qkv / out-proj weights alone, or the first K tiles of each weight, still take 1-3 % off
-    (profiles/round5/prefetch_box_survey.txt).  First off against on for every weight (`rounds` alternations, `steps` replays each, a fresh capture
-    per switch); then, with `per_class`, one pass over the four weight classes (fc2, fc1, out-proj, to_qkv) trying skip / first 4 K tiles / whole
+    (profiles/round5/prefetch_box_survey.txt).  First off, on for every weight and the library's default against each other (`rounds` alternations, `steps` replays each, a fresh
+    capture per switch); then, with `per_class`, from the fastest of them one pass over the four weight classes (fc2, fc1, out-proj, to_qkv) trying skip / first 4 K tiles / whole
     slice for each while the others stay.  About 0.5 s + 2.5 s at batch 1; synthetic latents.
     Returns {"on_ms", "off_ms", "chosen": "on" | "off" | "per-class", "classes": {...}, "mode", "tuned_ms"} (milliseconds per step)."""
     dev = model.device
@@ -136,12 +136,13 @@ def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps:
         torch.cuda.synchronize(dev)
         return (time.perf_counter() - t0) / steps * 1e3
 
-    on, off = (1, 1, 1, 1), (0, 0, 0, 0)
-    best = {on: float("inf"), off: float("inf")}
+    on, off, safe = (1, 1, 1, 1), (0, 0, 0, 0), (1, 4, 4, 1)      # safe: the library's default (never slower than off on any GPU surveyed)
+    starts = (on, off, safe) if per_class else (on, off)
+    best = {cls: float("inf") for cls in starts}
     for _ in range(rounds):
-        for cls in (on, off):
+        for cls in starts:
             best[cls] = min(best[cls], timed(cls))
-    cur = on if best[on] <= best[off] else off
+    cur = min(starts, key=lambda cls: best[cls])
     cur_ms = best[cur]
     if per_class:
         for c in (2, 1, 0, 3):
