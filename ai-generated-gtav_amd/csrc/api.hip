@@ -2016,6 +2016,44 @@ void gtav_op_gemm_set_stamps(void* buf_dev, int32_t max_blocks) { gemm_set_stamp
 #endif
 void gtav_op_gemm_set_wm(int32_t wm) { gemm_set_wm(wm); }
 
+// Calibration of the in-situ profiler (gtav_dit_profile / gtav_vae_profile): `reps` launches of a one-wave kernel that spins `spin_us` microseconds on the
+// device's own 100 MHz clock, enqueued back to back, each with an event pair attached to its dispatch exactly like a profiled kernel.  Returns the mean event-pair
+// reading and the mean duration the kernel measured itself; their difference is what an attached event pair adds to a kernel's time.
+int gtav_timer_calibrate(int32_t spin_us, int32_t reps, double* event_us_mean, double* device_us_mean, void* stream) {
+    GTAV_REQUIRE(spin_us >= 0 && spin_us <= 1000 && reps >= 1 && reps <= 256 && event_us_mean && device_us_mean, "timer_calibrate: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* dev = nullptr;
+    GTAV_CHECK_HIP(hipMalloc(&dev, sizeof(unsigned long long) * reps));
+    std::vector<hipEvent_t> ev(2 * reps, nullptr);
+    int rc = 0;
+    for (int i = 0; i < 2 * reps && !rc; ++i)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { set_error("timer_calibrate: hipEventCreate failed"); rc = 1; }
+    if (!rc) rc = launch_calib_spin((unsigned long long)spin_us * 100ull, dev, s);   // warm-up (module load), no events
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) { set_error("timer_calibrate: synchronize failed"); rc = 1; }
+    for (int i = 0; i < reps && !rc; ++i) {
+        g_launch_ev[0] = ev[2 * i];
+        g_launch_ev[1] = ev[2 * i + 1];
+        rc = launch_calib_spin((unsigned long long)spin_us * 100ull, dev + i, s);
+        g_launch_ev[0] = nullptr;
+    }
+    std::vector<unsigned long long> ticks(reps, 0);
+    if (!rc && (hipStreamSynchronize(s) != hipSuccess ||
+                hipMemcpy(ticks.data(), dev, sizeof(unsigned long long) * reps, hipMemcpyDeviceToHost) != hipSuccess)) { set_error("timer_calibrate: read-back failed"); rc = 1; }
+    double e = 0, d = 0;
+    for (int i = 0; i < reps && !rc; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { set_error("timer_calibrate: hipEventElapsedTime failed"); rc = 1; break; }
+        e += ms * 1e3;
+        d += (double)ticks[i] * 0.01;
+    }
+    for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
+    (void)hipFree(dev);
+    if (rc) return rc;
+    *event_us_mean = e / reps;
+    *device_us_mean = d / reps;
+    return 0;
+}
+
 int gtav_op_convert_f16(const float* src, int32_t lds, int32_t R, int32_t C, void* dst, int32_t Rp, int32_t Cp, int32_t tiled,
                         void* stream) {
     return launch_convert_pad_f16(src, lds, R, C, (f16*)dst, Rp, Cp, 1.0f, tiled, (hipStream_t)stream);

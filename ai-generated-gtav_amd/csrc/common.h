@@ -200,8 +200,11 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // The same function for the GEMM epilogues (round 5): erf(x / sqrt 2) = z Q(z^2 - 1) with z = x sqrt 2 / 4.5 clamped to [-sqrt 2, sqrt 2] (beyond |x| = 4.5 the
 // polynomial's end value, 1 to 3e-8, stands for erf) and Q a degree-9 minimax polynomial in a variable that spans [-1, 1] (coefficients of order 1: no
 // cancellation in fp32), fitted to the ABSOLUTE error of the GELU value: |error| <= 3.0e-5 for every fp32 x in [-65504, 65504] (tools/gelu_poly_fit.py prints
-// the table and re-measures it), an order of magnitude under the fp16 rounding of the stored activation (4.9e-4 relative) — no sigmoid shortcut, the
-// definition itself.  14 operations per value, all but the clamp as packed fp32 (v_pk_mul / v_pk_fma: two values per instruction): ~7.5 issue slots per value.
+// the table and re-measures it; 7e-6 of it is the fit, the rest the cancellation in hx f + hx where f is near -1) — no sigmoid shortcut, the definition
+// itself.  That is an order of magnitude under the fp16 rounding of the stored activation (4.9e-4 relative) wherever |GELU| >~ 0.06; in the negative
+// tail (x < -4, |GELU| < 1e-4) only the absolute bound holds: the relative error there can exceed 100 % and the sign may flip at magnitudes below 3e-5
+// (tests/test_gpu_ops.py::test_gelu_erf_epilogue_absolute_error pins the bound).  14 operations per value, all but the clamp as packed fp32 (v_pk_mul /
+// v_pk_fma: two values per instruction): ~7.5 issue slots per value.
 constexpr float kGeluErfL = 4.5f;
 constexpr float kGeluErfC[10] = {9.985491633e-01f, -4.911968410e-01f, 3.479329944e-01f, -2.564433515e-01f, 1.821636558e-01f,
                                  -1.155658439e-01f, 6.453407556e-02f, -4.252957553e-02f, 2.962661162e-02f, -9.964072146e-03f};

@@ -647,6 +647,19 @@ __global__ void qkv_head_major_kernel(const f16* __restrict__ src, f16* __restri
     *(uint4*)(dst + tiled_off(nd, kc * 8, D)) = *(const uint4*)(src + tiled_off(ns, kc * 8, D));
 }
 
+// Timer calibration (api.hip gtav_timer_calibrate): ONE wave that spins on s_memrealtime (100 MHz, chip-wide) for `ticks` ticks and writes how long it
+// really ran (device clock, first instruction to last) into dev_ticks[0].  Launched through GTAV_LAUNCH like every profiled kernel, so the difference between
+// the event pair's reading and the device's own figure is the profiler's constant offset (marker packet + completion-signal handling).
+__global__ void calib_spin_kernel(unsigned long long ticks, unsigned long long* __restrict__ dev_ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = t0;
+    while (t1 - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(2);
+        t1 = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0) dev_ticks[0] = t1 - t0;
+}
+
 }  // namespace
 
 // -DGTAV_EXPERIMENTS builds: GTAV_LN_FLAGS (see LnPending::flags)
@@ -764,6 +777,12 @@ int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream) {
 
 int launch_axpy_f32(float* y, const float* x, float alpha, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(axpy_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, y, x, alpha, n);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_calib_spin(unsigned long long ticks, unsigned long long* dev_ticks, hipStream_t stream) {
+    GTAV_LAUNCH(calib_spin_kernel, dim3(1), dim3(64), 0, stream, ticks, dev_ticks);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

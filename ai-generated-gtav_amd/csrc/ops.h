@@ -111,6 +111,8 @@ int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
 // cs[pos][k] = (cos[pos][2k], sin[pos][2k]) for k < 32: the GEMM epilogue's interleaved RoPE table
 int launch_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int npos, hipStream_t stream);
 int launch_add_f32(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
+// timer calibration: one wave spins `ticks` ticks of s_memrealtime (100 MHz) and stores the ticks it really ran in dev_ticks[0]; launched through GTAV_LAUNCH
+int launch_calib_spin(unsigned long long ticks, unsigned long long* dev_ticks, hipStream_t stream);
 int launch_axpy_f32(float* y, const float* x, float alpha, size_t n, hipStream_t stream);   // y += alpha x (x may alias y)
 
 // Conditioning inputs (model/dit.py:96-118,359-364) for `rows` (b, frame) pairs, row r = (r / Tq, r % Tq):

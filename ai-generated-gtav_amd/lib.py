@@ -79,6 +79,7 @@ SIGNATURES = {
     "gtav_dit_set_weight_prefetch": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "gtav_timer_calibrate": [_i, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), _p],
     "gtav_comm_unique_id": [_p],
     "gtav_comm_init": [C.POINTER(_p), _i, _i, _p],
     "gtav_comm_allreduce_f32": [_p, _p, _l, _i, _p],

@@ -46,8 +46,14 @@ class AutoencoderKL(_HipModule):
 
     def __init__(self, latent_dim, input_height=270, input_width=480, patch_size=24, enc_dim=768, enc_depth=6, enc_heads=12,
                  dec_dim=768, dec_depth=6, dec_heads=12, mlp_ratio=4.0, norm_layer=None, use_variational=True,
-                 *, max_frames_per_call=8, init_weights=True, **kwargs):
+                 *, max_frames_per_call=8, grow_frames_per_call=False, init_weights=True, **kwargs):
+        """`max_frames_per_call` (keyword-only, not in the reference) sizes the handle's HBM workspace: encode / decode of more frames run in chunks of that
+        many (frames never interact in the VAE, model/vae.py:306-338).  The workspace costs ~23 MB per frame at ViT-L/20 on 360 x 640 (1.8 GB at 80 frames per
+        call) and the chunk size selects the kernels (from 80 frames per call on: 256 x 256 in-place residual tiles, one flash-attention grid), so results
+        move by ~3e-4 relative L2 between chunk sizes — which is why the cap is the caller's choice.  `grow_frames_per_call=True` lets a larger call re-create
+        the handle with room for it (up to 128 frames) instead of chunking."""
         super().__init__()
+        self._grow = bool(grow_frames_per_call)
         self.input_height, self.input_width, self.patch_size = input_height, input_width, patch_size
         self.seq_h, self.seq_w = input_height // patch_size, input_width // patch_size
         self.seq_len = self.seq_h * self.seq_w
@@ -90,7 +96,7 @@ class AutoencoderKL(_HipModule):
 
     def _ensure(self, n: int):
         want = min(max(n, 1), 128)
-        if want > self._capacity:
+        if want > self._capacity and (self._grow or not self._handle and self._capacity < 1):
             self._capacity = want
             self._free()
         if not self._handle:

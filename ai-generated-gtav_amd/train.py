@@ -231,11 +231,12 @@ def gradient_buckets(dit):
     return buckets
 
 
-def backward_overlapped(dit, v_pred, v_target, world_size: int, comm_stream=None, all_reduce=None):
+def backward_overlapped(dit, v_pred, v_target, world_size: int, comm_stream=None, all_reduce=None, bucket_timings=None):
     """backward_ in phases with the all-reduce (SUM) of each finished bucket enqueued on `comm_stream` while the compute stream differentiates
     the next block (what DDP's bucketed reducer does under accelerate).  `all_reduce(tensor)` defaults to
     torch.distributed.all_reduce (SUM) and may be gtav_amd.comm.Comm.all_reduce_.  The arena then holds the SUM over the ranks and
-    dit.grad_divisor = world_size tells the optimizer (no pass over the arena)."""
+    dit.grad_divisor = world_size tells the optimizer (no pass over the arena).  `bucket_timings` (a list, measurement passes only) receives one
+    (phase, bytes, start event, stop event) per bucket, recorded on the communication stream around its all-reduce."""
     if all_reduce is None:
         import torch.distributed as dist
         all_reduce = lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -255,8 +256,14 @@ def backward_overlapped(dit, v_pred, v_target, world_size: int, comm_stream=None
         ev.record(torch.cuda.current_stream(dit.device))
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(ev)
-            for _, off, cnt in ready:
+            for ph, off, cnt in ready:
+                if bucket_timings is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(comm_stream)
                 all_reduce(arena[off: off + cnt])
+                if bucket_timings is not None:
+                    e1.record(comm_stream)
+                    bucket_timings.append((ph, cnt * 4, e0, e1))
     if world_size > 1:
         torch.cuda.current_stream(dit.device).wait_stream(comm_stream)
     dit.grad_divisor = float(max(1, world_size))
@@ -265,7 +272,8 @@ def backward_overlapped(dit, v_pred, v_target, world_size: int, comm_stream=None
 @torch.inference_mode()
 def training_step(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], target_noise_idx, ctx_noise_idx, ctx_noise, noise, lr: float,
                   weight_decay: float = 0.0, max_grad_norm: float = 1.0, world_size: int = 1, noise_steps: int = 50, n_prompt_frames: int = 4,
-                  noise_abs_max: float = 20.0, clamp_min: float = 1e-6, overlap_all_reduce: bool = True, comm_stream=None, all_reduce=None):
+                  noise_abs_max: float = 20.0, clamp_min: float = 1e-6, overlap_all_reduce: bool = True, comm_stream=None, all_reduce=None,
+                  bucket_timings=None):
     """One optimisation step on a batch of latent clips: for every target frame forward + loss and its backward (train_dit.py:590-680: each
     frame's loss is differentiated inside the frame loop, the gradients add up), gradient all-reduce (bucketed and overlapped with the LAST
     frame's backward pass when world_size > 1), clip, AdamW.  Returns the mean loss over the target frames, a (1,) tensor."""
@@ -275,7 +283,7 @@ def training_step(dit, latents: torch.Tensor, actions: Optional[torch.Tensor], t
 
     def on_frame(k, v_pred, v_target):
         if overlap and k == n_iter - 1:
-            backward_overlapped(dit, v_pred, v_target, world_size, comm_stream, all_reduce)
+            backward_overlapped(dit, v_pred, v_target, world_size, comm_stream, all_reduce, bucket_timings)
         else:
             dit.backward_(v_pred, v_target)
 

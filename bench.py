@@ -37,6 +37,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.time()       # wall clock of this process: the default run must fit the driver's window (--wall-budget)
 
 P_TOK, D_MODEL, DEPTH, HM = 144, 1024, 16, 4096
 # SURVEY.md §8(d) geometry presets.  native: the only geometry the reference's factories support (360x640 frames, VAE patch 20 ->
@@ -151,6 +152,11 @@ def parse_args(argv=None):
     ap.add_argument("--g256-clips", type=int, default=2,
                     help="timed clips of the bounded g256 leg of the default (native-geometry, N = 1) run: BASELINE.json's literal 256x256 frames through "
                          "the SURVEY.md 8(d) preset, batch 1, window algorithm; 0 disables it")
+    ap.add_argument("--wall-budget", type=float, default=420.0,
+                    help="seconds of wall clock the whole run may take: an optional leg (config2 / config3, config4, g256) that would not fit in front of the "
+                         "CPU baseline is skipped and named in the line's `skipped_legs`; the headline leg and the CPU baseline always run")
+    ap.add_argument("--cached-clips", type=int, default=3,
+                    help="timed clips of the context-cached algorithm of the headline leg (--algo both; value = window): bounded, it is an extra, not the headline")
     ap.add_argument("--mode", choices=["generate", "train", "train_step"], default="generate",
                     help="train = BASELINE configs[4]: training forward + loss (train_dit.py:554-650: VAE-encode 5-frame clips, noise, "
                          "one DiT forward over the window, MSE vs the v-target), data-parallel, metric samples/s (not the headline); "
@@ -207,10 +213,9 @@ def bench_train(args, world, rank, dev, dist, torch):
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
+    el = time.perf_counter() - t0           # this rank's time; the barrier behind it and the MAX over ranks make the figure the slowest rank's
     if world > 1:
         dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = t.item()
@@ -281,10 +286,9 @@ def bench_config4(args, world, rank, dev, dist, torch):
         for _ in range(k):
             out = fn()
         torch.cuda.synchronize()
+        el = time.perf_counter() - t0       # (taken before the closing barrier: no collective inside the timing; the MAX over ranks is the slowest rank)
         if world > 1:
             dist.barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
@@ -296,18 +300,31 @@ def bench_config4(args, world, rank, dev, dist, torch):
     t_step, loss_s = timed(step, n)
     t_enc, _ = timed(enc, n)
     applied, skipped, gnorm = tdit.train_stats()
+    # ---- N > 1: one more step with an event pair around every bucket's all-reduce on the communication stream (outside the timed regions): the first SCALE run
+    # then shows which buckets hide behind the backward pass and what the ring reaches per bucket ----
+    buckets_report = None
+    if world > 1:
+        bt = []
+        training_step(tdit, enc(), tact, tgt, ctx, cn, nz, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, world_size=world, bucket_timings=bt)
+        torch.cuda.synchronize()
+        per = [{"after_phase": int(ph), "mbytes": round(nb / 1e6, 1), "ms": round(e0.elapsed_time(e1), 3),
+                "bus_gbps": round(2.0 * (world - 1) / world * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1) if e0.elapsed_time(e1) > 0 else None} for ph, nb, e0, e1 in bt]
+        buckets_report = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "buckets": per,
+                          "sum_ms": round(sum(b["ms"] for b in per), 2), "total_mbytes": round(sum(b["mbytes"] for b in per), 1),
+                          "note": "in-situ: each all-reduce runs on the communication stream beside the backward pass of the blocks still being differentiated; "
+                                  "bus_gbps = 2 (N - 1) / N x bytes / time, the ring's per-link figure (xGMI: ~153 GB/s per link)"}
     fl_dit = TB * dit_forward_flops(5 * P_TOK, 5, 15, 1)
     fl_vae = NF * GEOM["native"]["vae_gflop"][0] * 1e9
     # ---- in-situ per-class kernel times: two profiled encodes + two profiled forwards (outside the timed regions) ----
     vae4.profile(True)
     for _ in range(2):
         enc()
-    vprof = vae4.profile_read()
+    vprof = debias(vae4.profile_read())
     vae4.profile(False)
     tdit.profile(True)
     for _ in range(2):
         forward_loss(tdit, enc(), tact, tgt, ctx, cn, nz)
-    dprof = tdit.profile_read()
+    dprof = debias(tdit.profile_read())
     tdit.profile(False)
     Mv, Md = NF * 576, TB * 5 * P_TOK
     gf = {"vae_qkv": (vprof["gemm_qkv"], 2.0 * Mv * 3072 * 1024, "VAE qkv GEMM + bias / partial-RoPE / head-layout epilogue (N=3072 K=1024)"),
@@ -333,6 +350,8 @@ def bench_config4(args, world, rank, dev, dist, torch):
              "vae_ln_affine": {"us_per_launch": round(vprof["ln_affine"][0] / max(vprof["ln_affine"][1], 1) * 1e3, 2), "launches_per_forward": int(vprof["ln_affine"][1] // 2)},
              "dit_ln_modulate": {"us_per_launch": round(dprof["ln_modulate"][0] / max(dprof["ln_modulate"][1], 1) * 1e3, 2), "launches_per_forward": int(dprof["ln_modulate"][1] // 2)},
              "vae_patchify_embed_quant_ms_per_forward": round(vprof["other"][0] / 2, 3)}
+    if not per_class:
+        raise RuntimeError("bench_config4: the profiler recorded no GEMM launch (gtav_vae_profile / gtav_dit_profile returned empty classes)")
     dom = max(per_class, key=lambda k: per_class[k]["ms_per_forward"])
     (ms_d, n_d), fl_d, desc = gf[dom]
     ach = fl_d / (ms_d / n_d * 1e-3) / 1e12
@@ -342,7 +361,7 @@ def bench_config4(args, world, rank, dev, dist, torch):
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "mfma_busy_pmc": mfma_busy, "traffic_source": tsrc,
                 "avg_launch_us": round(ms_d / n_d * 1e3, 2), "launches_timed": int(n_d), "flops_per_launch": fl_d,
-                "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
+                "timing": "HIP events attached to the dispatch (hipExtLaunchKernel), less the calibrated offset of the pair (timer.bias_us of the line)",
                 "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,
                 "per_class": per_class, "other_classes": other}
     out = {"workload": "BASELINE configs[4] as specified: train_dit.py forward + loss (configs/train_dit_actions.yaml: batch %d per GPU x %d GPU(s), 5-frame 360x640 clips, "
@@ -357,6 +376,7 @@ def bench_config4(args, world, rank, dev, dist, torch):
                           "grad_norm": round(gnorm, 4),
                           "gradient_all_reduce": ("RCCL, world size %d: bucketed all-reduce of the 2.4 GB fp32 gradient arena, overlapped with the backward pass" % world)
                           if world > 1 else "none (one rank)",
+                          "gradient_all_reduce_buckets": buckets_report,
                           "dtype": "fp16 operands, fp32 accumulate / master weights / gradients / AdamW state, loss scale %g" % tdit.loss_scale},
            "vae_encode_80_frames": {"ms": round(t_enc * 1e3, 3), "tflops": round(fl_vae / t_enc / 1e12, 1), "frac_of_mfma_peak": round(fl_vae / t_enc / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                     "frames_per_call": NF},
@@ -442,6 +462,48 @@ def traffic_for(cls, M):
     return ent.get("hbm_bytes_per_launch"), ent.get("mfma_busy"), tj.get("source", "")
 
 
+_TIMER = None
+
+
+def timer_calibration():
+    """Constant offset of the in-situ profiler's readings (HIP events attached to a kernel's dispatch): a one-wave kernel spins a known time on the device's own
+    100 MHz clock under the same attached event pairs (gtav_timer_calibrate, 5 us and 20 us spins, 64 back-to-back launches each): `event_minus_device_us` is what
+    the pair reads beyond the kernel's own figure.  rocprofv3's kernel duration also contains the dispatch ramp (dispatch -> first instruction, last instruction
+    -> completion signal): `rocprof_minus_device_us`, measured by rocprofv3 on the same spin kernel (profiles/timer_calibration.json, tools/timer_calibration.sh).
+    bias_us = event_minus_device_us - rocprof_minus_device_us is subtracted from every per-launch time, which puts them on rocprofv3's scale."""
+    global _TIMER
+    if _TIMER is not None:
+        return _TIMER
+    import ctypes as C
+    from gtav_amd import lib as L
+    import torch
+    out = {}
+    for spin in (5, 20):
+        e, d = C.c_double(0), C.c_double(0)
+        L.check(L.load().gtav_timer_calibrate(spin, 64, C.byref(e), C.byref(d), torch.cuda.current_stream().cuda_stream))
+        out[spin] = (e.value, d.value)
+    off = sum(e - d for e, d in out.values()) / len(out)
+    ramp, src = None, "profiles/timer_calibration.json missing: readings are NOT corrected"
+    tpath = os.path.join(ROOT, "profiles", "timer_calibration.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        ramp, src = tj.get("rocprof_minus_device_us"), tj.get("source", "profiles/timer_calibration.json")
+    bias = max(0.0, off - ramp) if ramp is not None else 0.0
+    _TIMER = {"bias_us": round(bias, 3), "event_minus_device_us": round(off, 3), "rocprof_minus_device_us": ramp,
+              "spin_5us": {"event_us": round(out[5][0], 3), "device_us": round(out[5][1], 3)},
+              "spin_20us": {"event_us": round(out[20][0], 3), "device_us": round(out[20][1], 3)},
+              "method": "every us_per_launch / frac in this line = (event-pair reading - bias_us): the offset of an event pair attached to a dispatch, calibrated on a "
+                        "kernel of known device duration, less the dispatch ramp rocprofv3 counts too", "ramp_source": src}
+    return _TIMER
+
+
+def debias(prof):
+    """Profiler readings {class: (ms summed over n launches, n)} on rocprofv3's scale: the single-kernel classes (events attached to the dispatch) lose
+    timer_calibration()'s bias per launch; "other" and the empty pair are plain event records around several launches and stay as read."""
+    b = timer_calibration()["bias_us"] * 1e-3
+    return {k: ((max(ms - n * b, 0.0), n) if k not in ("other", "empty_event_pair") else (ms, n)) for k, (ms, n) in prof.items()}
+
+
 def bench_generate(args, world, rank, dev, dist, torch):
     global P_TOK
     import gtav_amd.weights as W
@@ -466,7 +528,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
     dit.reserve(Bmax, 5, steps)      # one workspace for both legs: nothing is rebuilt inside a timed region
     vae = None
     if not args.no_vae:
-        nfc = min(32, max(4, Bmax * 4))
+        nfc = min(128, 32 * Bmax)        # frames per VAE call (workspace cap): the 32 frames of a clip in one decode at batch 1, 128-frame chunks at batch 8
         if args.geometry == "native":
             vae = VAE_models["vit-l-20-shallow-encoder"](init_weights=False, max_frames_per_call=nfc)
             vae.load_state_dict(W.synth_state_dict(W.vae_param_shapes(), seed=1))
@@ -501,10 +563,9 @@ def bench_generate(args, world, rank, dev, dist, torch):
         for _ in range(nclips):
             one_clip(inp, cached, steps)
         torch.cuda.synchronize()
+        el = time.perf_counter() - t0       # (taken before the closing barrier: no collective inside the timing; the MAX over ranks is the slowest rank)
         if world > 1:
             dist.barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
@@ -524,7 +585,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
         for _ in range(nprof):
             dit(xw, tw, aw)
         torch.cuda.synchronize()
-        prof = dit.profile_read()
+        prof = debias(dit.profile_read())
         dit.profile(False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -561,8 +622,9 @@ def bench_generate(args, world, rank, dev, dist, torch):
         roofline = {"kernel": "%s, csrc/gemm.hip, M=%d, fp16 MFMA (the GEMM class with the largest time per forward)" % (shape_of[dom], M), "bound": "mfma",
                     "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                     "traffic": traffic, "mfma_busy_pmc": mfma_busy, "traffic_source": tsrc, "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": int(n_d),
-                    "flops_per_launch": gflop[dom], "timing": "HIP events attached to the dispatch (hipExtLaunchKernel)",
-                    "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2),
+                    "flops_per_launch": gflop[dom],
+                    "timing": "HIP events attached to the dispatch (hipExtLaunchKernel), less the calibrated offset of the pair (timer.bias_us of the line)",
+                    "timer_bias_us": timer_calibration()["bias_us"], "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2),
                     "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,
                     "gemm_aggregate_note": "FLOP-weighted over the four GEMM classes: sum of 2 M N K over their launches / sum of their launch times",
                     "worst_class": {"kernel": shape_of[worst], "frac": classes[worst].get("frac_of_mfma_peak")},
@@ -605,7 +667,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
         frame(False)                      # eager warm-up + capture of this key
         graph_ms = min(frame(False), frame(False))
         frame(True)
-        prof = dit.profile_read()
+        prof = debias(dit.profile_read())
         dit.profile(False)
         M = b * P_TOK
         ev_ms, ev_n = prof.pop("empty_event_pair")
@@ -639,14 +701,37 @@ def bench_generate(args, world, rank, dev, dist, torch):
         return roof, {"graph_ms_per_step": round(graph_ms, 4), "tokens": M, "kernel_classes": classes,
                       "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2)}
 
-    def algo_report(b, results, nclips):
+    def algo_report(b, results):
+        """results: algo -> (seconds, clips timed)"""
         out = {}
-        for algo, e in results.items():
+        for algo, (e, nclips) in results.items():
             fl = clip_flops(b, n_prompt, total, steps, 5, algo == "cached") * world
-            out["algo_" + algo] = {"generated_frames_per_s": round(world * b * (total - n_prompt) * nclips / e, 4),
+            out["algo_" + algo] = {"generated_frames_per_s": round(world * b * (total - n_prompt) * nclips / e, 4), "clips_timed": nclips,
                                    "ms_per_clip": round(e / nclips * 1e3, 1), "executed_pflop_per_clip": round(fl / 1e15, 4),
                                    "achieved_tflops_per_gpu": round(fl / world * nclips / e / 1e12, 1)}
         return out
+
+    # ---- wall-clock accounting: every leg's wall time goes into the line; an OPTIONAL leg is skipped when it would push the run past --wall-budget ----
+    leg_wall, skipped_legs = {}, []
+    t_leg = [time.time()]
+
+    def leg_done(name):
+        now = time.time()
+        leg_wall[name] = round(now - t_leg[0], 1)
+        t_leg[0] = now
+
+    CPU_RESERVE = 50.0 if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 5.0
+
+    def fits(name, estimate_s):
+        """rank 0 decides (its clock), every rank follows: an optional leg runs only if it is expected to end before the CPU baseline's reserve"""
+        ok = (time.time() - T_START) + estimate_s + CPU_RESERVE <= args.wall_budget
+        if world > 1:
+            t = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.broadcast(t, src=0)
+            ok = bool(t.item())
+        if not ok:
+            skipped_legs.append({"leg": name, "estimate_s": estimate_s, "elapsed_s": round(time.time() - T_START, 1)})
+        return ok
 
     # ---- the next-weight L2 prefetch pays on some boxes and not on others (bit-identical results either way): time both on this box, keep the faster ----
     prefetch_choice = None
@@ -654,37 +739,48 @@ def bench_generate(args, world, rank, dev, dist, torch):
         from gtav_amd.generate import tune_weight_prefetch
         prefetch_choice = tune_weight_prefetch(dit, B, use_actions=args.use_actions, latent_hw=(LH, LW))
     # ---- headline leg: batch B per GPU (configs[1] by default) ----
+    leg_done("setup_models_and_prefetch_tuner")
     inp = leg_inputs(B, args.use_actions, seed=1000)
     algos = ["window", "cached"] if args.algo == "both" else [args.algo]
-    results = {algo: timed(inp, algo == "cached", args.steps, args.warmup) for algo in algos}
-    head = "window" if "window" in results else algos[0]
-    el = results[head]
+    head = "window" if "window" in algos else algos[0]
+    results = {}
+    for algo in algos:
+        if algo == head:         # the headline: exactly --steps timed clips after --warmup untimed ones
+            results[algo] = (timed(inp, algo == "cached", args.steps, args.warmup), args.steps)
+        else:                    # the extra algorithm: bounded (--cached-clips), one short warm-up clip with the same shapes / graph keys
+            nc = max(1, min(args.steps, args.cached_clips))
+            results[algo] = (timed(inp, algo == "cached", nc, 1, short_warm=True), nc)
+        leg_done("headline_" + algo)
+    el = results[head][0]
     gen_frames = world * B * (total - n_prompt)
     value = gen_frames * args.steps / el
     roofline, dit_step, (xw, tw) = profile_forward(B, inp[2])
     roofline_cached = dit_step_cached = None
     if "cached" in results:
         roofline_cached, dit_step_cached = profile_cached_step(B, inp[2])
+    leg_done("headline_in_situ_profiles")
 
     # ---- batched leg: batch 8 per GPU, action-conditioned (configs[2] at N = 1, configs[3]-shaped at N > 1), bounded ----
     batched = None
-    if Bb > 0 and Bb != B:
+    # (estimate: per algorithm one 2-step warm-up clip + --batched-clips clips of ~20 s window / ~8 s cached at batch 8, + profiles)
+    if Bb > 0 and Bb != B and fits("config2" if world == 1 else "config3", (args.batched_clips * 28.0 + 12.0) * Bb / 8.0):
         binp = leg_inputs(Bb, True, seed=5000)
         bpf = None
         if "cached" in algos and 256 <= Bb * P_TOK <= 1536:      # the context-cached step of this leg (Bb x one frame of tokens) is in the prefetch's range: tune it at that size
             from gtav_amd.generate import tune_weight_prefetch
             bpf = tune_weight_prefetch(dit, Bb, window=1, use_actions=True, latent_hw=(LH, LW))
-        bres = {algo: timed(binp, algo == "cached", args.batched_clips, 1, short_warm=True) for algo in algos}
+        bres = {algo: (timed(binp, algo == "cached", args.batched_clips, 1, short_warm=True), args.batched_clips) for algo in algos}
         broof, bstep, _ = profile_forward(Bb, binp[2])
         broof_c, bstep_c = profile_cached_step(Bb, binp[2]) if "cached" in bres else (None, None)
-        bel = bres["window" if "window" in bres else algos[0]]
+        bel = bres["window" if "window" in bres else algos[0]][0]
         batched = {"workload": "BASELINE configs[%d]: batch %d per GPU x %d GPU(s) = %d sequences, action-conditioned, %d frames (%d prompt), "
                                "%d noise steps, VAE inside the timed region" % (2 if world == 1 else 3, Bb, world, world * Bb, total, n_prompt, steps),
                    "clips_timed": args.batched_clips, "warmup": "1 clip with 2 noise steps (same shapes and hipGraph keys)",
                    "value": round(world * Bb * (total - n_prompt) * args.batched_clips / bel, 4), "unit": "generated frames/s",
                    "roofline": broof, "dit_step": bstep, "roofline_cached": broof_c, "dit_step_cached": bstep_c, "weight_prefetch_cached_step": bpf}
-        batched.update(algo_report(Bb, bres, args.batched_clips))
+        batched.update(algo_report(Bb, bres))
         del binp
+        leg_done("config2" if world == 1 else "config3")
 
     # ---- multi-GPU self-validation (N > 1, outside every timed region): rank 0 recomputes the shard of the LAST rank on its own GPU (same
     # per-GPU batch, same kernels, inputs a function of the global sample ids) for a short clip and requires the all-gathered latents of that
@@ -706,24 +802,49 @@ def bench_generate(args, world, rank, dev, dist, torch):
             if not same:
                 sys.stderr.write("bench.py: SHARD SELF-CHECK FAILED: the gathered latents of rank %d differ from rank 0's recomputation\n" % other)
         dist.barrier()       # (the other ranks only took part in the gather)
+        leg_done("shard_self_check")
+    # ---- N > 1: what the path's one collective costs (outside the timed regions): all-gather of a clip's latents, and of the batched leg's ----
+    multi_gpu = None
+    if world > 1:
+        from gtav_amd.generate import all_gather_latents
+        ag = {}
+        for name, b in (("headline", B), ("batched", Bb)):
+            if b <= 0 or name in ag:
+                continue
+            xl = torch.zeros(b, total, 16, LH, LW, device=dev)
+            all_gather_latents(xl)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                all_gather_latents(xl)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 5 * 1e3
+            ag[name] = {"bytes_per_rank": xl.numel() * 4, "bytes_gathered": xl.numel() * 4 * world, "ms": round(ms, 3),
+                        "bus_gbps": round((world - 1) / world * xl.numel() * 4 * world / (ms * 1e-3) / 1e9, 1)}
+            del xl
+        multi_gpu = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ranks_per_gpu": "one process per GPU (LOCAL_RANK -> cuda:LOCAL_RANK)",
+                     "all_gather_latents": ag, "collectives_per_clip": 1}
+        leg_done("collective_probe")
 
     # ---- bounded config4 leg (every N): BASELINE configs[4] AS SPECIFIED — batch 16 per GPU of 5-frame 360x640 clips, `encode_frames` of the 80 frames
     # INSIDE the timed region (train_dit.py:329-351,570), then forward + loss (train_dit.py:590-650) and, as a second timing, the whole optimisation step
     # (backward, bucketed gradient all-reduce over RCCL when N > 1 — overlapped with the backward pass —, clip, AdamW: SURVEY.md 8(f)1).  Frames are
     # resident in HBM before the region starts; barrier + synchronize on both sides, maximum over ranks ----
     config4 = None
-    if args.config4_steps > 0 and args.geometry == "native":
+    if args.config4_steps > 0 and args.geometry == "native" and fits("config4", 30.0 + 0.4 * args.config4_steps):
         config4 = bench_config4(args, world, rank, dev, dist, torch)
+        leg_done("config4")
 
     # ---- bounded g256 leg (N = 1, native default run only): BASELINE.json's literal "[B, 32 frames, 256x256]" through the SURVEY.md 8(d) preset
     # (VAE patch 16 -> 16x16x16 latents, 64 DiT tokens per frame, DiT-S / ViT-L widths), batch 1, no actions, window algorithm, VAE in the timed region ----
     g256_leg = None
-    if world == 1 and args.geometry == "native" and args.g256_clips > 0 and vae is not None:
+    if world == 1 and args.geometry == "native" and args.g256_clips > 0 and vae is not None and fits("g256", 12.0 + 5.0 * args.g256_clips):
         g2 = GEOM["g256"]
         dit2 = DiT(**g2["dit"], init_weights=False, max_batch=1)
         dit2.load_state_dict(W.synth_state_dict(W.dit_param_shapes(**g2["dit"]), seed=0))
         dit2.reserve(1, 5, steps)
-        vae2 = AutoencoderKL(**g2["vae"], init_weights=False, max_frames_per_call=4)
+        vae2 = AutoencoderKL(**g2["vae"], init_weights=False, max_frames_per_call=32)
         vae2.load_state_dict(W.synth_state_dict(W.vae_param_shapes(**g2["vae"]), seed=1))
         _, fr2, nz2 = shard_inputs(1, 0, 1, n_prompt, total, g2["frame"], g2["lat"], seed=1000)
         fr2, nz2 = fr2.to(dev), nz2.to(dev)
@@ -749,6 +870,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
                     "achieved_tflops_per_gpu": round(fl2 * args.g256_clips / e2 / 1e12, 1), "weight_prefetch": pf2}
         del dit2, vae2, fr2, nz2
         torch.cuda.empty_cache()
+        leg_done("g256")
 
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1) ----
     cpu = None
@@ -787,6 +909,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
                          "(%.3f / %.3f s per frame), extrapolated to %d forwards + %d enc + %d dec" %
                          (nf, t_fwd, t_enc, t_dec, (total - n_prompt) * (steps + 1), n_prompt, total)}
 
+    leg_done("cpu_baseline")
     if rank == 0:
         cfg_name = ("DiT-S/2 (608M) + ViT-L/20 VAE, native 360x640 frames -> 16x18x32 latents" if args.geometry == "native" else
                     "DiT-S/2 widths on a 16x16 latent grid + ViT-L/16 VAE, g256 preset: 256x256 frames -> 16x16x16 latents (SURVEY.md 8(d))")
@@ -807,7 +930,9 @@ def bench_generate(args, world, rank, dev, dist, torch):
             "roofline": roofline, "cpu_baseline": cpu, "dit_step": dit_step,
             "roofline_cached": roofline_cached, "dit_step_cached": dit_step_cached, "weight_prefetch": prefetch_choice,
         }
-        line.update(algo_report(B, results, args.steps))
+        line.update(algo_report(B, results))
+        line["timer"] = timer_calibration()
+        line["wall"] = {"total_s": round(time.time() - T_START, 1), "budget_s": args.wall_budget, "legs_s": leg_wall, "skipped_legs": skipped_legs}
         if batched is not None:
             line["config2" if world == 1 else "config3"] = batched
         if config4 is not None:
@@ -816,6 +941,8 @@ def bench_generate(args, world, rank, dev, dist, torch):
             line["g256"] = g256_leg
         if shard_check is not None:
             line["shard_self_check"] = shard_check
+        if multi_gpu is not None:
+            line["multi_gpu"] = multi_gpu
         print(json.dumps(line))
 
 

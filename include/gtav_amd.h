@@ -136,6 +136,12 @@ int gtav_dit_set_weight_prefetch(gtav_dit* h, int32_t mode);
 int gtav_dit_profile(gtav_dit* h, int32_t enable);
 int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class);
 
+/* Calibration of the in-situ profiler's timer: `reps` back-to-back launches of a one-wave kernel that spins `spin_us` microseconds on the device's own 100 MHz
+ * clock, each with an event pair attached to its dispatch like a profiled kernel.  *event_us_mean = what the event pairs read, *device_us_mean = what the kernel
+ * measured itself; the difference is the constant an attached pair adds (bench.py subtracts it, less the dispatch ramp rocprofv3 also counts).  Allocates,
+ * creates events and synchronises `stream`. */
+int gtav_timer_calibrate(int32_t spin_us, int32_t reps, double* event_us_mean, double* device_us_mean, void* stream);
+
 /* ---- DiT training step ------------------------------------------------------------------------------------
  * Replaces, for the DiT, what train_dit.py does through torch autograd / torch.optim / accelerate:
  *   :649-650 `v_pred = self.dit(x_noisy, t, actions); loss = mse_loss(v_pred[:, -1:], v_target)`  -> gtav_dit_train_forward (+ gtav_mse)

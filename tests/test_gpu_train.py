@@ -229,6 +229,35 @@ def test_full_size_gradients_grouped_weight_gradient_launch(B, T):
     assert max(worst.values()) < GRAD_TOL, worst
 
 
+def test_plain_forward_of_a_trainable_handle_at_large_m_equals_the_inference_handle():
+    """at M >= 3649 tokens the plain forward (gtav_dit_forward) of a TRAINABLE handle takes the in-place residual epilogue of the persistent kernel
+    (EPI_RESID, csrc/api.hip resid_gemm) like an inference handle does — it keeps no activations, so nothing of the training path depends on the slabs — and
+    must return the same bits.  DiT-S/2, B = 8, T = 5 (M = 5 760); forward_train on the same inputs agrees to rounding (it runs the slab path)."""
+    import gtav_amd.weights as W
+    from gtav_amd.model.dit import DiT_models
+    B, T = 8, 5
+    sd = W.synth_state_dict(W.dit_param_shapes(depth=16), seed=0)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, T, 16, 18, 32, generator=g) * 0.6
+    t = torch.randint(0, 1000, (B, T), generator=g)
+    a = torch.zeros(B, T, 25)
+    a[:, :, 3] = 1
+    mi = DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
+    mi.load_state_dict(sd)
+    ref = mi(x, t, a).clone()
+    mi.check()
+    del mi
+    torch.cuda.empty_cache()
+    mt = DiT_models["DiT-S/2"](init_weights=False, max_batch=B, trainable=True)
+    mt.load_state_dict(sd)
+    out = mt(x, t, a).clone()
+    mt.check()
+    assert torch.equal(out, ref)
+    vt = mt.forward_train(x, t, a)
+    assert rel_l2(vt, ref) < 2e-4
+    assert torch.equal(mt(x, t, a), ref)          # the saved activations of forward_train do not disturb a later plain forward
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (1, 5), (5, 5)])
 def test_gradients_other_windows(B, T):
     """Windows of 1, 2 and 5 frames (the temporal attention backward is specialised per window length; T = 1 has one key per query);
