@@ -3,6 +3,7 @@
 #include "../../include/gtav_amd.h"
 #include "../../include/gtav_amd_testing.h"
 #include "ops.h"
+#include "ops_bf16.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -14,6 +15,7 @@
 #include <tuple>
 #include <vector>
 
+namespace gtav_shared { thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr}; }   // common.h GTAV_LAUNCH: the profiler's event pair for the next launch of this thread
 namespace gtav {
 static thread_local char g_err[1024] = "";
 void set_error(const char* fmt, ...) {
@@ -24,6 +26,16 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 }  // namespace gtav
+// the bf16 twin objects (ops_bf16.h) report through the same thread-local string
+namespace gtav_bf16 {
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(gtav::g_err, sizeof(gtav::g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return gtav::g_err; }
+}  // namespace gtav_bf16
 
 using namespace gtav;
 
@@ -32,6 +44,38 @@ using namespace gtav;
         int _rc = (expr);       \
         if (_rc) return _rc;    \
     } while (0)
+
+// ---- the two sets of launchers (ops_bf16.h): fp16 operands (default) and their bf16 twins ----
+namespace {
+const gtav_bf16::GemmParams& bfp(const GemmParams& p) { return reinterpret_cast<const gtav_bf16::GemmParams&>(p); }
+const gtav_bf16::LnPending* bfl(const LnPending* p) { return reinterpret_cast<const gtav_bf16::LnPending*>(p); }
+int f16_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t st, bool qp) { return launch_attn_spatial(Q, K, Vt, O, NB, heads, S, st, qp); }
+int bf_gemm(const GemmParams& p, int epi, hipStream_t st) { return gtav_bf16::launch_gemm(bfp(p), epi, st); }
+int bf_ln_modulate(float* x, int ldx, f16* out, int ldo, int M, int D, const float* shift, const float* scale, int mod_stride, const int* rows, int rpm,
+                   const LnPending* pend, int* ef, hipStream_t st) {
+    return gtav_bf16::launch_ln_modulate(x, ldx, (__bf16*)out, ldo, M, D, shift, scale, mod_stride, rows, rpm, bfl(pend), ef, st);
+}
+int bf_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta, const LnPending* pend, int* ef, hipStream_t st) {
+    return gtav_bf16::launch_ln_affine(x, ldx, (__bf16*)out, ldo, M, D, gamma, beta, bfl(pend), ef, st);
+}
+int bf_patchify(const float* img, const int* fi, int NB, int C, int H, int W, int p, f16* out, int ldo, float a, float b, int* ef, hipStream_t st) {
+    return gtav_bf16::launch_patchify(img, fi, NB, C, H, W, p, (__bf16*)out, ldo, a, b, ef, st);
+}
+int bf_convert_pad(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t st) {
+    return gtav_bf16::launch_convert_pad_f16(src, lds, R, C, (__bf16*)dst, Rp, Cp, scale, tiled, st);
+}
+int bf_unpad(const f16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t st) { return gtav_bf16::launch_unpad_f16_to_f32((const __bf16*)src, lds, R, C, dst, tiled, st); }
+int bf_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t st, bool qp) {
+    return gtav_bf16::launch_attn_spatial((const __bf16*)Q, (const __bf16*)K, (const __bf16*)Vt, (__bf16*)O, NB, heads, S, st, qp);
+}
+int bf_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax, hipStream_t st) {
+    return gtav_bf16::launch_attn_temporal((const __bf16*)q, (const __bf16*)kv, (__bf16*)O, B, P, D, Tq, t0, Tmax, st);
+}
+const OperandOps OPS_F16 = {launch_gemm, launch_ln_modulate, launch_ln_affine, launch_patchify, launch_convert_pad_f16, launch_unpad_f16_to_f32, f16_attn_spatial,
+                            launch_attn_temporal, false};
+const OperandOps OPS_BF16 = {bf_gemm, bf_ln_modulate, bf_ln_affine, bf_patchify, bf_convert_pad, bf_unpad, bf_attn_spatial, bf_attn_temporal, true};
+}  // namespace
+const OperandOps& gtav::operand_ops(bool bf16) { return bf16 ? OPS_BF16 : OPS_F16; }
 
 namespace {
 
@@ -68,12 +112,29 @@ struct Slot {
     float *master = nullptr, *grad = nullptr, *am = nullptr, *av = nullptr;
     f16* wT = nullptr;
     bool trainable = false;
+    // operand type of an f16 slot's device image (common.h "operand type"): the group of layers it belongs to (gtav_dit_set_operand_dtype; -1 = the handle
+    // as a whole) and whether the image is bf16.  A type change un-sets the slot: the caller sends the fp32 weight again.
+    int group = -1;
+    bool bf16 = false;
 };
 
 struct WeightTable {
     std::map<std::string, Slot> slots;
-    void add_f16(const std::string& n, int R, int C, f16* dst, int Rp, int Cp) {
+    void add_f16(const std::string& n, int R, int C, f16* dst, int Rp, int Cp, int group = -1) {
         slots[n] = Slot{SLOT_F16_PAD, R, C, dst, Rp, Cp, 0, false, true};
+        slots[n].group = group;
+    }
+    // operand type of every f16 slot of `group` (-1: all f16 slots): images of the other type are stale -> the slots count as not set
+    int set_dtype(int group, bool bf16) {
+        int changed = 0;
+        for (auto& kv : slots) {
+            Slot& sl = kv.second;
+            if (sl.kind != SLOT_F16_PAD || (group >= 0 && sl.group != group) || sl.bf16 == bf16) continue;
+            sl.bf16 = bf16;
+            sl.set = false;
+            ++changed;
+        }
+        return changed;
     }
     void add_f32(const std::string& n, int R, int C, float* dst, int ldd, int c0 = 0, bool required = true) {
         slots[n] = Slot{SLOT_F32, R, C, dst, R, ldd, c0, false, required};
@@ -84,7 +145,7 @@ struct WeightTable {
         Slot& sl = it->second;
         GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "set_weight: '%s' has %lld elements, expected %d x %d", name,
                      (long long)numel, sl.R, sl.C);
-        if (sl.kind == SLOT_F16_PAD) RET_IF(launch_convert_pad_f16(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, 1, s));
+        if (sl.kind == SLOT_F16_PAD) RET_IF(operand_ops(sl.bf16).convert_pad(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, 1, s));
         else RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, (float*)sl.dst, sl.Cp, sl.c0, s));
         if (sl.master && sl.kind == SLOT_F16_PAD) RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, sl.master, sl.C, 0, s));
         if (sl.wT) RET_IF(launch_convert_T_f16(src, sl.C, sl.R, sl.C, sl.wT, s));
@@ -97,7 +158,7 @@ struct WeightTable {
         Slot& sl = it->second;
         GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "get_weight: '%s' size mismatch", name);
         if (sl.kind == SLOT_F16_PAD && sl.master) RET_IF(launch_copy_f32_strided(sl.master, sl.C, sl.R, sl.C, dst, sl.C, s));   // training: the fp32 master
-        else if (sl.kind == SLOT_F16_PAD) RET_IF(launch_unpad_f16_to_f32((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, 1, s));
+        else if (sl.kind == SLOT_F16_PAD) RET_IF(operand_ops(sl.bf16).unpad((const f16*)sl.dst, sl.Cp, sl.R, sl.C, dst, 1, s));
         else RET_IF(launch_copy_f32_strided((const float*)sl.dst + sl.c0, sl.Cp, sl.R, sl.C, dst, sl.C, s));
         return 0;
     }
@@ -255,7 +316,16 @@ struct gtav_dit {
     std::vector<f16*> kvcache;  // [L]
     float *resid, *fo, *vout, *E, *HC, *Sc, *mod, *parts;
     size_t parts_rows = 0;
+    // device error words: [0] the handle's (bad timestep, non-finite input, training-side saturation), [4 + g] one per operand group g — the fp16 stores of group
+    // g's kernels raise ERR_F16_SAT THERE, so that gtav_dit_autorange can move exactly the saturated layers to bf16 operands
     int* err_flag = nullptr;
+    // operand groups: g = 2 l + (0 spatial | 1 temporal) half of block l, 2 L = patch embedding, 2 L + 1 = final layer.  grp_bf16[g]: the group's 2-byte tensors
+    // (LayerNorm output, q / k / v, attention output, MLP hidden, K/V cache, its GEMM weights) are bf16 instead of fp16 (common.h "operand type")
+    std::vector<unsigned char> grp_bf16;
+    int n_groups = 0;
+    bool any_bf16 = false;
+    const OperandOps& ops(int g) const { return operand_ops(grp_bf16[g] != 0); }
+    int* err_of(int g) const { return err_flag + 4 + g; }
     int* frame_idx = nullptr;   // [maxB * maxT]
     StepParams* step_dev = nullptr;
     int* mod_rows_dev = nullptr;   // [maxB * maxT] rows of the per-frame conditioning table used by the current step
@@ -416,7 +486,7 @@ static int fold_alloc(gtav_dit* h) {
 static void fold_policy(const gtav_dit* h, int M, bool& fa, bool& fb) {
     const gtav_dit::Fold& f = h->fold;
     fa = fb = false;
-    if (!f.ok || f.mode == 0 || h->tr.on || h->fuse_tattn) return;
+    if (!f.ok || f.mode == 0 || h->tr.on || h->fuse_tattn || h->any_bf16) return;
     fa = f.mode == 2 || M >= f.min_m_a;
     fb = f.mode == 2 || M >= f.min_m_b;
 }
@@ -473,11 +543,13 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         PROF(h, cls, s, launch_gemm(q, EPI_RESID_FOLD, s));
         return 0;
     };
-    PROF(h, PC_OTHER, s, launch_patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, h->err_flag, s));
+    const int g_embed = 2 * h->L, g_final = 2 * h->L + 1;      // operand groups (gtav_dit::grp_bf16)
+    // (patchify reports a non-finite input and a finite latent beyond the fp16 range into the embedding group's word: gtav_dit_check folds every word together)
+    PROF(h, PC_OTHER, s, h->ops(g_embed).patchify(x_src, frame_index, NB, h->C, h->H, h->W, h->p, h->xp, h->Kpe, 1.f, 0.f, h->err_of(g_embed), s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kpe; g.W = h->w_pe; g.M = M; g.N = D; g.K = h->Kpe; g.bias = h->b_pe; g.out = h->resid; g.ldo = D;
-    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, h->ops(g_embed).gemm(g, EPI_F32, s));
     // Residual GEMMs (out-proj, fc2) write split-K partial slabs; the LayerNorm that always follows reduces them and
     // applies bias + gate + residual (LnPending), so the GEMM epilogue has no read-modify-write and small-M
     // launches can spread their K loop over all CUs.
@@ -517,7 +589,7 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         if (skn < 1 || nkt % skn || (skn >= 8 ? skn % 8 : 8 % skn)) skn = 1;
         q.pf = PrefetchDesc{t.W, cdiv(t.N, 128), nkt, skn, v >= 2 ? v : 0};
     };
-    auto resid_gemm = [&](int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const PfNext& pfn) -> int {
+    auto resid_gemm = [&](const OperandOps& ops, int cls, const f16* X, int ldx, const f16* Wt, int K, const float* bias, const float* gate, const PfNext& pfn) -> int {
         GemmParams q;
         memset(&q, 0, sizeof(q));
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = D; q.K = K; q.out = h->parts; q.ldo = D;
@@ -530,12 +602,12 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             // resid_inplace_min_m keeps that experiment reachable in the experiments build.)
             q.splitk = 0; q.out = h->resid; q.bias = bias; q.gate = gate; q.gate_stride = h->MODW; q.gate_rows = mod_rows;
             q.rows_per_gate = P;
-            PROF(h, cls, s, launch_gemm(q, EPI_RESID, s));
+            PROF(h, cls, s, ops.gemm(q, EPI_RESID, s));
             have_pend = false;
             return 0;
         }
         GTAV_REQUIRE((size_t)q.splitk * M <= h->parts_rows, "split-K slabs exceed workspace");
-        PROF(h, cls, s, launch_gemm(q, EPI_PARTIAL, s));
+        PROF(h, cls, s, ops.gemm(q, EPI_PARTIAL, s));
         memset(&pend, 0, sizeof(pend));
         pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * D; pend.ld = D; pend.bias = bias;
         pend.gate = gate; pend.gate_stride = h->MODW; pend.gate_rows = mod_rows; pend.rows_per_gate = P;
@@ -547,19 +619,21 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
         for (int hf = 0; hf < 2; ++hf) {
             const int hb = l * 2 + hf;
             const gtav_dit::Half& w = h->halves[hb];
+            const OperandOps& ops = h->ops(hb);     // this half-block's operand type: every 2-byte tensor below lives and dies inside the half-block
+            int* const ef = h->err_of(hb);
             const float* mb = mod + (size_t)hb * 6 * D;
             // temporal half of a batch-1 window step: QKV projection and attention in one launch, on LayerNorm rows written in
             // (b, 16 positions, frame) tile order
-            const bool fused_t = hf == 1 && h->fuse_tattn && !h->tr.on && w.w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
+            const bool fused_t = hf == 1 && h->fuse_tattn && !h->tr.on && !ops.bf16 && w.w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
             if (fused_t) {
                 if (!have_pend) memset(&pend, 0, sizeof(pend));   // no slabs (the residual GEMM before updated in place): the descriptor carries the row permutation only
                 pend.tperm_T = Tq; pend.tperm_P = P;
             }
             if (!folded_in)
-                PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, (have_pend || fused_t) ? &pend : nullptr, h->err_flag, s));
+                PROF(h, PC_LN, s, ops.ln_modulate(h->resid, D, h->xn, D, M, D, mb, mb + D, h->MODW, mod_rows, P, (have_pend || fused_t) ? &pend : nullptr, ef, s));
             have_pend = false;
             memset(&g, 0, sizeof(g));
-            g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = h->err_flag;
+            g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = ef;
             if (folded_in) fold_consumer(g, 2 * hb, 3 * D);
             set_pf(g, pf_target(hb, 0));
             if (fused_t) {
@@ -575,13 +649,13 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                     g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT;
                     g.rope_cs = h->rope_t.cs_dev;
                 }
-                PROF(h, PC_QKV, s, launch_gemm(g, folded_in ? EPI_QKV_FOLD : EPI_QKV, s));
-                if (hf == 0) PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s));
-                else PROF(h, PC_ATTN_T, s, launch_attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
+                PROF(h, PC_QKV, s, ops.gemm(g, folded_in ? EPI_QKV_FOLD : EPI_QKV, s));
+                if (hf == 0) PROF(h, PC_ATTN_S, s, ops.attn_spatial(h->qs, h->ks, h->vts, h->ao, NB, h->heads, P, s, false));
+                else PROF(h, PC_ATTN_T, s, ops.attn_temporal(h->qt, h->kvcache[l], h->ao, B, P, D, Tq, t0, h->maxT, s));
             }
             folded_in = false;
             memset(&g, 0, sizeof(g));
-            g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = h->err_flag;
+            g.X = h->xn; g.ldx = D; g.W = w.w_fc1; g.M = M; g.N = h->Hm; g.K = D; g.bias = w.b_fc1; g.out = h->hbuf; g.ldo = h->Hm_pad; g.err_flag = ef;
             set_pf(g, pf_target(hb, 2));
             if (fold_a) {
                 // seam A: out-proj updates the residual in place and emits fc1's operand + row statistics; fc1 normalises in its epilogue
@@ -589,10 +663,10 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                 fold_consumer(g, 2 * hb + 1, h->Hm);
                 PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH_FOLD, s));
             } else {
-                RET_IF(resid_gemm(PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D, pf_target(hb, 1)));
-                PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
+                RET_IF(resid_gemm(ops, PC_OUT, h->ao, D, w.w_out, D, w.b_out, mb + 2 * D, pf_target(hb, 1)));
+                PROF(h, PC_LN, s, ops.ln_modulate(h->resid, D, h->xn, D, M, D, mb + 3 * D, mb + 4 * D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, ef, s));
                 have_pend = false;
-                PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_TANH, s));
+                PROF(h, PC_FC1, s, ops.gemm(g, EPI_GELU_TANH, s));
             }
             if (fold_b) {
                 // seam B: the LayerNorm that follows fc2 is the next half-block's first one (scale_msa) or the final layer's
@@ -600,17 +674,17 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
                 RET_IF(fold_producer(PC_FC2, h->hbuf, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, next_scale));
                 folded_in = true;
             } else {
-                RET_IF(resid_gemm(PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, pf_target(hb, 3)));
+                RET_IF(resid_gemm(ops, PC_FC2, h->hbuf, h->Hm_pad, w.w_fc2, h->Hm_pad, w.b_fc2, mb + 5 * D, pf_target(hb, 3)));
             }
         }
     }
     const float* mf = mod + (size_t)h->L * 12 * D;
     if (!folded_in)
-        PROF(h, PC_LN, s, launch_ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_flag, s));
+        PROF(h, PC_LN, s, h->ops(g_final).ln_modulate(h->resid, D, h->xn, D, M, D, mf, mf + D, h->MODW, mod_rows, P, have_pend ? &pend : nullptr, h->err_of(g_final), s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = D; g.W = h->w_final; g.M = M; g.N = h->Nfin; g.K = D; g.bias = h->b_final; g.out = h->fo; g.ldo = h->Nfin;
     if (folded_in) fold_consumer(g, 4 * h->L, h->Nfin);
-    PROF(h, PC_OTHER, s, launch_gemm(g, folded_in ? EPI_F32_FOLD : EPI_F32, s));
+    PROF(h, PC_OTHER, s, h->ops(g_final).gemm(g, folded_in ? EPI_F32_FOLD : EPI_F32, s));
     PROF(h, PC_OTHER, s, launch_unpatchify(h->fo, h->Nfin, v_out, NB, h->C, h->H, h->W, h->p, 0, 1.f, 0.f, s));
     PROF(h, PC_EMPTY, s, 0);   // an event pair around nothing: the per-pair overhead to subtract from every class
     return h->prof.collect(s);
@@ -653,7 +727,9 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     int rc = 0;
 #define A_(expr) do { if (!rc) rc = (expr); } while (0)
     A_(a.alloc_t(&h->w_pe, (size_t)round_up(D, 128) * h->Kpe));
-    wt.add_f16("x_embedder.proj.weight", D, h->C * h->p * h->p, h->w_pe, round_up(D, 128), h->Kpe);
+    h->n_groups = 2 * h->L + 2;
+    h->grp_bf16.assign(h->n_groups, 0);
+    wt.add_f16("x_embedder.proj.weight", D, h->C * h->p * h->p, h->w_pe, round_up(D, 128), h->Kpe, 2 * h->L);
     A_(a.alloc_t(&h->b_pe, D)); wt.add_f32("x_embedder.proj.bias", 1, D, h->b_pe, D);
     A_(a.alloc_t(&h->w_t0, (size_t)D * 256)); wt.add_f32("t_embedder.mlp.0.weight", D, 256, h->w_t0, 256);
     A_(a.alloc_t(&h->b_t0, D)); wt.add_f32("t_embedder.mlp.0.bias", 1, D, h->b_t0, D);
@@ -673,20 +749,21 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
             char pre[64];
             snprintf(pre, sizeof(pre), "blocks.%d.%c_", l, hf == 0 ? 's' : 't');
             std::string P_(pre);
-            A_(a.alloc_t(&w.w_qkv, (size_t)3 * D * D)); wt.add_f16(P_ + "attn.to_qkv.weight", 3 * D, D, w.w_qkv, 3 * D, D);
+            const int grp = l * 2 + hf;
+            A_(a.alloc_t(&w.w_qkv, (size_t)3 * D * D)); wt.add_f16(P_ + "attn.to_qkv.weight", 3 * D, D, w.w_qkv, 3 * D, D, grp);
             w.w_qkv_hm = nullptr;   // allocated by gtav_dit_set_fused_temporal(h, 1)
-            A_(a.alloc_t(&w.w_out, (size_t)D * D)); wt.add_f16(P_ + "attn.to_out.weight", D, D, w.w_out, D, D);
+            A_(a.alloc_t(&w.w_out, (size_t)D * D)); wt.add_f16(P_ + "attn.to_out.weight", D, D, w.w_out, D, D, grp);
             A_(a.alloc_t(&w.b_out, D)); wt.add_f32(P_ + "attn.to_out.bias", 1, D, w.b_out, D);
-            A_(a.alloc_t(&w.w_fc1, (size_t)h->Hm_pad * D)); wt.add_f16(P_ + "mlp.fc1.weight", h->Hm, D, w.w_fc1, h->Hm_pad, D);
+            A_(a.alloc_t(&w.w_fc1, (size_t)h->Hm_pad * D)); wt.add_f16(P_ + "mlp.fc1.weight", h->Hm, D, w.w_fc1, h->Hm_pad, D, grp);
             A_(a.alloc_t(&w.b_fc1, h->Hm_pad)); wt.add_f32(P_ + "mlp.fc1.bias", 1, h->Hm, w.b_fc1, h->Hm);
-            A_(a.alloc_t(&w.w_fc2, (size_t)D * h->Hm_pad)); wt.add_f16(P_ + "mlp.fc2.weight", D, h->Hm, w.w_fc2, D, h->Hm_pad);
+            A_(a.alloc_t(&w.w_fc2, (size_t)D * h->Hm_pad)); wt.add_f16(P_ + "mlp.fc2.weight", D, h->Hm, w.w_fc2, D, h->Hm_pad, grp);
             A_(a.alloc_t(&w.b_fc2, D)); wt.add_f32(P_ + "mlp.fc2.bias", 1, D, w.b_fc2, D);
             const size_t row0 = (size_t)(l * 2 + hf) * 6 * D;
             wt.add_f32(P_ + "adaLN_modulation.1.weight", 6 * D, D, h->w_ada + row0 * D, D);
             wt.add_f32(P_ + "adaLN_modulation.1.bias", 1, 6 * D, h->b_ada + row0, 6 * D);
         }
     A_(a.alloc_t(&h->w_final, (size_t)round_up(h->Nfin, 128) * D));
-    wt.add_f16("final_layer.linear.weight", h->Nfin, D, h->w_final, round_up(h->Nfin, 128), D);
+    wt.add_f16("final_layer.linear.weight", h->Nfin, D, h->w_final, round_up(h->Nfin, 128), D, 2 * h->L + 1);
     A_(a.alloc_t(&h->b_final, round_up(h->Nfin, 128))); wt.add_f32("final_layer.linear.bias", 1, h->Nfin, h->b_final, h->Nfin);
     {
         const size_t row0 = (size_t)h->L * 12 * D;
@@ -716,7 +793,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     A_(a.alloc_t(&h->parts, h->parts_rows * D));
     const size_t R = h->max_rows;
     A_(a.alloc_t(&h->E, R * 256)); A_(a.alloc_t(&h->HC, R * ldhc)); A_(a.alloc_t(&h->Sc, R * D)); A_(a.alloc_t(&h->mod, R * h->MODW));
-    A_(a.alloc_t(&h->err_flag, 4)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
+    A_(a.alloc_t(&h->err_flag, 4 + h->n_groups)); A_(a.alloc_t(&h->frame_idx, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->ac_table, 1000));
     A_(a.alloc_t(&h->step_dev, 4)); A_(a.alloc_t(&h->mod_rows_dev, (size_t)h->maxB * h->maxT));
     A_(a.alloc_t(&h->mod_cur, (size_t)h->maxB * h->maxT * h->MODW)); A_(a.alloc_t(&h->mod_last, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->mod_changed, (size_t)h->maxB * h->maxT)); A_(a.alloc_t(&h->t_steps_dev, 1024));
     h->use_graph = GTAV_ENV_INT("GTAV_GRAPH", 1) != 0;   // the shipped library reads no environment: gtav_dit_set_graph() is the switch
@@ -1034,6 +1111,7 @@ int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by
 int gtav_dit_train_enable(gtav_dit* h, float* grad_arena_dev, int64_t grad_arena_numel) {
     GTAV_REQUIRE(h, "train_enable: null handle");
     GTAV_REQUIRE(!h->tr.on, "train_enable: already enabled");
+    GTAV_REQUIRE(!h->any_bf16, "train_enable: the training step runs on fp16 operands (gtav_dit_set_operand_dtype(h, -1, GTAV_OPERAND_F16) first)");
     for (auto& kv : h->wt.slots) GTAV_REQUIRE(!kv.second.set, "train_enable: call it before any gtav_dit_set_weight (the fp32 masters are filled by set_weight)");
     gtav_dit::Train& t = h->tr;
     Arena& a = h->arena;
@@ -1558,13 +1636,79 @@ int gtav_dit_train_stats(gtav_dit* h, float* out4_host, void* stream) {
     return 0;
 }
 
+// the handle's error words (gtav_dit::err_flag): copied back, cleared on the device; `words` gets 4 + n_groups ints
+static int dit_read_err_words(gtav_dit* h, std::vector<int>& words, hipStream_t s) {
+    words.assign(4 + h->n_groups, 0);
+    GTAV_CHECK_HIP(hipMemcpyAsync(words.data(), h->err_flag, words.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    GTAV_CHECK_HIP(hipStreamSynchronize(s));
+    GTAV_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, words.size() * sizeof(int), s));
+    return 0;
+}
+
 int gtav_dit_check(gtav_dit* h, void* stream) {
     GTAV_REQUIRE(h, "dit_check: null handle");
-    int flag = 0;
-    GTAV_CHECK_HIP(hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    GTAV_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-    GTAV_CHECK_HIP(hipMemsetAsync(h->err_flag, 0, sizeof(int), (hipStream_t)stream));
+    std::vector<int> w;
+    RET_IF(dit_read_err_words(h, w, (hipStream_t)stream));
+    int flag = w[0];
+    for (int g = 0; g < h->n_groups; ++g) flag |= w[4 + g];
     return report_err_flag(flag, "DiT");
+}
+
+static void dit_drop_graphs(gtav_dit* h) {
+    for (auto& kv : h->graphs)
+        if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+int gtav_dit_set_operand_dtype(gtav_dit* h, int32_t group, int32_t dtype) {
+    GTAV_REQUIRE(h, "dit_set_operand_dtype: null handle");
+    GTAV_REQUIRE(dtype == GTAV_OPERAND_F16 || dtype == GTAV_OPERAND_BF16, "dit_set_operand_dtype: dtype %d (0 = fp16, 1 = bf16)", dtype);
+    GTAV_REQUIRE(group >= -1 && group < h->n_groups, "dit_set_operand_dtype: group %d outside [-1, %d)", group, h->n_groups);
+    GTAV_REQUIRE(!h->tr.on || dtype == GTAV_OPERAND_F16, "dit_set_operand_dtype: a training handle keeps fp16 operands (its backward pass and loss scaling are fp16)");
+    int changed = 0;
+    for (int g = (group < 0 ? 0 : group); g < (group < 0 ? h->n_groups : group + 1); ++g) {
+        if ((h->grp_bf16[g] != 0) == (dtype == GTAV_OPERAND_BF16)) continue;
+        h->grp_bf16[g] = dtype == GTAV_OPERAND_BF16;
+        changed += 1 + h->wt.set_dtype(g, dtype == GTAV_OPERAND_BF16);
+    }
+    if (changed) {
+        // the weight images of the changed groups are of the other type now: the caller sends those weights again (gtav_dit_set_weight) and finalizes;
+        // captured steps hold the other kernels; the temporal K/V caches of a switched half hold the other encoding
+        h->finalized = false;
+        h->kvrec.valid = false;
+        dit_drop_graphs(h);
+    }
+    h->any_bf16 = false;
+    for (unsigned char b : h->grp_bf16) h->any_bf16 |= b != 0;
+    return 0;
+}
+
+int gtav_dit_get_operand_dtype(gtav_dit* h, int32_t group, int32_t* dtype) {
+    GTAV_REQUIRE(h && dtype && group >= 0 && group < h->n_groups, "dit_get_operand_dtype: bad argument (group %d of %d)", group, h ? h->n_groups : 0);
+    *dtype = h->grp_bf16[group] ? GTAV_OPERAND_BF16 : GTAV_OPERAND_F16;
+    return 0;
+}
+
+int gtav_dit_operand_groups(gtav_dit* h, int32_t* n_groups) {
+    GTAV_REQUIRE(h && n_groups, "dit_operand_groups: null argument");
+    *n_groups = h->n_groups;
+    return 0;
+}
+
+int gtav_dit_autorange(gtav_dit* h, int32_t* n_switched, void* stream) {
+    GTAV_REQUIRE(h && n_switched, "dit_autorange: null argument");
+    *n_switched = 0;
+    std::vector<int> w;
+    RET_IF(dit_read_err_words(h, w, (hipStream_t)stream));
+    int other = w[0];
+    for (int g = 0; g < h->n_groups; ++g) {
+        other |= w[4 + g] & ~ERR_F16_SAT;
+        if ((w[4 + g] & ERR_F16_SAT) && !h->grp_bf16[g]) {
+            RET_IF(gtav_dit_set_operand_dtype(h, g, GTAV_OPERAND_BF16));
+            *n_switched += 1;
+        }
+    }
+    return report_err_flag(other, "DiT");
 }
 
 }  // extern "C"
@@ -1587,6 +1731,7 @@ struct gtav_vae {
     int* err_flag = nullptr;
     size_t parts_rows = 0;
     bool finalized = false;
+    const OperandOps* ops = &operand_ops(false);   // operand type of every 2-byte tensor of the handle (gtav_vae_set_operand_dtype; common.h "operand type")
     Profiler prof;   // gtav_vae_profile: per-class dispatch-attached events (bench.py's config4 roofline)
 };
 
@@ -1604,37 +1749,37 @@ static int vae_blocks(gtav_vae* h, std::vector<gtav_vae::Block>& blocks, int dim
         q.X = X; q.ldx = ldx; q.W = Wt; q.M = M; q.N = dim; q.K = K; q.out = h->parts; q.ldo = dim;
         if (gemm_resid_inplace_ok(M, dim, K, 0)) {   // large M: in-place residual epilogue of the persistent loader-wave kernel (see dit_forward_core): no slab round trip
             q.out = h->resid; q.bias = bias;
-            PROF(h, cls, s, launch_gemm(q, EPI_RESID, s));
+            PROF(h, cls, s, h->ops->gemm(q, EPI_RESID, s));
             have_pend = false;
             return 0;
         }
         q.splitk = gemm_choose_splitk(M, dim, K);
         GTAV_REQUIRE((size_t)q.splitk * M * dim <= h->parts_rows * (size_t)h->Dmax, "split-K slabs exceed workspace");
-        PROF(h, cls, s, launch_gemm(q, EPI_PARTIAL, s));
+        PROF(h, cls, s, h->ops->gemm(q, EPI_PARTIAL, s));
         memset(&pend, 0, sizeof(pend));
         pend.parts = h->parts; pend.nsplit = q.splitk; pend.slab_stride = (size_t)M * dim; pend.ld = dim; pend.bias = bias;
         have_pend = true;
         return 0;
     };
     for (auto& b : blocks) {
-        PROF(h, PC_LN, s, launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, h->err_flag, s));
+        PROF(h, PC_LN, s, h->ops->ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g1, b.b1, have_pend ? &pend : nullptr, h->err_flag, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_qkv; g.M = M; g.N = 3 * dim; g.K = dim; g.bias = b.b_qkv; g.D = dim; g.S = h->S;
         g.qkv_mode = QKV_SPATIAL; g.q = h->q; g.k = h->k; g.v = h->vt; g.rope_cs = rope.cs_dev; g.err_flag = h->err_flag;
         const bool qps = attn_spatial_wants_prescaled_q(h->S);   // long sequences: q leaves the epilogue in the exponent's unit of the flash attention kernel
         g.rope_cs_q = qps ? rope.csq_dev : nullptr;
-        PROF(h, PC_QKV, s, launch_gemm(g, EPI_QKV, s));
-        PROF(h, PC_ATTN_S, s, launch_attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s, qps));
+        PROF(h, PC_QKV, s, h->ops->gemm(g, EPI_QKV, s));
+        PROF(h, PC_ATTN_S, s, h->ops->attn_spatial(h->q, h->k, h->vt, h->ao, N, heads, h->S, s, qps));
         RET_IF(resid_gemm(PC_OUT, h->ao, dim, b.w_proj, dim, b.b_proj));
-        PROF(h, PC_LN, s, launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, h->err_flag, s));
+        PROF(h, PC_LN, s, h->ops->ln_affine(h->resid, dim, h->xn, dim, M, dim, b.g2, b.b2, have_pend ? &pend : nullptr, h->err_flag, s));
         have_pend = false;
         memset(&g, 0, sizeof(g));
         g.X = h->xn; g.ldx = dim; g.W = b.w_fc1; g.M = M; g.N = Hm; g.K = dim; g.bias = b.b_fc1; g.out = h->hbuf; g.ldo = Hm_pad; g.err_flag = h->err_flag;
-        PROF(h, PC_FC1, s, launch_gemm(g, EPI_GELU_ERF, s));
+        PROF(h, PC_FC1, s, h->ops->gemm(g, EPI_GELU_ERF, s));
         RET_IF(resid_gemm(PC_FC2, h->hbuf, Hm_pad, b.w_fc2, Hm_pad, b.b_fc2));
     }
-    PROF(h, PC_LN, s, launch_ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, h->err_flag, s));
+    PROF(h, PC_LN, s, h->ops->ln_affine(h->resid, dim, h->xn, dim, M, dim, g_last, b_last, have_pend ? &pend : nullptr, h->err_flag, s));
     return 0;
 }
 
@@ -1766,15 +1911,15 @@ int gtav_vae_encode(gtav_vae* h, const float* img, float in_scale, float in_shif
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_encode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int De = h->cfg.enc_dim, M = N * h->S;
-    PROF(h, PC_OTHER, s, launch_patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, h->err_flag, s));
+    PROF(h, PC_OTHER, s, h->ops->patchify(img, nullptr, N, 3, h->H, h->W, h->p, h->xp, h->Kp, in_scale, in_shift, h->err_flag, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->xp; g.ldx = h->Kp; g.W = h->w_patch; g.M = M; g.N = De; g.K = h->Kp; g.bias = h->b_patch; g.out = h->resid; g.ldo = De;
-    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, h->ops->gemm(g, EPI_F32, s));
     RET_IF(vae_blocks(h, h->enc, De, h->cfg.enc_heads, h->rope_e, N, h->g_enc, h->be_enc, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = De; g.W = h->w_quant; g.M = M; g.N = h->Mom; g.K = De; g.bias = h->b_quant; g.out = moments; g.ldo = h->Mom;
-    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, h->ops->gemm(g, EPI_F32, s));
     if (h->cfg.use_variational) PROF(h, PC_OTHER, s, launch_clamp_cols(moments, M, h->Mom, h->Lat, h->Mom, -30.f, 20.f, s));
     if (h->prof.on) {
         RET_IF(h->prof.begin(PC_EMPTY, s));
@@ -1790,15 +1935,15 @@ int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, floa
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_decode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int Dd = h->cfg.dec_dim, M = N * h->S;
-    PROF(h, PC_OTHER, s, launch_convert_pad_f16(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s));
+    PROF(h, PC_OTHER, s, h->ops->convert_pad(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->zin; g.ldx = 64; g.W = h->w_post; g.M = M; g.N = Dd; g.K = 64; g.bias = h->b_post; g.out = h->resid; g.ldo = Dd;
-    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, h->ops->gemm(g, EPI_F32, s));
     RET_IF(vae_blocks(h, h->dec, Dd, h->cfg.dec_heads, h->rope_d, N, h->g_dec, h->be_dec, s));
     memset(&g, 0, sizeof(g));
     g.X = h->xn; g.ldx = Dd; g.W = h->w_pred; g.M = M; g.N = h->Npred; g.K = Dd; g.bias = h->b_pred; g.out = h->po; g.ldo = h->Npred;
-    PROF(h, PC_OTHER, s, launch_gemm(g, EPI_F32, s));
+    PROF(h, PC_OTHER, s, h->ops->gemm(g, EPI_F32, s));
     PROF(h, PC_OTHER, s, launch_unpatchify(h->po, h->Npred, img, N, 3, h->H, h->W, h->p, 1, out_scale, out_shift, s));
     if (h->prof.on) {
         RET_IF(h->prof.begin(PC_EMPTY, s));
@@ -1817,6 +1962,23 @@ int gtav_vae_profile(gtav_vae* h, int32_t enable) {
 int gtav_vae_profile_read(gtav_vae* h, double* ms_by_class, int64_t* launches_by_class) {
     GTAV_REQUIRE(h && ms_by_class && launches_by_class, "vae_profile_read: null argument");
     for (int i = 0; i < PC_COUNT; ++i) { ms_by_class[i] = h->prof.ms[i]; launches_by_class[i] = h->prof.n[i]; }
+    return 0;
+}
+
+int gtav_vae_set_operand_dtype(gtav_vae* h, int32_t dtype) {
+    GTAV_REQUIRE(h, "vae_set_operand_dtype: null handle");
+    GTAV_REQUIRE(dtype == GTAV_OPERAND_F16 || dtype == GTAV_OPERAND_BF16, "vae_set_operand_dtype: dtype %d (0 = fp16, 1 = bf16)", dtype);
+    const bool bf = dtype == GTAV_OPERAND_BF16;
+    if (h->ops->bf16 != bf) {
+        h->ops = &operand_ops(bf);
+        h->wt.set_dtype(-1, bf);      // every weight image is of the other type now: send the weights again, then finalize
+        h->finalized = false;
+    }
+    return 0;
+}
+int gtav_vae_get_operand_dtype(gtav_vae* h, int32_t* dtype) {
+    GTAV_REQUIRE(h && dtype, "vae_get_operand_dtype: null argument");
+    *dtype = h->ops->bf16 ? GTAV_OPERAND_BF16 : GTAV_OPERAND_F16;
     return 0;
 }
 

@@ -112,8 +112,8 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __r
             const char* kr = Ks + key * 128;
             const f16x8 k0 = *(const f16x8*)(kr + (((0 + g) ^ (key & 7)) << 4));
             const f16x8 k1 = *(const f16x8*)(kr + (((4 + g) ^ (key & 7)) << 4));
-            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[1], sc[kt], 0, 0, 0);
+            sc[kt] = mfma16(k0, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            sc[kt] = mfma16(k1, qf[1], sc[kt], 0, 0, 0);
         }
         // padded keys (only the last tiles can hold any) never win the maximum and contribute exp2(-inf) = 0
         float bmax = -INFINITY;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __r
                 union { f16x8 v8; f16x4 v4[2]; } vf;
                 vf.v4[0] = *(const f16x4*)(vr);
                 vf.v4[1] = *(const f16x4*)(vr + 32);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v8, pf, o[dt], 0, 0, 0);
+                o[dt] = mfma16(vf.v8, pf, o[dt], 0, 0, 0);
             }
         }
         float lt = psum + __shfl_xor(psum, 16, 64);
@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
             const f16x8 k1 = *(const f16x8*)(sb + (kt >> 1) * 4096 + koff[kt & 1][1]);
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
-                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[qt][0], cin[qt], 0, 0, 0);
-                sc[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[qt][1], sc[qt][kt], 0, 0, 0);
+                sc[qt][kt] = mfma16(k0, qf[qt][0], cin[qt], 0, 0, 0);
+                sc[qt][kt] = mfma16(k1, qf[qt][1], sc[qt][kt], 0, 0, 0);
             }
         }
         if constexpr (RAGGED) {
@@ -421,10 +421,10 @@ __global__ __launch_bounds__(256, OCC) void attn_flash_kernel(const f16* __restr
             for (int dt = 0; dt < 4; ++dt) {
                 const f16x8 vf = *(const f16x8*)(sb + dt * 2048 + voff[s2]);
 #pragma unroll
-                for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt], o[qt][dt], 0, 0, 0);
+                for (int qt = 0; qt < NQT; ++qt) o[qt][dt] = mfma16(vf, pf[qt], o[qt][dt], 0, 0, 0);
             }
 #pragma unroll
-            for (int qt = 0; qt < NQT; ++qt) o[qt][4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt], o[qt][4], 0, 0, 0);
+            for (int qt = 0; qt < NQT; ++qt) o[qt][4] = mfma16(ones, pf[qt], o[qt][4], 0, 0, 0);
         }
     }
 
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
             if (t <= tq) {  // causal (model/attention.py:62-64), wave-uniform
                 float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_fdot2(qall[tl].h[e], k8[t].h[e], d, false);
+                for (int e = 0; e < 4; ++e) d = dot2acc(qall[tl].h[e], k8[t].h[e], d, false);
                 s[t] = group8_sum(d) * 0.125f;
                 mx = fmaxf(mx, s[t]);
             }

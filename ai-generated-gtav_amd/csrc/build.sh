@@ -24,8 +24,16 @@ for f in gemm skinny elementwise attention train comm api; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed $DEFS $extra "$@" -c $f.hip -o "$BUILD/$f.o" &
   pids+=($!)
 done
+# the bf16-operand twins (common.h "operand type", ops_bf16.h): the same three sources with f16 = __bf16 in a namespace of their own.  Never with -DGTAV_EXPERIMENTS:
+# the laboratory kernels exist for fp16 only.
+for f in gemm elementwise attention; do
+  extra=""
+  [ $f = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed -DGTAV_BF16_OPERANDS -Dgtav=gtav_bf16 $extra "$@" -c $f.hip -o "$BUILD/${f}_bf16.o" &
+  pids+=($!)
+done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$BUILD/lib.so" "$BUILD"/{gemm,skinny,elementwise,attention,train,comm,api}.o -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$BUILD/lib.so" "$BUILD"/{gemm,skinny,elementwise,attention,train,comm,api,gemm_bf16,elementwise_bf16,attention_bf16}.o -ldl
 mv -f "$BUILD/lib.so" "$OUT.tmp.$$"
 mv -f "$OUT.tmp.$$" "$OUT"
 echo "built $(realpath $OUT)"

@@ -6,14 +6,44 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+// ---- operand type of the 2-byte GEMM / attention operands -------------------------------------------------------------------
+// The product's default is fp16 (10 mantissa bits: 6-9e-4 relative L2 per forward against the fp32 oracle).  The reference itself runs this path
+// under bf16 autocast (generate.py:125-127, train_dit.py:190-198), whose exponent range is fp32's: a checkpoint with activations beyond +-65504 is clamped
+// (and flagged) in fp16.  So gemm.hip, attention.hip and elementwise.hip are compiled a SECOND time with -DGTAV_BF16_OPERANDS -Dgtav=gtav_bf16 (csrc/build.sh):
+// the same kernels, tiles, layouts and launch heuristics with `f16` = __bf16 — v_mfma_f32_16x16x32_bf16, v_cvt_pk_bf16_f32 (round to nearest even),
+// v_dot2c_f32_bf16 — in a namespace of their own (the macro renames `gtav` for the whole translation unit).  api.hip picks a set of launchers per half-block
+// (gtav_dit_set_operand_dtype / the automatic switch of gtav_dit_autorange); the fp16 objects are unchanged by this, bit for bit.
+#ifdef GTAV_BF16_OPERANDS
+#define GTAV_F16_T __bf16
+#else
+#define GTAV_F16_T _Float16
+#endif
+
 namespace gtav {
 
-typedef _Float16 f16;
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef GTAV_F16_T f16;
+typedef GTAV_F16_T f16x4 __attribute__((ext_vector_type(4)));
+typedef GTAV_F16_T f16x8 __attribute__((ext_vector_type(8)));
+typedef GTAV_F16_T f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// D = A (16 x 32) x B (32 x 16) + C on the matrix pipe, fp32 accumulate: the one MFMA shape of the 2-byte operand kernels
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c, int, int, int) {
+#ifdef GTAV_BF16_OPERANDS
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// c + a[0] b[0] + a[1] b[1] in fp32 (v_dot2_f32_f16 / v_dot2c_f32_bf16)
+__device__ __forceinline__ float dot2acc(f16x2 a, f16x2 b, float c, bool) {
+#ifdef GTAV_BF16_OPERANDS
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+#else
+    return __builtin_amdgcn_fdot2(a, b, c, false);
+#endif
+}
 
 constexpr int WAVE = 64;
 
@@ -21,12 +51,15 @@ constexpr int WAVE = 64;
 // When g_launch_ev[0] is set (api.hip's Profiler, one class at a time), the next launch of this thread attaches the start /
 // stop events to its own dispatch packet (hipExtLaunchKernel) and clears the slot: in-situ kernel times then carry no
 // marker-packet overhead and agree with rocprofv3's kernel trace.
-extern thread_local hipEvent_t g_launch_ev[2];
+}  // namespace gtav
+namespace gtav_shared { extern thread_local hipEvent_t g_launch_ev[2]; }   // one slot for the fp16 objects and their bf16 twins (defined in api.hip)
+namespace gtav {
+using gtav_shared::g_launch_ev;
 #define GTAV_LAUNCH(kern, grid, block, shmem, stream, ...)                                                              \
     do {                                                                                                                \
-        if (gtav::g_launch_ev[0]) {                                                                                     \
-            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, gtav::g_launch_ev[0], gtav::g_launch_ev[1], 0, __VA_ARGS__); \
-            gtav::g_launch_ev[0] = nullptr;                                                                             \
+        if (gtav_shared::g_launch_ev[0]) {                                                                                     \
+            hipExtLaunchKernelGGL(kern, grid, block, shmem, stream, gtav_shared::g_launch_ev[0], gtav_shared::g_launch_ev[1], 0, __VA_ARGS__); \
+            gtav_shared::g_launch_ev[0] = nullptr;                                                                             \
         } else {                                                                                                        \
             hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                                          \
         }                                                                                                               \
@@ -125,7 +158,11 @@ static inline bool prefetch_desc_ok(const PrefetchDesc& d) {
 // through sat4(): one v_med3_f32 per value clamps to +-65504 and a running |x| maximum (two v_max3_f32 per four values)
 // lets the kernel raise a device flag (bit 1 of the handle's error word, reported by gtav_dit_check / gtav_vae_check)
 // when anything was clamped: results stay finite and the caller learns that the fp16 range was exceeded.
+#ifdef GTAV_BF16_OPERANDS
+constexpr float F16_MAX = 3.3895313892515355e38f;   // largest finite bf16: the clamp never bites below fp32's own overflow, ERR_F16_SAT is never raised
+#else
 constexpr float F16_MAX = 65504.0f;
+#endif
 constexpr int ERR_TIMESTEP = 1, ERR_F16_SAT = 2, ERR_NONFINITE = 4;
 __device__ __forceinline__ f16x4 sat4(float a, float b, float c, float d, float& amax) {
     amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), amax);

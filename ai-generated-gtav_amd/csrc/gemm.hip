@@ -283,9 +283,9 @@ __device__ __forceinline__ void mainloop(const GemmParams& p, char* smem, int n0
 #pragma unroll
                     for (int j = 0; j < FJ; ++j) {
                         if (TR)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
                         else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = mfma16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                     }
         }
         if (refill && late) {
@@ -343,8 +343,8 @@ __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int
         xoff[s] = (2 + (wm >> 1)) * TILE_BYTES + (64 * (wm & 1) + li) * 128 + ch;
     }
     auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) {
-        if (TR) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xv, wv, c, 0, 0, 0);
-        else c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, xv, c, 0, 0, 0);
+        if (TR) c = mfma16(xv, wv, c, 0, 0, 0);
+        else c = mfma16(wv, xv, c, 0, 0, 0);
     };
 
     stage(sx0, 2, 0); stage(sx1, 3, 0); stage(sw0, 0, 0); stage(sw1, 1, 0);
@@ -420,6 +420,157 @@ __device__ __forceinline__ void mainloop256(const GemmParams& p, char* smem, int
         if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // (a)
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
+}
+
+// The same 256 x 256 tile, LDS image, fill schedule and accumulator layout as mainloop256, run as TWO WAVE GROUPS IN ANTIPHASE (round 6; cdna_hip_programming.md
+// "The 256^2 8-phase template"): waves 0-3 and waves 4-7 — one wave of each group per SIMD — execute the same phase sequence one barrier interval apart, so that on
+// every SIMD one wave issues its 16 MFMAs of a phase (s_setprio 1) while its partner issues the fragment reads and the LDS-DMA fills of its next phase and waits for
+// the reads to land.  In the lockstep loop both waves of a SIMD reach their reads at the same time and the matrix pipe waits out the LDS round trip with them
+// (docs/LABNOTES.md 4.11: reads + MFMAs without fills 1.18 us per K-tile against 0.77 us of MFMA issue); here that latency and the address-pipe time of a fill
+// (a wave that issues an LDS-DMA instruction is held until the pipe accepts it) lie under the partner's MFMAs.  Price: two barriers per phase.
+//   phase p of a wave:   [L]  fill one half-tile | fragment reads of the phase | (phase 4: counted vmcnt) | lgkmcnt(0) | barrier
+//                        [M]  16 MFMAs                                                                                | barrier
+//   K-tile t (parity b):  L1 W0(t+1) | wa (W rows 0-63: 8 reads), xa (tokens 0-31: 4)     M1 wa x xa
+//                         L2 W1(t+1) | xb (tokens 32-63: 4)                               M2 wa x xb
+//                         L3 X0(t+2) | wb (W rows 64-127: 8)                              M3 wb x xb
+//                         L4 X1(t+2) | vmcnt(4): all but X0 / X1(t+2) landed              M4 wb x xa
+// Group 1 starts one barrier late and group 0 ends one barrier late: barrier instance k closes group 0's section k and group 1's section k - 1.
+// WAR: a slot is refilled at least one barrier after every wave's last read of it HAS RETURNED — the lgkmcnt(0) stands in FRONT of the barrier that ends a read section
+// (X slots of parity b: last read L2(t), refilled L3(t) by group 0 while group 1 is in M2(t), its L2 reads retired before the barrier between; W slots: last read
+// L3(t), refilled L1(t+1)).  RAW: a wave reads K-tile t+1 (from L1(t+1) on) only behind BOTH groups' vmcnt(4) of L4(t): group 0's own stands two barriers back, group
+// 1's one barrier back (its L4(t) ends at the barrier that ends group 0's M4(t)); group 1 reads after group 0's by construction.  LDS-DMA data is ordered for a
+// ds_read by exactly that: the issuing wave's counted vmcnt, then a barrier the reader has passed (MI355X_MICROARCH.md).
+template <bool TR, typename AfterPrologue>
+__device__ __forceinline__ void mainloop256_pp(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                               f32x4 (&acc)[8][4], BlockStamps& bs, AfterPrologue after_prologue) {
+    constexpr int PAR = 4 * TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = w & 1, wm = w >> 1;
+    const bool late = w >= 4;                        // group 1: one barrier interval behind group 0
+    const int nktot = p.K / TK;
+    const int last_wt = ((p.N + 127) >> 7) - 1, last_rt = (p.M - 1) >> 7;
+    const int wt0 = n0 >> 7, wt1 = wt0 + 1 < last_wt ? wt0 + 1 : last_wt;     // ragged edges re-read a valid tile (masked)
+    const int rt0 = (m0 >> 7) < last_rt ? (m0 >> 7) : last_rt, rt1 = (m0 >> 7) + 1 < last_rt ? (m0 >> 7) + 1 : last_rt;
+    const size_t po = (size_t)(2 * w) * 1024 + lane * 16;
+    const char* const sw0 = (const char*)p.W + ((size_t)wt0 * nktot + kt0) * TILE_BYTES + po;
+    const char* const sw1 = (const char*)p.W + ((size_t)wt1 * nktot + kt0) * TILE_BYTES + po;
+    const char* const sx0 = (const char*)p.X + ((size_t)rt0 * nktot + kt0) * TILE_BYTES + po;
+    const char* const sx1 = (const char*)p.X + ((size_t)rt1 * nktot + kt0) * TILE_BYTES + po;
+    char* const dst0 = smem + (2 * w) * 1024;
+    auto stage = [&](const char* src, int h, int t) {
+        const char* s = src + (size_t)t * TILE_BYTES;
+        char* d = dst0 + (t & 1) * PAR + h * TILE_BYTES;
+        glds16(s, d);
+        glds16(s + 1024, d + 1024);
+    };
+    const int li = lane & 15, g = lane >> 4;
+    int woff[2], xoff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        woff[s] = wn * TILE_BYTES + li * 128 + ch;
+        xoff[s] = (2 + (wm >> 1)) * TILE_BYTES + (64 * (wm & 1) + li) * 128 + ch;
+    }
+    auto mma = [&](const f16x8& wv, const f16x8& xv, f32x4& c) {
+        if (TR) c = mfma16(xv, wv, c, 0, 0, 0);
+        else c = mfma16(wv, xv, c, 0, 0, 0);
+    };
+    // end of a read / fill section: this wave's LDS reads have returned (the WAR rule above), then the barrier; nothing may be scheduled across
+    auto end_l = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto end_m = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    stage(sx0, 2, 0); stage(sx1, 3, 0); stage(sw0, 0, 0); stage(sw1, 1, 0);
+    if (nkt > 1) {
+        stage(sx0, 2, 1); stage(sx1, 3, 1);
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    after_prologue();
+    const bool fills = !GTAV_DBG(p, 1);
+    GTAV_STAMP(bs.t[1]);
+    if (late) end_m();                               // group 1 enters the loop one interval behind
+    for (int t = 0; t < nkt; ++t) {
+        const char* b = smem + (t & 1) * PAR;
+        const bool n1 = t + 1 < nkt && fills, n2 = t + 2 < nkt && fills;
+        f16x8 wa[2][4], wb[2][4], xa[2][2], xb[2][2];
+        // ---- L1 / M1 ----
+        if (n1) stage(sw0, 0, t + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xa[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wa[s][i] = *(const f16x8*)(b + woff[s] + i * 16 * 128);
+        }
+        end_l();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(wa[s][i], xa[s][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        end_m();
+        // ---- L2 / M2 ----
+        if (n1) stage(sw1, 1, t + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xb[s][j] = *(const f16x8*)(b + xoff[s] + (2 + j) * 16 * 128);
+        end_l();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(wa[s][i], xb[s][j], acc[i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        end_m();
+        // ---- L3 / M3 ----
+        if (n2) stage(sx0, 2, t + 2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wb[s][i] = *(const f16x8*)(b + woff[s] + (4 + i) * 16 * 128);
+        end_l();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(wb[s][i], xb[s][j], acc[4 + i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        end_m();
+        // ---- L4 / M4 ----
+        if (n2) stage(sx1, 3, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // K-tile t + 1 complete (this wave's share): everything but X0 / X1(t+2)
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma(wb[s][i], xa[s][j], acc[4 + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        end_m();
+    }
+    if (!late) end_m();                              // group 0 leaves one interval late: every wave has executed the same number of barriers
 }
 
 // Piece-granular main loop for block tiles that are not multiples of the 128-row operand tiles: TNB = 32 FI features x
@@ -504,8 +655,8 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                    if (TR) acc[i][j] = mfma16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = mfma16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                 }
     };
     if constexpr (FI * FJ >= 16) {
@@ -526,8 +677,8 @@ __device__ __forceinline__ void mainloop_g(const GemmParams& p, char* smem, int 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[j], wf[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    if (TR) acc[i][j] = mfma16(xf[j], wf[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = mfma16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                 }
         };
         const bool domm = !GTAV_DBG(p, 2);
@@ -1531,12 +1682,12 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[0][i].h, xf[0][j].h, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FJ; ++j) acc[i][j] = mfma16(wf[0][i].h, xf[0][j].h, acc[i][j], 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" : GTAV_TN_FRAGS(1));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[1][i].h, xf[1][j].h, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FJ; ++j) acc[i][j] = mfma16(wf[1][i].h, xf[1][j].h, acc[i][j], 0, 0, 0);
 #undef GTAV_TN_FRAGS
         if (refill && late) {
             asm volatile("" ::: "memory");
@@ -1551,7 +1702,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_kernel(GemmParams p) {
     bs.end(p);
 }
 
-template <int EPI>
+template <int EPI, bool PP = false>   // PP: the antiphase main loop (mainloop256_pp, block shape 17)
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[8 * TILE_BYTES + (EPI == EPI_QKV ? 2048 : 0)];   // + qkv_staged's token table
     BlockStamps bs;
@@ -1569,11 +1720,17 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     auto nopf = []() {};
     if constexpr (EPI == EPI_QKV) {
         tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
-        if (tr) mainloop256<true>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
-        else mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+        if constexpr (PP) {
+            if (tr) mainloop256_pp<true>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+            else mainloop256_pp<false>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+        } else {
+            if (tr) mainloop256<true>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+            else mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs, nopf);
+        }
         pf();   // the QKV variant is at the 256-register limit: fetch after the main loop
     } else {
-        mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        if constexpr (PP) mainloop256_pp<false>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        else mainloop256<false>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     }
     GTAV_STAMP(bs.t[2]);
     epilogue<EPI, 8, 4, 4>(p, acc, pbias, smem, n0, m0, ks, tr);
@@ -1631,7 +1788,7 @@ __device__ __forceinline__ void mainloop256_tn(const GemmParams& p, char* smem, 
         lds_read_tr_asm(f.u[0], b + ax[0][j] + (unsigned)(4 * sh * PSTR));
         lds_read_tr_asm(f.u[1], b + ax[1][j] + (unsigned)(4 * sh * PSTR));
     };
-    auto mma = [&](const TnFrag& wv, const TnFrag& xv, f32x4& c) { c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv.h, xv.h, c, 0, 0, 0); };
+    auto mma = [&](const TnFrag& wv, const TnFrag& xv, f32x4& c) { c = mfma16(wv.h, xv.h, c, 0, 0, 0); };
 
     stage(sx0, rtx, 2, 0); stage(sx1, rtx, 3, 0); stage(sw0, rtw, 0, 0); stage(sw1, rtw, 1, 0);
     if (nkt > 1) {
@@ -1949,8 +2106,8 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
+                    if (TR) acc[i][j] = mfma16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = mfma16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                 }
     };
     if constexpr (FI * FJ >= 16) {
@@ -1971,8 +2128,8 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    if (TR) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[j], wf[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    if (TR) acc[i][j] = mfma16(xf[j], wf[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = mfma16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                 }
         };
         const bool domm = !GTAV_DBG(p, 2);
@@ -2212,7 +2369,7 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
                 if (t <= tl) {   // causal (model/attention.py:62-64)
                     float dsum = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dsum = __builtin_amdgcn_fdot2(q8.h[e], k8[t].h[e], dsum, false);
+                    for (int e = 0; e < 4; ++e) dsum = dot2acc(q8.h[e], k8[t].h[e], dsum, false);
                     sc[t] = group8_sum(dsum) * 0.125f;
                     mx = fmaxf(mx, sc[t]);
                 }
@@ -2405,7 +2562,7 @@ __global__ __launch_bounds__(768, 1) void gemm_lp_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < FI; ++i)
 #pragma unroll
-                for (int j = 0; j < FJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FJ; ++j) acc[i][j] = mfma16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         };
         for (int t = 0; t < nkt; ++t) {
             wait_lgkm0();
@@ -2538,7 +2695,6 @@ int gemm_choose_splitk(int M, int N, int K) {
     return s;
 }
 
-thread_local hipEvent_t g_launch_ev[2] = {nullptr, nullptr};   // common.h GTAV_LAUNCH
 #define GEMM_LAUNCH(kern, grid, block) GTAV_LAUNCH(kern, grid, block, 0, stream, p)
 
 // shape: 2 = 128x128 / 4 waves, 3 = 128x128 / 8 waves, 7 = 256x256 / 8 waves, phased K-tile (mainloop256),
@@ -2735,7 +2891,7 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
         set_gn(48, 64);
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384));   // 6 stages measured 6-8 % slower
-    } else if (shape == 7) {
+    } else if (shape == 7 || shape == 17) {   // 17: shape 7 with the two wave groups of a block in antiphase (mainloop256_pp)
 #ifndef GTAV_EXPERIMENTS
         if constexpr (EPI == EPI_QKV) {   // 15 spilled registers and never selected by the heuristic
             GTAV_REQUIRE(false, "gemm: the 256 x 256 tile has no QKV epilogue in the product build");
@@ -2748,7 +2904,8 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
             // launch by the PMC counters (profiles/traffic.json vae_fc2), 426 -> 408 us (profiles/round5/gemm_tile_group_width_large_M.txt)
             if (!g_force_gn && splitk == 1 && p.N <= 1024 && (size_t)p.M >= 8 * (size_t)p.N) p.tm.gn = cdiv(p.N, 256);
             const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
-            GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
+            if (shape == 17) GEMM_LAUNCH((gemm256_kernel<EPI, true>), grid, dim3(512));
+            else GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
         }
     } else if (shape == 3) {
         set_gn(128, TN);

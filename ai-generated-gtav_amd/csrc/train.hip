@@ -481,10 +481,10 @@ constexpr int AB_MAXS = 160;   // S <= 160 (DiT: 144)
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot8(const f16x8& a, const f16x8& b, float acc) {
     // v_dot2_f32_f16: two fp16 products accumulated in fp32 per instruction
-    acc = __builtin_amdgcn_fdot2(f16x2{a[0], a[1]}, f16x2{b[0], b[1]}, acc, false);
-    acc = __builtin_amdgcn_fdot2(f16x2{a[2], a[3]}, f16x2{b[2], b[3]}, acc, false);
-    acc = __builtin_amdgcn_fdot2(f16x2{a[4], a[5]}, f16x2{b[4], b[5]}, acc, false);
-    acc = __builtin_amdgcn_fdot2(f16x2{a[6], a[7]}, f16x2{b[6], b[7]}, acc, false);
+    acc = dot2acc(f16x2{a[0], a[1]}, f16x2{b[0], b[1]}, acc, false);
+    acc = dot2acc(f16x2{a[2], a[3]}, f16x2{b[2], b[3]}, acc, false);
+    acc = dot2acc(f16x2{a[4], a[5]}, f16x2{b[4], b[5]}, acc, false);
+    acc = dot2acc(f16x2{a[6], a[7]}, f16x2{b[6], b[7]}, acc, false);
     return acc;
 }
 template <int NT>   // threads per block: NT / 16 query rows per row block, NT / 64 key groups
@@ -715,8 +715,8 @@ __global__ __launch_bounds__(64 * ABM_NW) void attn_spatial_bwd_mfma_kernel(cons
                 for (int h = 0; h < 2; ++h) {
                     const f16x8 kb = *(const f16x8*)(sK + (16 * j + c) * LP + 32 * h + 8 * g);
                     const f16x8 vb = *(const f16x8*)(sV + (16 * j + c) * LP + 32 * h + 8 * g);
-                    sa[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa[h], kb, sa[j], 0, 0, 0);
-                    da[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga[h], vb, da[j], 0, 0, 0);
+                    sa[j] = mfma16(qa[h], kb, sa[j], 0, 0, 0);
+                    da[j] = mfma16(ga[h], vb, da[j], 0, 0, 0);
                 }
             }
         }
@@ -805,8 +805,8 @@ __global__ __launch_bounds__(64 * ABM_NW) void attn_spatial_bwd_mfma_kernel(cons
             for (int h = 0; h < 2; ++h) {
                 const f16x8 qa = *(const f16x8*)(sQ + (16 * i + c) * LP + 32 * h + 8 * g);
                 const f16x8 ga = *(const f16x8*)(sdO + (16 * i + c) * LP + 32 * h + 8 * g);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(qa, kb[h], sa, 0, 0, 0);     // rows: queries 16 i + 4 g + r; column: key 16 j + c
-                da = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, vb[h], da, 0, 0, 0);
+                sa = mfma16(qa, kb[h], sa, 0, 0, 0);     // rows: queries 16 i + 4 g + r; column: key 16 j + c
+                da = mfma16(ga, vb[h], da, 0, 0, 0);
             }
             const f32x4 l4 = *(const f32x4*)(slse + 16 * i + 4 * g), d4 = *(const f32x4*)(sDq + 16 * i + 4 * g);
             f16x4 ph, dsh;

@@ -75,15 +75,23 @@ def generate_latents(model, x_prompt: torch.Tensor, total_frames: int, noise_ste
     noise_range = torch.linspace(0, 999, noise_steps + 1)                      # generate.py:194 (float)
     t_of = [int(v) for v in noise_range]                                       # long() truncation (train_dit.py:70)
     order = list(reversed(range(0, noise_steps + 1)))
-    for i in range(n_prompt, total_frames):
-        start = max(0, i + 1 - model.max_frames)                              # generate.py:204
-        if hoist_cond:
-            model.prepare_frame_(B, total_frames, start, i, stabilization_level, [t_of[k] for k in order], act)
-        for step, noise_idx in enumerate(order):
-            cached = ctx_cache and noise_idx != noise_steps
-            model.denoise_step_(x, start, i, stabilization_level, t_of[noise_idx], t_of[max(0, noise_idx - 1)],
-                                noise_idx <= 0, act, cached=cached, cond_step=step if hoist_cond else -1)
-    model.check()
+    x_init = x.clone() if getattr(model, "range_policy", "report") == "auto" else None
+    for attempt in range(1 + (model.n_operand_groups if x_init is not None else 0)):
+        for i in range(n_prompt, total_frames):
+            start = max(0, i + 1 - model.max_frames)                              # generate.py:204
+            if hoist_cond:
+                model.prepare_frame_(B, total_frames, start, i, stabilization_level, [t_of[k] for k in order], act)
+            for step, noise_idx in enumerate(order):
+                cached = ctx_cache and noise_idx != noise_steps
+                model.denoise_step_(x, start, i, stabilization_level, t_of[noise_idx], t_of[max(0, noise_idx - 1)],
+                                    noise_idx <= 0, act, cached=cached, cond_step=step if hoist_cond else -1)
+        try:
+            model.check()
+            break
+        except _lib.GtavRangeSwitch:
+            # range_policy "auto": the layers whose fp16 stores saturated run on bf16 operands from here on; the clip is clipped — generate it again from
+            # the same inputs (each retry can only add layer groups, so the loop ends)
+            x.copy_(x_init)
     return x
 
 

@@ -18,6 +18,14 @@ class GtavError(RuntimeError):
     pass
 
 
+class GtavRangeSwitch(GtavError):
+    """check() under range_policy="auto": fp16 stores saturated, the layer groups in `.groups` were moved to bf16 operands; recompute."""
+
+    def __init__(self, msg, groups=()):
+        super().__init__(msg)
+        self.groups = list(groups)
+
+
 def build(force: bool = False) -> str:
     """Compile csrc/*.hip into libgtav_amd.so (hipcc --offload-arch=gfx950). Returns the library path."""
     src_dir = os.path.join(_HERE, "csrc")
@@ -57,6 +65,10 @@ SIGNATURES = {
     "gtav_dit_denoise_step": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "gtav_dit_prepare_frame": [_p, _i, _i, _i, _i, _i, C.POINTER(C.c_int32), _i, _p, _p],
     "gtav_dit_check": [_p, _p],
+    "gtav_dit_operand_groups": [_p, C.POINTER(C.c_int32)],
+    "gtav_dit_set_operand_dtype": [_p, _i, _i],
+    "gtav_dit_get_operand_dtype": [_p, _i, C.POINTER(C.c_int32)],
+    "gtav_dit_autorange": [_p, C.POINTER(C.c_int32), _p],
     "gtav_dit_train_param_count": [_p, C.POINTER(C.c_int64)],
     "gtav_dit_train_enable": [_p, _p, _l],
     "gtav_dit_set_loss_scale": [_p, _f],
@@ -93,6 +105,8 @@ SIGNATURES = {
     "gtav_vae_encode": [_p, _p, _f, _f, _p, _i, _p],
     "gtav_vae_decode": [_p, _p, _f, _p, _f, _f, _i, _p],
     "gtav_vae_check": [_p, _p],
+    "gtav_vae_set_operand_dtype": [_p, _i],
+    "gtav_vae_get_operand_dtype": [_p, C.POINTER(C.c_int32)],
     "gtav_vae_profile": [_p, _i],
     "gtav_vae_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "gtav_clamp_frames": [_p, _i, _i, _i, _i, _f, _f, _p],

@@ -144,7 +144,7 @@ class DiT(_HipModule):
     _prefix = "gtav_dit"
 
     def __init__(self, input_h=18, input_w=32, patch_size=2, in_channels=16, hidden_size=1024, depth=12, num_heads=16,
-                 mlp_ratio=4.0, external_cond_dim=25, max_frames=5, *, max_batch=1, init_weights=True, trainable=False):
+                 mlp_ratio=4.0, external_cond_dim=25, max_frames=5, *, max_batch=1, init_weights=True, trainable=False, range_policy="report"):
         super().__init__()
         self._trainable = bool(trainable)    # keyword-only, not in the reference: keeps fp32 masters, gradients and AdamW state on the GPU
         self._grads = None
@@ -165,6 +165,13 @@ class DiT(_HipModule):
         self._spatial_freqs = _w.rope_freqs_pixel(hd // 2, 256)   # model/dit.py:259-261
         self._temporal_freqs = _w.rope_freqs_lang(hd)             # model/dit.py:262
         self._schedule = None
+        # operand groups (include/gtav_amd.h "operand type"): 2 l / 2 l + 1 = spatial / temporal half of block l, 2 depth = patch embedding, 2 depth + 1 = final layer
+        self.n_operand_groups = 2 * depth + 2
+        self._bf16_groups = set()
+        self.range_policy = range_policy
+        if range_policy not in ("report", "auto"):
+            raise ValueError("range_policy must be 'report' (check() raises when an fp16 activation saturated) or 'auto' (check() moves the saturated "
+                             "layers to bf16 operands and raises GtavRangeSwitch: recompute)")
         if init_weights:
             self.initialize_weights()
 
@@ -237,6 +244,8 @@ class DiT(_HipModule):
                     _lib.check(L.gtav_dit_set_fold(self._handle, *self._fold))
                 if getattr(self, "_weight_prefetch", None) is not None:
                     _lib.check(L.gtav_dit_set_weight_prefetch(self._handle, int(self._weight_prefetch)))
+                for g in sorted(self._bf16_groups):                      # a re-created handle keeps the operand types chosen before
+                    _lib.check(L.gtav_dit_set_operand_dtype(self._handle, g, 1))
                 if self._trainable:
                     n = C.c_int64(0)
                     _lib.check(L.gtav_dit_train_param_count(self._handle, C.byref(n)))
@@ -502,9 +511,59 @@ class DiT(_HipModule):
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fold(self._handle, *self._fold))
 
+    # ------------------------------------------------------------------------------------------
+    # operand type / range safety (include/gtav_amd.h "operand type"; reference: bf16 autocast, generate.py:125-127, train_dit.py:190-198)
+    # ------------------------------------------------------------------------------------------
+    def set_operand_dtype(self, dtype, groups=None):
+        """torch.float16 (default: 6-9e-4 relative L2 per forward against the fp32 reference, range +-65504) or torch.bfloat16 (the reference's own autocast type:
+        fp32 range, ~8e-3) for the 2-byte GEMM / attention operands of `groups` (None = every layer group; group numbering: n_operand_groups).  The weights of
+        the changed groups are converted again from the fp32 host copies at the next call."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"set_operand_dtype: {dtype} (torch.float16 or torch.bfloat16)")
+        if self._trainable and dtype == torch.bfloat16:
+            raise _lib.GtavError("set_operand_dtype: a trainable DiT keeps fp16 operands (its backward pass and loss scaling are fp16)")
+        gs = set(range(self.n_operand_groups)) if groups is None else {int(g) for g in groups}
+        if any(g < 0 or g >= self.n_operand_groups for g in gs):
+            raise ValueError(f"set_operand_dtype: groups {sorted(gs)} outside [0, {self.n_operand_groups})")
+        new = (self._bf16_groups | gs) if dtype == torch.bfloat16 else (self._bf16_groups - gs)
+        if new == self._bf16_groups:
+            return
+        if self._handle:
+            L = _lib.load()
+            for g in sorted(new ^ self._bf16_groups):
+                _lib.check(L.gtav_dit_set_operand_dtype(self._handle, g, 1 if g in new else 0))
+            self._dirty = True               # the changed groups' weight images are stale: the next call re-sends the weights and finalizes
+        self._bf16_groups = new
+
+    def operand_dtypes(self):
+        """torch dtype of every operand group, in group order."""
+        return [torch.bfloat16 if g in self._bf16_groups else torch.float16 for g in range(self.n_operand_groups)]
+
     def check(self):
+        """Raises if a timestep was out of range, an input held NaN / inf, or an fp16 activation saturated since the last call (synchronises).
+        range_policy "auto": a saturation moves exactly the layer groups that saturated to bf16 operands (gtav_dit_autorange) and raises GtavRangeSwitch —
+        what was computed since the last check is clipped and must be recomputed; the recomputation runs the switched layers in bf16."""
+        if not self._handle:
+            return
+        L = _lib.load()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.load().gtav_dit_check(self._handle, _lib.current_stream()))
+            if self.range_policy != "auto" or self._trainable:
+                _lib.check(L.gtav_dit_check(self._handle, _lib.current_stream()))
+                return
+            n = C.c_int32(0)
+            _lib.check(L.gtav_dit_autorange(self._handle, C.byref(n), _lib.current_stream()))
+            if n.value:
+                d = C.c_int32(0)
+                new = set()
+                for g in range(self.n_operand_groups):
+                    _lib.check(L.gtav_dit_get_operand_dtype(self._handle, g, C.byref(d)))
+                    if d.value == 1:
+                        new.add(g)
+                switched = sorted(new - self._bf16_groups)
+                self._bf16_groups = new
+                self._dirty = True
+                raise _lib.GtavRangeSwitch(f"DiT: an activation exceeded the fp16 range (|x| > 65504) in operand group(s) {switched}; those layers now run "
+                                           "on bf16 operands (the reference's own autocast type): results since the last check are clipped — recompute them", switched)
 
 
 def DiT_S_2(**kwargs):

@@ -103,6 +103,8 @@ class AutoencoderKL(_HipModule):
             cfg = _lib.VaeConfig(max_frames_per_call=self._capacity, **self._cfg_kwargs)
             with torch.cuda.device(self.device):
                 _lib.check(_lib.load().gtav_vae_create(C.byref(cfg), C.byref(self._handle)))
+                if getattr(self, "_bf16", False):
+                    _lib.check(_lib.load().gtav_vae_set_operand_dtype(self._handle, 1))
             self._dirty = True
         if self._dirty:
             # model/vae.py:71-76: RotaryEmbedding(dim=head_dim // 4, pixel, max_freq=H*W).get_axial_freqs(H, W)
@@ -154,6 +156,19 @@ class AutoencoderKL(_HipModule):
                 _lib.check(L.gtav_vae_decode(self._handle, zd[i:i + n].data_ptr(), z_scale, out[i:i + n].data_ptr(), out_scale,
                                              out_shift, n, _lib.current_stream()))
         return out
+
+    def set_operand_dtype(self, dtype):
+        """torch.float16 (default) or torch.bfloat16 (the reference's autocast type: fp32 range, lower precision) for every 2-byte GEMM / attention operand of
+        the VAE (include/gtav_amd.h "operand type"); the weights are converted again from the fp32 host copies at the next call."""
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"set_operand_dtype: {dtype} (torch.float16 or torch.bfloat16)")
+        bf = dtype == torch.bfloat16
+        if bf == getattr(self, "_bf16", False):
+            return
+        self._bf16 = bf
+        if self._handle:
+            _lib.check(_lib.load().gtav_vae_set_operand_dtype(self._handle, 1 if bf else 0))
+            self._dirty = True
 
     def check(self):
         """Raises if an input held NaN/inf or an fp16 activation saturated since the last call (gtav_vae_check; synchronises)."""

@@ -21,10 +21,16 @@ def ddim_update(x: torch.Tensor, v: torch.Tensor, alpha_t: torch.Tensor, alpha_n
 
 @torch.inference_mode()
 def denoise_step(dit_model, x_noisy, actions, noise_idx, stabilization_level, noise_range, alphas_cumprod, start_frame=0,
-                 dtype=torch.bfloat16):
+                 dtype=None):
     """Same signature and return value as train_dit.denoise_step (train_dit.py:30-125): returns
-    (x_pred, v_pred) for the window x_noisy[:, start_frame:].  `dtype` is accepted for call compatibility;
-    the kernels always compute with fp16 operands / fp32 accumulation."""
+    (x_pred, v_pred) for the window x_noisy[:, start_frame:].  `dtype` is the reference's autocast type (train_dit.py:105-107): torch.bfloat16 /
+    torch.float16 select the model's operand type (DiT.set_operand_dtype: accumulation, residual stream, LayerNorm, softmax and the conditioning path are
+    fp32 either way).  One deviation: the DEFAULT is None = leave the model as it is (fp16 operands unless it was switched), where the reference's default is
+    torch.bfloat16 — fp16 is what keeps a forward within 1e-3 of the fp32 reference; pass torch.bfloat16 for the reference's own range / precision."""
+    if dtype is not None:
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"denoise_step: dtype {dtype} (torch.float16, torch.bfloat16 or None)")
+        dit_model.set_operand_dtype(dtype)
     dev = dit_model.device
     B = x_noisy.shape[0]
     t_ctx = torch.full((B, x_noisy.shape[1] - 1), int(stabilization_level), dtype=torch.long)

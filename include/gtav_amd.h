@@ -24,7 +24,7 @@
  *                            plain launches, which never allocate
  *   gtav_dit_set_fused_temporal   first enable: hipMalloc of the head-major weight copies, device synchronise
  *   gtav_dit_forward         with gtav_dit_profile enabled only: creates events and synchronises at the end of the forward
- *   gtav_dit_check / gtav_vae_check   copy the device error word back and synchronise `stream`
+ *   gtav_dit_check / gtav_vae_check / gtav_dit_autorange   copy the device error words back and synchronise `stream`
  *   gtav_dit_train_enable    hipMalloc + hipMemset of masters, optimizer state, saved-activation and backward workspace, two small
  *                            synchronous hipMemcpy (the multi-tensor AdamW tables)
  *   gtav_dit_train_stats     copies four floats back and synchronises `stream`
@@ -203,6 +203,26 @@ int gtav_dit_set_opt_step(gtav_dit* h, int64_t applied_steps, int64_t skipped_st
  * silently producing NaN). */
 int gtav_dit_check(gtav_dit* h, void* stream);
 
+/* ---- operand type of the 2-byte tensors (range safety) ---------------------------------------------------------------------------
+ * The reference runs this path under bf16 autocast by default (generate.py:125-127 `Accelerator(mixed_precision=...)`, train_dit.py:190-198; train_dit.denoise_step's
+ * `dtype=torch.bfloat16`): fp32 exponent range, 8 mantissa bits.  This library defaults to fp16 operands (fp32 accumulation), which is what holds the forward within
+ * 1e-3 relative L2 of the fp32 reference — but an activation beyond +-65504 is clamped (and reported by gtav_dit_check).  For checkpoints with such outliers every
+ * 2-byte tensor of a group of layers — LayerNorm output, q / k / v, attention output, MLP hidden, temporal K/V cache and the group's GEMM weights — can be bf16 instead:
+ * the same kernels and layouts compiled for bf16 operands (v_mfma_f32_16x16x32_bf16), ~8e-3 relative L2 per forward when every group is bf16.
+ *   groups of a DiT handle: 2 l = spatial half of block l, 2 l + 1 = its temporal half, 2 depth = the patch embedding, 2 depth + 1 = the final layer
+ *   gtav_dit_set_operand_dtype(h, group, dtype)   group -1 = every group.  The fp16 / bf16 images of the changed groups' GEMM weights become stale: send those weights
+ *       again with gtav_dit_set_weight (any weight may be re-sent) and call gtav_dit_finalize.  Drops the captured graphs and the cached context.  Training handles
+ *       keep fp16 operands.
+ *   gtav_dit_autorange(h, &n, stream)   gtav_dit_check that RECOVERS: every fp16 group whose stores saturated since the last check is switched to bf16
+ *       (*n_switched of them; weights to be re-sent as above, results since the last check to be recomputed); other errors are reported like gtav_dit_check.
+ * The VAE handle has one type for all its layers. */
+#define GTAV_OPERAND_F16 0
+#define GTAV_OPERAND_BF16 1
+int gtav_dit_operand_groups(gtav_dit* h, int32_t* n_groups);
+int gtav_dit_set_operand_dtype(gtav_dit* h, int32_t group, int32_t dtype);
+int gtav_dit_get_operand_dtype(gtav_dit* h, int32_t group, int32_t* dtype);
+int gtav_dit_autorange(gtav_dit* h, int32_t* n_switched, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * ViT-VAE — replaces model/vae.py:160-361 (class AutoencoderKL)
  * ---------------------------------------------------------------------------------------------- */
@@ -236,6 +256,10 @@ int gtav_vae_decode(gtav_vae* h, const float* z_dev, float z_scale, float* img_d
 
 /* Same as gtav_dit_check for the VAE handle (NaN/inf input pixels, fp16 saturation). */
 int gtav_vae_check(gtav_vae* h, void* stream);
+/* Operand type of every 2-byte tensor of the VAE handle (see gtav_dit_set_operand_dtype): GTAV_OPERAND_F16 (default) or GTAV_OPERAND_BF16.  A change makes every GEMM
+ * weight image stale: send the weights again (gtav_vae_set_weight), then gtav_vae_finalize. */
+int gtav_vae_set_operand_dtype(gtav_vae* h, int32_t dtype);
+int gtav_vae_get_operand_dtype(gtav_vae* h, int32_t* dtype);
 /* In-situ kernel timing of encode / decode, as gtav_dit_profile (same GTAV_PROFILE_CLASSES order; class 3, temporal attention, stays empty; 4 = the
  * attention projection, 7 = patchify / patch embedding / quant_conv / post_quant_conv / predictor / unpatchify): bench.py's config4 roofline object.
  * With it enabled every encode / decode call synchronises `stream` at its end. */
