@@ -2891,7 +2891,13 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
         set_gn(48, 64);
         const dim3 grid(cdiv(p.M, 48) * cdiv(p.N, 64) * splitk);
         GEMM_LAUNCH((gemm_g_kernel<EPI, 4, 2, 1, 3>), grid, dim3(384));   // 6 stages measured 6-8 % slower
-    } else if (shape == 7 || shape == 17) {   // 17: shape 7 with the two wave groups of a block in antiphase (mainloop256_pp)
+    } else if (shape == 7 || shape == 17) {   // 17 (experiments build only): shape 7 with the two wave groups of a block in antiphase (mainloop256_pp)
+#ifndef GTAV_EXPERIMENTS
+        // round 6: correct, race-screened (profiles/round6/race_screen_shape17.txt) and within +-1 % of shape 7 on the shapes that select it (fc2 / projection at M >= 11 520,
+        // fc1 -7 % at M = 11 520 where shape 12 is still ahead of both at the model level): the K-tile is bound by how many fill bytes a CU keeps in flight, not by
+        // how its two waves per SIMD interleave reads and MFMAs (profiles/round6/antiphase_256x256_main_loop_shape17_vs_shape7_vs_heuristic.txt: main loop 26.9 vs 27.2 us)
+        GTAV_REQUIRE(shape != 17, "gemm: block shape 17 (antiphase 256 x 256 main loop) exists only in the experiments build (csrc/build.sh exp)");
+#endif
 #ifndef GTAV_EXPERIMENTS
         if constexpr (EPI == EPI_QKV) {   // 15 spilled registers and never selected by the heuristic
             GTAV_REQUIRE(false, "gemm: the 256 x 256 tile has no QKV epilogue in the product build");
@@ -2904,8 +2910,11 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
             // launch by the PMC counters (profiles/traffic.json vae_fc2), 426 -> 408 us (profiles/round5/gemm_tile_group_width_large_M.txt)
             if (!g_force_gn && splitk == 1 && p.N <= 1024 && (size_t)p.M >= 8 * (size_t)p.N) p.tm.gn = cdiv(p.N, 256);
             const dim3 grid(cdiv(p.M, 256) * cdiv(p.N, 256) * splitk);
+#ifdef GTAV_EXPERIMENTS
             if (shape == 17) GEMM_LAUNCH((gemm256_kernel<EPI, true>), grid, dim3(512));
-            else GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
+            else
+#endif
+            GEMM_LAUNCH((gemm256_kernel<EPI>), grid, dim3(512));
         }
     } else if (shape == 3) {
         set_gn(128, TN);

@@ -23,7 +23,7 @@ def main():
     lib = L.load()
     cases = [(720, 4096, 1024), (5760, 1024, 1024), (144, 3072, 1024), (333, 512, 4096), (2880, 3072, 1024), (1152, 4096, 1024)]
     bad = 0
-    ap_shapes = a.shapes or [2, 3, 7, 17, 11, 12, 13, 14, 20, 24, 26, 29, 31]
+    ap_shapes = a.shapes or [2, 3, 7, 11, 12, 13, 14, 20, 24, 26, 29, 31]
     for shape in ap_shapes:
         for (M, N, K) in cases:
             g = torch.Generator().manual_seed(M + N + K)
