@@ -528,7 +528,8 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
     GTAV_REQUIRE(!q_prescaled || attn_spatial_wants_prescaled_q(S), "attn_spatial: S=%d runs a kernel that takes plain q", S);
     const int S_pad = round_up(S, 32);
     const int nqt = cdiv(S, 16);
-    if (S_pad <= 160) {   // short sequences (the DiT's frames): one pass per query tile, scores in registers
+    static const int force_flash = GTAV_ENV_INT("GTAV_ATTN_FORCE_FLASH", 0);   // experiments build: the flash kernel for short sequences too (A/B runs)
+    if (S_pad <= 160 && !force_flash) {   // short sequences (the DiT's frames): one pass per query tile, scores in registers
         const size_t lds = (size_t)S_pad * 128 + (size_t)64 * (S_pad + 8) * 2;
         int devid = 0;
         GTAV_CHECK_HIP(hipGetDevice(&devid));
@@ -548,6 +549,20 @@ int launch_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int N
             }                                                                                                                         \
             GTAV_LAUNCH((attn_spatial_1p_kernel<4, NK_>), grid, dim3(256), lds, stream, Q, K, Vt, O, heads, S, qsplit, g_attn_sc1 & 1);   \
         } while (0)
+#ifdef GTAV_EXPERIMENTS
+        // experiments build: waves per block of the one-pass kernel at NK = 10 (A/B runs: GTAV_ATTN_1P_NW = 3, 5 or 9; the product runs 4)
+        static const int nw_exp = GTAV_ENV_INT("GTAV_ATTN_1P_NW", 4);
+#define GTAV_ATTN_1P_NW(NW_)                                                                                                            \
+        do {                                                                                                                          \
+            GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)attn_spatial_1p_kernel<NW_, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            int qs_ = 1;                                                                                                              \
+            GTAV_LAUNCH((attn_spatial_1p_kernel<NW_, 10>), dim3(NB * heads, qs_), dim3(64 * NW_), lds, stream, Q, K, Vt, O, heads, S, qs_, g_attn_sc1 & 1); \
+        } while (0)
+        if (nk == 10 && nw_exp == 3) { GTAV_ATTN_1P_NW(3); GTAV_CHECK_HIP(hipGetLastError()); return 0; }
+        if (nk == 10 && nw_exp == 5) { GTAV_ATTN_1P_NW(5); GTAV_CHECK_HIP(hipGetLastError()); return 0; }
+        if (nk == 10 && nw_exp == 9) { GTAV_ATTN_1P_NW(9); GTAV_CHECK_HIP(hipGetLastError()); return 0; }
+#undef GTAV_ATTN_1P_NW
+#endif
         if (nk == 2) GTAV_ATTN_1P(2);
         else if (nk == 4) GTAV_ATTN_1P(4);
         else if (nk == 6) GTAV_ATTN_1P(6);

@@ -16,7 +16,7 @@ fi
 BUILD=$(mktemp -d "${TMPDIR:-/tmp}/gtav_build.XXXXXX")
 trap 'rm -rf "$BUILD"' EXIT
 pids=()
-for f in gemm skinny elementwise attention train comm api; do
+for f in gemm skinny elementwise attention train comm api api_dit api_train api_vae; do
   extra=""
   # attention: keep MFMA accumulators in VGPRs — the softmax works on them every key block, and the AGPR form costs 56
   # v_accvgpr moves per 16 MFMAs there (the GEMMs touch their accumulators only in the epilogue and keep the default)
@@ -33,7 +33,7 @@ for f in gemm elementwise attention; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$BUILD/lib.so" "$BUILD"/{gemm,skinny,elementwise,attention,train,comm,api,gemm_bf16,elementwise_bf16,attention_bf16}.o -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$BUILD/lib.so" "$BUILD"/{gemm,skinny,elementwise,attention,train,comm,api,api_dit,api_train,api_vae,gemm_bf16,elementwise_bf16,attention_bf16}.o -ldl
 mv -f "$BUILD/lib.so" "$OUT.tmp.$$"
 mv -f "$OUT.tmp.$$" "$OUT"
 echo "built $(realpath $OUT)"

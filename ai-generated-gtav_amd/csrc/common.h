@@ -11,7 +11,7 @@
 // under bf16 autocast (generate.py:125-127, train_dit.py:190-198), whose exponent range is fp32's: a checkpoint with activations beyond +-65504 is clamped
 // (and flagged) in fp16.  So gemm.hip, attention.hip and elementwise.hip are compiled a SECOND time with -DGTAV_BF16_OPERANDS -Dgtav=gtav_bf16 (csrc/build.sh):
 // the same kernels, tiles, layouts and launch heuristics with `f16` = __bf16 — v_mfma_f32_16x16x32_bf16, v_cvt_pk_bf16_f32 (round to nearest even),
-// v_dot2c_f32_bf16 — in a namespace of their own (the macro renames `gtav` for the whole translation unit).  api.hip picks a set of launchers per half-block
+// v_dot2c_f32_bf16 — in a namespace of their own (the macro renames `gtav` for the whole translation unit).  api_dit.hip picks a set of launchers per half-block
 // (gtav_dit_set_operand_dtype / the automatic switch of gtav_dit_autorange); the fp16 objects are unchanged by this, bit for bit.
 #ifdef GTAV_BF16_OPERANDS
 #define GTAV_F16_T __bf16
@@ -48,7 +48,7 @@ __device__ __forceinline__ float dot2acc(f16x2 a, f16x2 b, float c, bool) {
 constexpr int WAVE = 64;
 
 // ---- kernel launch with optional dispatch-attached timing events (profiler hook) ----
-// When g_launch_ev[0] is set (api.hip's Profiler, one class at a time), the next launch of this thread attaches the start /
+// When g_launch_ev[0] is set (api_internal.h's Profiler, one class at a time), the next launch of this thread attaches the start /
 // stop events to its own dispatch packet (hipExtLaunchKernel) and clears the slot: in-situ kernel times then carry no
 // marker-packet overhead and agree with rocprofv3's kernel trace.
 }  // namespace gtav

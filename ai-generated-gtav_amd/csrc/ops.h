@@ -55,7 +55,7 @@ struct LnPending {
     int rows_per_gate;
     int flags;   // set by the launcher: bit 0 = residual write-back as sc1 stores, bit 1 = fp16 output as paired 16-byte sc1 stores, bit 2 = row and slabs by non-temporal loads
     int* err_flag;   // device error word (common.h ERR_F16_SAT is raised when the fp16 output saturated); may be null
-    // training forward (api.hip gtav_dit_train_forward): the backward pass needs every intermediate residual state and every
+    // training forward (api_train.hip gtav_dit_train_forward): the backward pass needs every intermediate residual state and every
     // branch output, so the updated row goes to x_out (same leading dimension as x) instead of in place, and the branch output
     // y = sum_s parts[s] + bias (before the gate) is kept as fp16 rows of ld elements in y_save.  Both may be null.
     float* x_out;

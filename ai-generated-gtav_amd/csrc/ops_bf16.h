@@ -1,4 +1,4 @@
-// The bf16-operand twins of the launchers api.hip dispatches per operand type (common.h "operand type"): gemm.hip, attention.hip and elementwise.hip compiled a second
+// The bf16-operand twins of the launchers api_dit.hip / api_vae.hip dispatch per operand type (common.h "operand type"): gemm.hip, attention.hip and elementwise.hip compiled a second
 // time with -DGTAV_BF16_OPERANDS -Dgtav=gtav_bf16 (csrc/build.sh).  Same kernels, same argument meaning as gemm.h / ops.h; `f16*` there is `__bf16*` here and the
 // parameter structs are the twin namespace's own (identical layout: api.hip passes its gtav::GemmParams / gtav::LnPending through a reference cast).
 // Keep the signatures in step with ops.h / gemm.h: a mismatch is a link error, never a silent one.

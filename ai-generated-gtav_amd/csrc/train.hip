@@ -1267,7 +1267,7 @@ __global__ void adamw_kernel(float* __restrict__ p, int ldp, int R, int C, const
 }
 
 // Multi-tensor AdamW (one launch for the whole model) fused with the refresh of the fp16 GEMM operands.  The host cuts every parameter
-// into work items (api.hip gtav_dit_train_enable): a 64 x 64 tile of a GEMM weight, or a run of up to 4096 elements of an fp32
+// into work items (api_train.hip gtav_dit_train_enable): a 64 x 64 tile of a GEMM weight, or a run of up to 4096 elements of an fp32
 // parameter.  A block updates its item in fp32 and, for a GEMM weight, writes the tile straight into the tile-major fp16 W (16 bytes
 // along c) and, through an LDS transpose, into the tile-major fp16 W^T (16 bytes along r): the separate convert passes (two more reads
 // of the 0.8 GB of masters, 370 launches) and 300 per-parameter AdamW launches are gone.

@@ -231,7 +231,7 @@ def test_full_size_gradients_grouped_weight_gradient_launch(B, T):
 
 def test_plain_forward_of_a_trainable_handle_at_large_m_equals_the_inference_handle():
     """at M >= 3649 tokens the plain forward (gtav_dit_forward) of a TRAINABLE handle takes the in-place residual epilogue of the persistent kernel
-    (EPI_RESID, csrc/api.hip resid_gemm) like an inference handle does — it keeps no activations, so nothing of the training path depends on the slabs — and
+    (EPI_RESID, csrc/api_dit.hip resid_gemm) like an inference handle does — it keeps no activations, so nothing of the training path depends on the slabs — and
     must return the same bits.  DiT-S/2, B = 8, T = 5 (M = 5 760); forward_train on the same inputs agrees to rounding (it runs the slab path)."""
     import gtav_amd.weights as W
     from gtav_amd.model.dit import DiT_models
