@@ -50,7 +50,8 @@ constexpr int WAVE = 64;
 // ---- kernel launch with optional dispatch-attached timing events (profiler hook) ----
 // When g_launch_ev[0] is set (api_internal.h's Profiler, one class at a time), the next launch of this thread attaches the start /
 // stop events to its own dispatch packet (hipExtLaunchKernel) and clears the slot: in-situ kernel times then carry no
-// marker-packet overhead and agree with rocprofv3's kernel trace.
+// marker-packet overhead and agree with rocprofv3's kernel trace (round 6, gtav_timer_calibrate on a spin kernel of known device duration: the pair reads
+// device time + 0.60 us, rocprofv3 device time + 0.62 us — profiles/timer_calibration.json).
 }  // namespace gtav
 namespace gtav_shared { extern thread_local hipEvent_t g_launch_ev[2]; }   // one slot for the fp16 objects and their bf16 twins (defined in api.hip)
 namespace gtav {

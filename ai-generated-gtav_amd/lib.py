@@ -154,6 +154,9 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise GtavError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"(hipcc --offload-arch=gfx950). gtav_amd has no CPU fallback.")
+    # torch's wheel bundles its own libamdhip64: it must be in the process BEFORE this library's dependency on libamdhip64 is resolved, or the process ends
+    # up with two HIP runtimes — torch's sees the GPU, the one this library was bound to reports "no ROCm-capable device" (seen as build(); smoke() in one process)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -183,6 +186,7 @@ def load_experiments(build_if_missing: bool = True) -> C.CDLL:
         raise GtavError("load_experiments() must be called before anything loaded the product library")
     if build_if_missing and not os.path.exists(EXP_LIB_PATH):
         subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh"), "exp"], check=True)
+    import torch  # noqa: F401   (torch's HIP runtime first: see load())
     lib = C.CDLL(EXP_LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
