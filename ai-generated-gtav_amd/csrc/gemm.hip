@@ -2263,6 +2263,230 @@ __global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_l_kernel(GemmPara
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Loader-wave GEMM with the WEIGHT operand straight into registers (shape 22, round 6).
+//
+// What bounds the loader-wave kernel at a few hundred tokens (the batch-1 window step: one 128 x 96 tile per CU, 16 K-steps) is how many fill bytes a CU keeps in
+// flight against the latency of a weight that comes from HBM or the Infinity Cache: the ring holds NS - 1 = 3 stages of 28 KiB, of which 16 KiB are W — 48 KiB of W
+// in flight per CU — and the K-step costs 0.45-0.5 us where ingest (64 B/clk) and the matrix pipes need 0.2-0.25 (profiles/round6/*per_class*: out-proj with 8
+// K-steps 6.1 us, fc2's slices with 16 K-steps 9.9 us).  LDS capacity caps the ring; the register file does not: 8 compute waves x D = 4 K-steps x 4 KiB of W
+// fragments = 128 KiB in flight per CU.  So here
+//   * the compute waves load their OWN W fragments (16 features x 32 k per 16-byte lane load: the tile-major image makes a fragment half of eight 128-byte lines)
+//     D K-steps ahead into a register ring (plain global loads: hipcc counts their vmcnt itself; the waves issue no other vector-memory operation in the loop);
+//   * the loader waves move only X (the activations: L2-hot, 12 KiB per K-step) through the LDS ring, as before;
+//   * W never touches LDS: the ring is 12 KiB per stage and the LDS array serves X fragment reads only.
+// Price: the WM = 2 waves that share a W row tile each load it (W crosses the CU's texture path twice: 32 + 12 = 44 KiB of ingest per K-step against 28).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, int D, typename AfterPrologue>
+__device__ __forceinline__ void mainloop_lw(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
+                                            f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
+    static_assert(NS >= 3 && NL >= 1 && D >= 2 && D % 2 == 0 && (FI == 1 || FI == 2), "X ring of at least 3 stages; an even W register ring; 1 or 2 feature tiles per wave");
+    constexpr int XPC = 2 * FJ * WM;                         // 1-KiB X pieces per stage
+    constexpr int G = (XPC + NL - 1) / NL;
+    constexpr int STAGE_BYTES = XPC * 1024;
+    constexpr bool XDB = FI * FJ * 2 + 2 * FJ * 8 <= 96;     // X fragments of two K-steps in registers (one-step software pipeline) only while they fit
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wraw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nktot = p.K / TK;
+    if (wraw < NL) {
+        // ------------------------------------------------ loader wave: X only ------------------------------------------------
+        const int lw = wraw;
+        const int last_rt = (p.M - 1) >> 7;
+        const unsigned voff = (unsigned)lane * 16u;
+        const unsigned smem0 = lds_offset(smem);
+        const char* sb[G];
+        unsigned ldso[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            int q = lw * G + i;
+            q = q < XPC ? q : XPC - 1;                       // the last wave repeats the final piece (same bytes, same place)
+            const int row = m0 + 8 * q;
+            int rt = row >> 7;
+            rt = rt < last_rt ? rt : last_rt;                // ragged edge: re-read a valid tile (results are masked)
+            sb[i] = (const char*)p.X + ((size_t)rt * nktot + kt0) * TILE_BYTES + ((row & 127) >> 3) * 1024;
+            ldso[i] = smem0 + q * 1024;
+        }
+        auto stage = [&](int t) {
+            const unsigned so = (unsigned)(t % NS) * STAGE_BYTES;
+            const size_t go = (size_t)t * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < G; ++i) glds16_s(sb[i] + go, voff, ldso[i] + so);
+        };
+        const int npro = nkt < NS - 1 ? nkt : NS - 1;
+        for (int t = 0; t < npro; ++t) stage(t);
+        for (int t = 0; t < nkt; ++t) {
+            wait_vm_ring<NS, G>(nkt - 1 - t);                // this wave's share of tile t has landed
+            wg_barrier();
+            if (t == 0) GTAV_STAMP(bs.t[1]);
+            if (t + NS - 1 < nkt && !GTAV_DBG(p, 1)) stage(t + NS - 1);
+        }
+        return;
+    }
+    // ------------------------------------------------ compute wave ------------------------------------------------
+    const int w = wraw - NL;
+    const int wn = w % WN, wm = w / WN;
+    const int li = lane & 15, g = lane >> 4;
+    int xoff[2];
+    // this lane's W fragment source: row n0 + 16 FI wn + 16 i + li of the tile-major weight, 16-byte chunk 4 s + g of its 128-byte row (common.h tiled_off)
+    const int last_wt = ((p.N + 127) >> 7) - 1;
+    const int wrow = n0 + 16 * FI * wn + li;                 // (+ 16 i: 16 FI WN <= 128 and n0 % 128 == 0 keep every i inside one row tile)
+    int wrt = wrow >> 7;
+    wrt = wrt < last_wt ? wrt : last_wt;
+    int soff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int ch = ((4 * s + g) ^ (li & 7)) << 4;
+        xoff[s] = (16 * FJ * wm + li) * 128 + ch;
+        soff[s] = ch;                                        // (row & 7) == (li & 7): n0 + 16 FI wn + 16 i is a multiple of 8
+    }
+    after_prologue();   // register loads the epilogue wants early (bias): OLDER than every W load, so the first W wait covers them
+    // The W loads and their waits are inline asm with hand-counted vmcnt: behind plain loads hipcc's wait-count pass loses the ring at the loop's back edge and
+    // drains to vmcnt(3) ... vmcnt(0) inside every K-step (seen in the first build of this loop: no load stayed in flight across a step).  A wait statement names
+    // the registers it retires as in-out operands, so no use of them can be scheduled above it (the pattern of mainloop256_tn).  vmcnt retires in issue order
+    // and these waves issue nothing else in the loop: when K-step u is consumed, the loads issued after its own are those of steps u + 1 .. min(u + D - 1, nkt - 1).
+    f16x8 wr[D][2][FI];
+    const unsigned wvoff0 = (unsigned)((wrow & 127) * 128 + soff[0]), wvoff1 = (unsigned)((wrow & 127) * 128 + soff[1]);
+    const char* const wbase = (const char*)p.W + ((size_t)wrt * nktot + kt0) * TILE_BYTES;    // wave-uniform
+    auto ldw = [&](int t, f16x8 (&dst)[2][FI]) {
+        const char* sb = wbase + (size_t)t * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[0][i]) : "v"(wvoff0), "s"(sb), "n"(i * 2048) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst[1][i]) : "v"(wvoff1), "s"(sb), "n"(i * 2048) : "memory");
+        }
+    };
+    // slot `a` is consumed while the loads of YOUNGER later K-steps (2 FI each) may still be in flight.  ONE asm statement per call site and a compile-time count:
+    // a run-time choice between wait statements makes the in-out registers phis of several definitions, and hipcc then copies them — in one of the paths AHEAD of
+    // the wait, i.e. before the data has landed (seen in the second build of this loop).  Hence the loop below has no branch around a wait: a steady part in which
+    // every step has D - 1 younger steps in flight, and a tail of exactly D steps with D - 1, ..., 0 (host-checked: K-steps per slice a multiple of D).
+    auto wait_w = [&](f16x8 (&a)[2][FI], auto younger) {
+        constexpr int CNT = decltype(younger)::value * 2 * FI;
+        if constexpr (FI == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) : "n"(CNT));
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0][0]), "+v"(a[1][0]) : "n"(CNT));
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) ldw(d, wr[d]);
+    auto mmh = [&](const f16x8 (&wf)[FI], const f16x8 (&xv)[FJ]) {      // one 32-deep half of a K-step
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                if (TR) acc[i][j] = mfma16(xv[j], wf[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = mfma16(wf[i], xv[j], acc[i][j], 0, 0, 0);
+            }
+    };
+    const bool domm = !GTAV_DBG(p, 2);
+    auto rdx = [&](int t, f16x8 (&dst)[2][FJ]) {
+        const char* b = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) dst[s][j] = *(const f16x8*)(b + xoff[s] + j * 16 * 128);
+    };
+    if constexpr (XDB) {
+        // one-step software pipeline on the X side (as mainloop_l): barrier u + 1 | read X(u + 1) | MFMAs of K-step u (W from register slot u % D) | refill the slot with step u + D
+        f16x8 xf[2][2][FJ];
+        auto next_x = [&](int t, f16x8 (&dst)[2][FJ]) {    // barrier t (X stage t complete and visible), then its fragment reads
+            wait_lgkm0();
+            wg_barrier();
+            rdx(t, dst);
+        };
+        auto mm = [&](const f16x8 (&wf)[2][FI], const f16x8 (&xv)[2][FJ]) { mmh(wf[0], xv[0]); mmh(wf[1], xv[1]); };
+        next_x(0, xf[0]);
+        GTAV_STAMP(bs.t[1]);
+        auto steady = [&](int u0, auto dc) {
+            constexpr int d = decltype(dc)::value;
+            next_x(u0 + d + 1, xf[(d + 1) & 1]);
+            wait_w(wr[d], std::integral_constant<int, D - 1>{});
+            if (domm) mm(wr[d], xf[d & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            ldw(u0 + d + D, wr[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto tail = [&](int u0, auto dc) {
+            constexpr int d = decltype(dc)::value;
+            if constexpr (d + 1 < D) next_x(u0 + d + 1, xf[(d + 1) & 1]);
+            wait_w(wr[d], std::integral_constant<int, D - 1 - d>{});
+            if (domm) mm(wr[d], xf[d & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto run = [&](auto&& f, int u0) {
+            if constexpr (D == 4) { f(u0, std::integral_constant<int, 0>{}); f(u0, std::integral_constant<int, 1>{}); f(u0, std::integral_constant<int, 2>{}); f(u0, std::integral_constant<int, 3>{}); }
+            else { static_assert(D == 8, "rings of 4 or 8 K-steps");
+                   f(u0, std::integral_constant<int, 0>{}); f(u0, std::integral_constant<int, 1>{}); f(u0, std::integral_constant<int, 2>{}); f(u0, std::integral_constant<int, 3>{});
+                   f(u0, std::integral_constant<int, 4>{}); f(u0, std::integral_constant<int, 5>{}); f(u0, std::integral_constant<int, 6>{}); f(u0, std::integral_constant<int, 7>{}); }
+        };
+        for (int u0 = 0; u0 < nkt - D; u0 += D) run(steady, u0);     // (nkt % D == 0: slot and X set of step u0 + d are d and d & 1)
+        run(tail, nkt - D);
+    } else {
+        // wide token tiles (FJ = 6: 48 fragment registers per K-step): no second X set — barrier u | read both halves of X(u) | MFMAs half 0 behind lgkmcnt(FJ),
+        // half 1 behind lgkmcnt(0) | refill.  The co-resident compute wave of the SIMD covers the LDS round trip.
+        f16x8 xf[2][FJ];
+        auto step = [&](int u, auto dc, auto yc, bool refill) {
+            constexpr int d = decltype(dc)::value;
+            wait_lgkm0();
+            wg_barrier();
+            if (u == 0) GTAV_STAMP(bs.t[1]);
+            rdx(u, xf);
+            wait_w(wr[d], yc);
+            if (domm) { mmh(wr[d][0], xf[0]); mmh(wr[d][1], xf[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (refill) ldw(u + D, wr[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(D == 8 || D == 4, "rings of 4 or 8 K-steps");
+#define GTAV_LW_STEADY(dd) step(u0 + dd, std::integral_constant<int, dd>{}, std::integral_constant<int, D - 1>{}, true)
+#define GTAV_LW_TAIL(dd) step(nkt - D + dd, std::integral_constant<int, dd>{}, std::integral_constant<int, D - 1 - dd>{}, false)
+        for (int u0 = 0; u0 < nkt - D; u0 += D) {
+            GTAV_LW_STEADY(0); GTAV_LW_STEADY(1); GTAV_LW_STEADY(2); GTAV_LW_STEADY(3);
+            if constexpr (D == 8) { GTAV_LW_STEADY(4); GTAV_LW_STEADY(5); GTAV_LW_STEADY(6); GTAV_LW_STEADY(7); }
+        }
+        GTAV_LW_TAIL(0); GTAV_LW_TAIL(1); GTAV_LW_TAIL(2); GTAV_LW_TAIL(3);
+        if constexpr (D == 8) { GTAV_LW_TAIL(4); GTAV_LW_TAIL(5); GTAV_LW_TAIL(6); GTAV_LW_TAIL(7); }
+#undef GTAV_LW_STEADY
+#undef GTAV_LW_TAIL
+    }
+}
+
+template <int EPIX, int NS, int FI, int FJ, int WN, int WM, int NL, int D>
+__global__ __launch_bounds__(64 * (WN * WM + NL), 1) void gemm_lw_kernel(GemmParams p) {
+    constexpr int EPI = epi_base(EPIX);
+    static_assert(!epi_is_fold_consumer(EPIX) && EPI != EPI_RESID_FOLD, "no LayerNorm-fold epilogues on this kernel");
+    constexpr int TNB = 16 * FI * WN, TM = 16 * FJ * WM;
+    static_assert(TNB <= 128 && 128 % TNB == 0, "a block's features stay inside one 128-row weight tile");
+    extern __shared__ __attribute__((aligned(16))) char smem_l[];
+    char* smem = smem_l;
+#define GTAV_PIN_S(x) asm volatile("" ::"s"(x))
+    GTAV_PIN_S(p.X); GTAV_PIN_S(p.W); GTAV_PIN_S(p.M); GTAV_PIN_S(p.N); GTAV_PIN_S(p.K); GTAV_PIN_S(p.splitk);
+    GTAV_PIN_S(p.tm.tiles_m); GTAV_PIN_S(p.tm.tiles_n); GTAV_PIN_S(p.tm.gn); GTAV_PIN_S(p.tm.group); GTAV_PIN_S(p.tm.tiles);
+    GTAV_PIN_S(p.tm.rcp_tiles); GTAV_PIN_S(p.tm.rcp_group); GTAV_PIN_S(p.tm.rcp_gn); GTAV_PIN_S(p.tm.rcp_gnlast);
+    GTAV_PIN_S(p.bias); GTAV_PIN_S(p.out); GTAV_PIN_S(p.ldo); GTAV_PIN_S(p.qkv_mode); GTAV_PIN_S(p.D);
+#undef GTAV_PIN_S
+    BlockStamps bs;
+    bs.begin(p);
+    int n0, m0, ks, kt0, nkt;
+    tile_map_fast<EPI == EPI_PARTIAL, TNB, TM>(p, n0, m0, ks, kt0, nkt);
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool tr = false;
+    f32x4 pbias[FI];
+    FoldTok<FJ> ft;
+    auto pf = [&]() { prefetch_bias<EPI, FI, WM, WN, NL>(p, n0, pbias); };
+    if constexpr (EPI == EPI_QKV) {
+        tr = (p.qkv_mode == QKV_SPATIAL) && (n0 >= 2 * p.D);
+        if (tr) mainloop_lw<true, NS, FI, FJ, WN, WM, NL, D>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+        else mainloop_lw<false, NS, FI, FJ, WN, WM, NL, D>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    } else {
+        mainloop_lw<false, NS, FI, FJ, WN, WM, NL, D>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    }
+    GTAV_STAMP(bs.t[2]);
+    epilogue<EPIX, FI, FJ, WM, WN, NL, false>(p, acc, pbias, smem, n0, m0, ks, tr, acc, ft);
+    bs.end(p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Temporal QKV projection + causal temporal attention in ONE launch (the window step at batch 1).
 //
 // The temporal attention of one (batch item, position, head) needs q, k, v of that head for the <= 5 frames of the window at that
@@ -2803,6 +3027,30 @@ static int launch_l(const GemmParams& p, int splitk, hipStream_t stream) {
     return 0;
 }
 
+// loader-wave kernel with the weight operand straight into registers (shape 22): dynamic LDS = the X ring, or the epilogue's image if that is larger
+template <int EPI, int NS, int FI, int FJ, int WN, int WM, int NL, int D>
+static int launch_lw(const GemmParams& p, int splitk, hipStream_t stream) {
+    constexpr int TNB = 16 * FI * WN, TM = 16 * FJ * WM;
+    constexpr int RING = NS * 2 * FJ * WM * 1024;
+    constexpr int PNB = (TNB / 8 + 7) / 8 * 8 * 16, PTB = (TM / 8 + 7) / 8 * 8 * 16;
+    constexpr int EPIB = (TM * PNB > TNB * PTB ? TM * PNB : TNB * PTB) + TM * 8;      // qkv_staged's pitched image + token table (gemm_l_kernel)
+    constexpr int GELUB = (TNB / 64 > 0 ? TNB / 64 : 1) * TM * 128;                     // the tile-major GELU image
+    constexpr int LDS = RING > EPIB ? (RING > GELUB ? RING : GELUB) : (EPIB > GELUB ? EPIB : GELUB);
+    static unsigned long long attr_devs = 0;
+    int dev = 0;
+    GTAV_REQUIRE(device_cus(&dev) > 0, "gemm: no current device");
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_lw_kernel<EPI, NS, FI, FJ, WN, WM, NL, D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_devs |= 1ull << (dev & 63);
+    }
+    GemmParams q = p;
+    if (int rc_ = fill_tile_map(q.tm, p.M, p.N, p.K, TM, TNB, splitk)) return rc_;
+    const dim3 grid(q.tm.tiles * splitk);
+    GTAV_LAUNCH((gemm_lw_kernel<EPI, NS, FI, FJ, WN, WM, NL, D>), grid, dim3(64 * (WN * WM + NL)), LDS, stream, q);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // persistent loader-wave kernel (shape 30): one block per CU, dynamic LDS = ring of NS x 40 KiB
 template <int EPI, int NS, int FI = 4, int FJ = 3, int WN = 2, int WM = 4>
 static int launch_lp(const GemmParams& p, hipStream_t stream) {
@@ -2839,6 +3087,26 @@ static int launch_epi(const GemmParams& p_in, int ns, int shape, int splitk, hip
     if constexpr (FOLDISH) GTAV_REQUIRE(shape == 2 || shape == 3 || shape == 11 || shape == 12 || shape == 13 || shape == 14 || shape == 20 || shape == 24 || shape == 26 || shape == 27 || shape == 28,
                                         "gemm: block shape %d has no LayerNorm-fold epilogue", shape);
     if (shape == 20) return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);   // 128 x 96, 8 compute + 4 loader waves
+#ifdef GTAV_EXPERIMENTS
+    // Round 6, measured SLOWER, experiments build only (profiles/round6/weight_operand_straight_into_registers_shapes_22_18.txt): the captured batch-1 step 2.05 -> 2.26 ms
+    // (shape 22) / 2.12 -> 2.23 ms (shape 18), bit-identical results.  More weight bytes in flight per CU (128 KiB in registers against 48 KiB of the LDS ring) buy
+    // nothing at M = 720: the K-step of the loader-wave kernel is not waiting for the weight.
+    if constexpr (!FOLDISH) {
+        // the same tile, the weight operand straight into registers 4 K-steps ahead (its K loop is written for K-steps per slice that are a multiple of 4: else shape 20)
+        if (shape == 22) {
+            if ((p.K / TK / (splitk > 0 ? splitk : 1)) % 4 == 0) return launch_lw<EPI, 4, 2, 3, 4, 2, 4, 4>(p, splitk, stream);
+            return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);
+        }
+        // ... and with the eight compute waves side by side along the features (16 features x all 96 tokens each): every W fragment is loaded by exactly one wave,
+        // 8 K-steps ahead
+        if (shape == 18) {
+            if ((p.K / TK / (splitk > 0 ? splitk : 1)) % 8 == 0) return launch_lw<EPI, 4, 1, 6, 8, 1, 4, 8>(p, splitk, stream);
+            return launch_l<EPI, 4, 2, 3, 4, 2, 4>(p, splitk, stream);
+        }
+    }
+#else
+    GTAV_REQUIRE(shape != 22 && shape != 18, "gemm: block shape %d (weight operand straight into registers) exists only in the experiments build (csrc/build.sh exp)", shape);
+#endif
     if (shape == 24) return launch_l<EPI, 4, 2, 1, 2, 3, 2>(p, splitk, stream);   // 64 x 48, 6 compute + 2 loader waves (the skinny shape 11 on the loader-wave kernel)
     if (shape == 26) return launch_l<EPI, 4, 2, 2, 2, 3, 2>(p, splitk, stream);   // 64 x 96, 6 compute + 2 loader waves (shape 14 likewise)
 #ifdef GTAV_EXPERIMENTS
@@ -3117,6 +3385,11 @@ int launch_gemm(const GemmParams& p_in, int epi_x, hipStream_t stream) {
     // Round 2: the 128 x 96 tile runs on the loader-wave kernel (shape 20: 4 loader + 8 compute waves, fills and MFMAs overlap by
     // construction): QKV 14.1 -> 10.7 us, fc1 13.3 -> 10.9, fc2 12.0 -> 10.2, out-proj 6.6 -> 6.1 at M = 720 (profiles/round2).
     if (!g_force_wm && !(g_debug & 64) && (wm == 9 || (wm == 8 && g_l_for_8))) wm = (g_debug & 128) ? 25 : 20;   // debug bit 6 (experiments build): round-1 shapes, for A/B runs in one process
+#ifdef GTAV_EXPERIMENTS
+    // round 6 A/B (debug bit 24): the 128 x 96 loader-wave tile with the weight operand straight into registers (shape 22) wherever the heuristic picks shape 20
+    if (!g_force_wm && wm == 20 && (g_debug & 0x1000000) && !foldish && (p.K / TK / (splitk > 0 ? splitk : 1)) % 4 == 0) wm = 22;
+    if (!g_force_wm && wm == 20 && (g_debug & 0x2000000) && !foldish && (p.K / TK / (splitk > 0 ? splitk : 1)) % 8 == 0) wm = 18;   // debug bit 25: shape 18
+#endif
     // Round 3: the skinny tiles on the loader-wave kernel too (6 compute + 2 loader waves): M = 144 QKV 8.45 -> 7.34 us, fc1 7.75 -> 6.83, out-proj 5.00 -> 4.68;
     // M = 288 QKV 10.3 -> 8.4, fc1 9.7 -> 8.4 (profiles/round3/skinny_loader_wave_shapes_M144_M288.txt); their compute waves carry the next-weight L2 prefetch.
     // The 8-slice fc2 at M = 288 stays on the all-waves-fill kernel (7.4 against 8.3 us).

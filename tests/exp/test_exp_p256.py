@@ -54,3 +54,12 @@ def test_persistent_256_token_tile_kernel(shape, M, N, K):
                 assert torch.equal(out, first[0]) and torch.equal(f32, first[1]) and torch.equal(parts, first[2]), r
     finally:
         lib.gtav_op_gemm_set_wm(0)
+
+
+@pytest.mark.parametrize("shape", [22, 18])
+def test_weight_operand_straight_into_registers(shape):
+    """Block shapes 22 / 18 (round 6; csrc/gemm.hip mainloop_lw): the 128 x 96 loader-wave tile with the weight operand loaded by the compute waves straight into a
+    register ring 4 / 8 K-steps ahead (hand-counted vmcnt), X through the LDS ring as before — measured slower than shape 20, kept for the record.  Every epilogue
+    through the product suite's shape sweep (K-steps per slice that are not a multiple of the ring depth fall back to shape 20)."""
+    import test_gpu_ops as T
+    T.test_gemm_other_tiles_all_epilogues(shape)
