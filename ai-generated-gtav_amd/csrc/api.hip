@@ -40,8 +40,11 @@ int bf_ln_affine(float* x, int ldx, f16* out, int ldo, int M, int D, const float
 int bf_patchify(const float* img, const int* fi, int NB, int C, int H, int W, int p, f16* out, int ldo, float a, float b, int* ef, hipStream_t st) {
     return gtav_bf16::launch_patchify(img, fi, NB, C, H, W, p, (__bf16*)out, ldo, a, b, ef, st);
 }
-int bf_convert_pad(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t st) {
-    return gtav_bf16::launch_convert_pad_f16(src, lds, R, C, (__bf16*)dst, Rp, Cp, scale, tiled, st);
+int f16_convert_pad(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t st, int* ef) {
+    return launch_convert_pad_f16(src, lds, R, C, dst, Rp, Cp, scale, tiled, st, ef);
+}
+int bf_convert_pad(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t st, int* ef) {
+    return gtav_bf16::launch_convert_pad_f16(src, lds, R, C, (__bf16*)dst, Rp, Cp, scale, tiled, st, ef);
 }
 int bf_unpad(const f16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t st) { return gtav_bf16::launch_unpad_f16_to_f32((const __bf16*)src, lds, R, C, dst, tiled, st); }
 int bf_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t st, bool qp) {
@@ -50,7 +53,7 @@ int bf_attn_spatial(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, i
 int bf_attn_temporal(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax, hipStream_t st) {
     return gtav_bf16::launch_attn_temporal((const __bf16*)q, (const __bf16*)kv, (__bf16*)O, B, P, D, Tq, t0, Tmax, st);
 }
-const OperandOps OPS_F16 = {launch_gemm, launch_ln_modulate, launch_ln_affine, launch_patchify, launch_convert_pad_f16, launch_unpad_f16_to_f32, f16_attn_spatial,
+const OperandOps OPS_F16 = {launch_gemm, launch_ln_modulate, launch_ln_affine, launch_patchify, f16_convert_pad, launch_unpad_f16_to_f32, f16_attn_spatial,
                             launch_attn_temporal, false};
 const OperandOps OPS_BF16 = {bf_gemm, bf_ln_modulate, bf_ln_affine, bf_patchify, bf_convert_pad, bf_unpad, bf_attn_spatial, bf_attn_temporal, true};
 }  // namespace

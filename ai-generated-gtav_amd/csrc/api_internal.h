@@ -70,6 +70,10 @@ struct Slot {
 
 struct WeightTable {
     std::map<std::string, Slot> slots;
+    // device error words of the owning handle (word 0; a DiT handle: + 4 + group for the f16 slots of an operand group): a GEMM weight beyond the fp16 range is
+    // clamped by the conversion AND raises ERR_F16_SAT there, so that check() reports it and gtav_dit_autorange moves the group to bf16
+    int* err_words = nullptr;
+    bool err_per_group = false;
     void add_f16(const std::string& n, int R, int C, f16* dst, int Rp, int Cp, int group = -1) {
         slots[n] = Slot{SLOT_F16_PAD, R, C, dst, Rp, Cp, 0, false, true};
         slots[n].group = group;
@@ -95,7 +99,10 @@ struct WeightTable {
         Slot& sl = it->second;
         GTAV_REQUIRE(numel == (int64_t)sl.R * sl.C, "set_weight: '%s' has %lld elements, expected %d x %d", name,
                      (long long)numel, sl.R, sl.C);
-        if (sl.kind == SLOT_F16_PAD) RET_IF(operand_ops(sl.bf16).convert_pad(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, 1, s));
+        if (sl.kind == SLOT_F16_PAD) {
+            int* ef = err_words ? err_words + (err_per_group && sl.group >= 0 ? 4 + sl.group : 0) : nullptr;
+            RET_IF(operand_ops(sl.bf16).convert_pad(src, sl.C, sl.R, sl.C, (f16*)sl.dst, sl.Rp, sl.Cp, 1.0f, 1, s, ef));
+        }
         else RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, (float*)sl.dst, sl.Cp, sl.c0, s));
         if (sl.master && sl.kind == SLOT_F16_PAD) RET_IF(launch_copy_f32(src, sl.C, sl.R, sl.C, sl.master, sl.C, 0, s));
         if (sl.wT) RET_IF(launch_convert_T_f16(src, sl.C, sl.R, sl.C, sl.wT, s));

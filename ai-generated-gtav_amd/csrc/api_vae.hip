@@ -145,7 +145,7 @@ int gtav_vae_create(const gtav_vae_config* c, gtav_vae** out) {
     A_(a.alloc_t(&h->resid, Mx * Dm)); A_(a.alloc_t(&h->po, Mx * h->Npred));
     h->parts_rows = (2 * Mx * Dm > (size_t)(8u << 20) ? 2 * Mx * Dm : (size_t)(8u << 20)) / Dm;   // in rows of Dmax floats; two slabs at the largest M
     A_(a.alloc_t(&h->parts, h->parts_rows * Dm));
-    A_(a.alloc_t(&h->err_flag, 4));
+    A_(a.alloc_t(&h->err_flag, 4)); wt.err_words = h->err_flag;
 #undef A_
     if (rc) {
         delete h;
@@ -223,7 +223,7 @@ int gtav_vae_decode(gtav_vae* h, const float* z, float z_scale, float* img, floa
     GTAV_REQUIRE(N >= 1 && N <= h->maxN, "vae_decode: N=%d exceeds max_frames_per_call=%d", N, h->maxN);
     hipStream_t s = (hipStream_t)stream;
     const int Dd = h->cfg.dec_dim, M = N * h->S;
-    PROF(h, PC_OTHER, s, h->ops->convert_pad(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s));
+    PROF(h, PC_OTHER, s, h->ops->convert_pad(z, h->Lat, M, h->Lat, h->zin, round_up(M, 128), 64, z_scale, 1, s, h->err_flag));
     GemmParams g;
     memset(&g, 0, sizeof(g));
     g.X = h->zin; g.ldx = 64; g.W = h->w_post; g.M = M; g.N = Dd; g.K = 64; g.bias = h->b_post; g.out = h->resid; g.ldo = Dd;

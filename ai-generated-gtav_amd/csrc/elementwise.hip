@@ -279,16 +279,21 @@ __global__ void unpatchify_kernel(const float* __restrict__ y, int ldy, float* _
 }
 
 __global__ void convert_pad_f16_kernel(const float* __restrict__ src, int lds, int R, int C, f16* __restrict__ dst, int Rp,
-                                       int Cp, float scale, int tiled) {
+                                       int Cp, float scale, int tiled, int* err_flag) {
     const size_t total = (size_t)Rp * Cp;
+    bool sat = false;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(idx % Cp);
         const size_t r = idx / Cp;
         float v = 0.f;
         if (r < (size_t)R && c < C) v = src[r * lds + c] * scale;
-        if (v == v) v = __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);   // weights / latents beyond the fp16 range saturate
+        if (v == v) {   // weights / latents beyond the operand type's range saturate — and say so (a weight clamped in silence would be a wrong model)
+            sat |= __builtin_fabsf(v) > F16_MAX;
+            v = __builtin_amdgcn_fmed3f(v, -F16_MAX, F16_MAX);
+        }
         dst[tiled ? tiled_off((int)r, c, Cp) : idx] = (f16)v;
     }
+    if (sat && err_flag) atomicOr(err_flag, ERR_F16_SAT);
 }
 
 __global__ void copy_f32_kernel(const float* __restrict__ src, int lds, int R, int C, float* __restrict__ dst, int ldd, int c0) {
@@ -741,11 +746,11 @@ int launch_unpatchify(const float* y, int ldy, float* img, int NB, int C, int H,
 }
 
 int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled,
-                           hipStream_t stream) {
+                           hipStream_t stream, int* err_flag) {
     GTAV_REQUIRE(Rp >= R && Cp >= C, "convert_pad: padded shape smaller than source");
     GTAV_REQUIRE(!tiled || (Rp % 128 == 0 && Cp % 64 == 0), "convert_pad: tile-major needs Rp %% 128 == 0 and Cp %% 64 == 0");
     hipLaunchKernelGGL(convert_pad_f16_kernel, dim3(grid_for((size_t)Rp * Cp)), dim3(256), 0, stream, src, lds, R, C, dst,
-                       Rp, Cp, scale, tiled);
+                       Rp, Cp, scale, tiled, err_flag);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

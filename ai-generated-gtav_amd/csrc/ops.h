@@ -89,8 +89,9 @@ int launch_unpatchify(const float* y, int ldy, float* img, int NB, int C, int H,
 
 // fp32 -> fp16 with zero padding: src [R][C] (ld = lds) -> dst [Rp][Cp]
 // tiled != 0: dst is tile-major (common.h tiled_off) with Rp % 128 == 0, Cp % 64 == 0
+// err_flag (optional device word): ERR_F16_SAT is raised when a finite value beyond the operand type's range was clamped
 int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled,
-                           hipStream_t stream);
+                           hipStream_t stream, int* err_flag = nullptr);
 // inverse of the above without padding (state_dict round trip): dst[r][c] = (float)src[r][c]
 int launch_unpad_f16_to_f32(const f16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t stream);
 int launch_copy_f32_strided(const float* src, int lds, int R, int C, float* dst, int ldd, hipStream_t stream);

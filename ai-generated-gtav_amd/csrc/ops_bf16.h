@@ -15,7 +15,7 @@ int launch_ln_affine(float* x, int ldx, __bf16* out, int ldo, int M, int D, cons
                      hipStream_t stream);
 int launch_patchify(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, __bf16* out, int ldo, float a, float b, int* err_flag,
                     hipStream_t stream);
-int launch_convert_pad_f16(const float* src, int lds, int R, int C, __bf16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t stream);
+int launch_convert_pad_f16(const float* src, int lds, int R, int C, __bf16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t stream, int* err_flag);
 int launch_unpad_f16_to_f32(const __bf16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t stream);
 int launch_attn_spatial(const __bf16* Q, const __bf16* K, const __bf16* Vt, __bf16* O, int NB, int heads, int S, hipStream_t stream, bool q_prescaled);
 int launch_attn_temporal(const __bf16* q, const __bf16* kv, __bf16* O, int B, int P, int D, int Tq, int t0, int Tmax, hipStream_t stream);
@@ -32,7 +32,7 @@ struct OperandOps {
                        const LnPending* pend, int* err_flag, hipStream_t stream);
     int (*ln_affine)(float* x, int ldx, f16* out, int ldo, int M, int D, const float* gamma, const float* beta, const LnPending* pend, int* err_flag, hipStream_t stream);
     int (*patchify)(const float* img, const int* frame_index, int NB, int C, int H, int W, int p, f16* out, int ldo, float a, float b, int* err_flag, hipStream_t stream);
-    int (*convert_pad)(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t stream);
+    int (*convert_pad)(const float* src, int lds, int R, int C, f16* dst, int Rp, int Cp, float scale, int tiled, hipStream_t stream, int* err_flag);
     int (*unpad)(const f16* src, int lds, int R, int C, float* dst, int tiled, hipStream_t stream);
     int (*attn_spatial)(const f16* Q, const f16* K, const f16* Vt, f16* O, int NB, int heads, int S, hipStream_t stream, bool q_prescaled);
     int (*attn_temporal)(const f16* q, const f16* kv, f16* O, int B, int P, int D, int Tq, int t0, int Tmax, hipStream_t stream);

@@ -253,6 +253,34 @@ def test_bf16_operands_full_size_vae_flash_attention():
     v.check()
 
 
+def test_weight_beyond_fp16_range_is_reported_and_recovered():
+    """A GEMM weight beyond +-65504 is clamped by the fp16 conversion: it must not be clamped in silence.  The conversion raises the saturation bit of the weight's
+    operand group; range_policy="auto" moves that group to bf16 (whose weight image holds the value) and the recomputed forward matches the oracle."""
+    sd = W.synth_state_dict(W.dit_param_shapes(**SMALL_DIT), seed=3)
+    big = dict(sd)
+    w = sd["blocks.1.s_attn.to_out.weight"].clone()
+    w[5, 7] = 3.0e5                                           # one outlier weight (fp16 would hold 65504)
+    big["blocks.1.s_attn.to_out.weight"] = w
+    cfg = O.DiTConfig(**SMALL_DIT)
+    x, t, a = _inputs(cfg, 1, 3, seed=12)
+    with torch.no_grad():
+        ref = O.dit_forward(big, cfg, x, t, a)
+    m = DiT(**SMALL_DIT, init_weights=False, max_batch=1)
+    m.load_state_dict(big)
+    m(x, t, a)
+    with pytest.raises(GtavError, match="fp16 range"):
+        m.check()
+    m2 = DiT(**SMALL_DIT, init_weights=False, max_batch=1, range_policy="auto")
+    m2.load_state_dict(big)
+    m2(x, t, a)
+    with pytest.raises(GtavRangeSwitch) as ei:
+        m2.check()
+    assert ei.value.groups == [2]                            # block 1, spatial half
+    out = m2(x, t, a)
+    m2.check()
+    assert rel_l2(out, ref) < TOL_BF16_ONE_GROUP
+
+
 def test_training_handle_refuses_bf16_operands():
     m = DiT(**SMALL_DIT, init_weights=False, max_batch=1, trainable=True)
     with pytest.raises(GtavError, match="fp16 operands"):
