@@ -159,6 +159,12 @@ def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
         assert r["chosen"] in ("on", "off", "per-class") and r["on_ms"] > 0 and r["off_ms"] > 0 and r["tuned_ms"] <= min(r["on_ms"], r["off_ms"])
         assert r["mode"] == prefetch_mode(tuple(r["classes"][c] for c in ("out", "fc1", "fc2", "qkv")))
         print("weight prefetch on / off / tuned (ms per step):", r)
+        ft = r["fused_temporal_qkv_attention"]                  # (round 6) the fused temporal to_qkv + attention launch, timed the same way on this five-frame window
+        assert ft is not None and ft["chosen"] in ("on", "off") and ft["on_ms"] > 0 and ft["off_ms"] > 0
+        x = x0.clone()
+        for k in range(4):
+            m.denoise_step_(x, 0, 4, 15, 900 - 10 * k, 890 - 10 * k, False, None)
+        assert torch.equal(x, outs[0])                            # whatever the tuner kept: the same latents
         with pytest.raises(Exception):
             m.set_weight_prefetch(7)                 # neither 0, 1 nor a per-class word
         # the form bench.py uses for the context-cached step of the batched leg: a one-frame window at batch 2 (288 tokens: inside the prefetch's range)
@@ -166,6 +172,7 @@ def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
         assert r1["tuned_ms"] > 0 and set(r1["classes"]) == {"out", "fc1", "fc2", "qkv"}
     finally:
         m.set_weight_prefetch(True)
+        m.set_fused_temporal(False)
     m.check()
 
 
