@@ -26,8 +26,8 @@ def main():
     g = torch.Generator().manual_seed(1)
     q, k, v = (torch.randn(NB, H, S, 64, generator=g).half() for _ in range(3))
     if a.jump != 0:
-        k[NB - 1, H - 1, S - 9] = q[NB - 1, H - 1, 7] * a.jump
-        k[0, min(1, H - 1), 70] = q[0, min(1, H - 1), 150] * a.jump
+        k[NB - 1, H - 1, max(S - 9, 0)] = q[NB - 1, H - 1, min(7, S - 1)] * a.jump
+        k[0, min(1, H - 1), min(70, S - 1)] = q[0, min(1, H - 1), min(150, S - 1)] * a.jump
     vt = v.transpose(-1, -2).contiguous()
     rows = (NB * S + 127) // 128 * 128
     qd, kd, vd = q.to(dev), k.to(dev), vt.to(dev)

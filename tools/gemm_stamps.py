@@ -87,6 +87,9 @@ def main():
                 lib.gtav_op_gemm_set_stamps(None, 0)
                 s = rows[-1]
                 nb = s.shape[0]
+                if nb == 0:            # the kernel this shape dispatches to does not write stamps (split-K slabs, persistent tiles without the hook)
+                    print(f"{name:>4} M={M:5d} N={N} K={K} wm={wm} splitk={sk}: {us_plain:7.2f} us/launch back-to-back; no stamps from this kernel")
+                    continue
                 t0, t1, t2, t3, c0, c1, xcc = (s[:, i] for i in range(7))     # t*: s_memrealtime (100 MHz); c*: s_memtime (cycles)
                 lstart, lland = s[:, 7], xcc >> 8            # loader-wave kernels: last loader's first issue / its tile-0 pieces landed
                 xcc = xcc & 0xF
