@@ -206,6 +206,16 @@ int gtav_op_gemm_qkvt_attn(const void* x_tperm, const void* w_hm, int32_t M, int
     g.rope_cs = rope_cs;
     return launch_gemm_qkvt_attn(g, (hipStream_t)stream);
 }
+int gtav_op_qkv_head_major_spatial(const void* w, void* w_hm, int32_t D, void* stream) {
+    return launch_qkv_head_major((const f16*)w, (f16*)w_hm, D, (hipStream_t)stream, 1);
+}
+int gtav_op_gemm_qkvs_attn(const void* x, const void* w_hm, int32_t M, int32_t D, int32_t P, const float* rope_cs, void* o, void* stream) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.X = (const f16*)x; g.ldx = D; g.W = (const f16*)w_hm; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P;
+    g.qkv_mode = QKV_SPATIAL; g.out = o; g.ldo = D; g.rope_cs = rope_cs;
+    return launch_gemm_qkvs_attn(g, (hipStream_t)stream);
+}
 int gtav_op_attn_spatial_bwd(const void* q, const void* k, const void* vt, const void* d_o, int32_t NB, int32_t heads, int32_t S,
                              const float* rope_cs, void* dqkv, void* stream) {
     return launch_attn_spatial_bwd((const f16*)q, (const f16*)k, (const f16*)vt, (const f16*)d_o, NB, heads, S, heads * 64, rope_cs, (f16*)dqkv, nullptr,

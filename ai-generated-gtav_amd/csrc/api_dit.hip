@@ -64,7 +64,7 @@ static int fold_alloc(gtav_dit* h) {
 static void fold_policy(const gtav_dit* h, int M, bool& fa, bool& fb) {
     const gtav_dit::Fold& f = h->fold;
     fa = fb = false;
-    if (!f.ok || f.mode == 0 || h->tr.on || h->fuse_tattn || h->any_bf16) return;
+    if (!f.ok || f.mode == 0 || h->tr.on || h->fuse_tattn || h->any_bf16) return;   // (the fused spatial launch steps aside per half-block: !folded_in)
     fa = f.mode == 2 || M >= f.min_m_a;
     fb = f.mode == 2 || M >= f.min_m_b;
 }
@@ -146,13 +146,16 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // what the GEMM launch at position `pos` of half-block `hb` (launch order: 0 to_qkv, 1 out-proj, 2 fc1, 3 fc2) prefetches: the weight of the next GEMM
     // launch of the step.  (One more launch of lead — the weight of the GEMM after the next — was measured in round 5 and gained nothing on either kind
     // of GPU: profiles/round5/prefetch_box_survey.txt.)
+    // the fused spatial to_qkv + attention launch: from 5 frames on (measured from 80 blocks up; a context-cached batch-1 step is 16 blocks: the split path's skinny kernels serve it)
+    auto fused_spatial_ok = [](int M_, int D_, int P_) { return gemm_qkvs_attn_ok(M_, D_, P_) && M_ / P_ >= 5 && (M_ / P_) * (D_ / 64) >= 80; };
     struct PfNext { const f16* W; int N, K, sk, consumer; };
     auto pf_target = [&](int hb, int pos) -> PfNext {
         const int q = pos + 1, hb2 = hb + q / 4, p2 = q % 4;
         if (!pf_on || hb2 >= 2 * h->L) return PfNext{nullptr, 0, 0, 1, 0};
         const gtav_dit::Half& w2 = h->halves[hb2];
         if (p2 == 0) {
-            const bool fused2 = (hb2 & 1) && h->fuse_tattn && !h->tr.on && w2.w_qkv_hm && gemm_qkvt_attn_ok(M, D, P, Tq, t0);
+            const bool fused2 = !h->tr.on && w2.w_qkv_hm && !h->ops(hb2).bf16 &&
+                                ((hb2 & 1) ? h->fuse_tattn && gemm_qkvt_attn_ok(M, D, P, Tq, t0) : h->fuse_sattn && fused_spatial_ok(M, D, P));
             return PfNext{fused2 ? w2.w_qkv_hm : w2.w_qkv, 3 * D, D, 1, 3};
         }
         if (p2 == 1) return PfNext{w2.w_out, D, D, gemm_choose_splitk(M, D, D), 0};
@@ -214,10 +217,14 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             g.X = h->xn; g.ldx = D; g.W = w.w_qkv; g.M = M; g.N = 3 * D; g.K = D; g.D = D; g.S = P; g.err_flag = ef;
             if (folded_in) fold_consumer(g, 2 * hb, 3 * D);
             set_pf(g, pf_target(hb, 0));
+            const bool fused_s = hf == 0 && h->fuse_sattn && !h->tr.on && !ops.bf16 && !folded_in && w.w_qkv_hm && fused_spatial_ok(M, D, P);
             if (fused_t) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
                 PROF(h, PC_QKV, s, launch_gemm_qkvt_attn(g, s));
+            } else if (fused_s) {
+                g.W = w.w_qkv_hm; g.qkv_mode = QKV_SPATIAL; g.out = h->ao; g.ldo = D; g.rope_cs = h->rope_s.cs_dev;
+                PROF(h, PC_QKV, s, launch_gemm_qkvs_attn(g, s));
             } else {
                 if (hf == 0) {
                     g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
@@ -320,6 +327,7 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
     }
     A_(a.alloc_t(&h->w_ada, (size_t)h->MODW * D)); A_(a.alloc_t(&h->b_ada, h->MODW));
     h->halves.resize(h->L * 2);
+    h->fuse_sattn = h->P == 144 && D % 256 == 0;   // gtav_dit_set_fused_spatial(h, 0) selects the two-kernel path
     for (int l = 0; l < h->L && !rc; ++l)
         for (int hf = 0; hf < 2; ++hf) {
             gtav_dit::Half& w = h->halves[l * 2 + hf];
@@ -328,7 +336,8 @@ int gtav_dit_create(const gtav_dit_config* c, gtav_dit** out) {
             std::string P_(pre);
             const int grp = l * 2 + hf;
             A_(a.alloc_t(&w.w_qkv, (size_t)3 * D * D)); wt.add_f16(P_ + "attn.to_qkv.weight", 3 * D, D, w.w_qkv, 3 * D, D, grp);
-            w.w_qkv_hm = nullptr;   // allocated by gtav_dit_set_fused_temporal(h, 1)
+            w.w_qkv_hm = nullptr;   // temporal halves: allocated by gtav_dit_set_fused_temporal(h, 1)
+            if (hf == 0 && h->P == 144 && D % 256 == 0) A_(a.alloc_t(&w.w_qkv_hm, (size_t)3 * D * D));   // spatial halves at 144 tokens per frame: the fused launch is the default
             A_(a.alloc_t(&w.w_out, (size_t)D * D)); wt.add_f16(P_ + "attn.to_out.weight", D, D, w.w_out, D, D, grp);
             A_(a.alloc_t(&w.b_out, D)); wt.add_f32(P_ + "attn.to_out.bias", 1, D, w.b_out, D);
             A_(a.alloc_t(&w.w_fc1, (size_t)h->Hm_pad * D)); wt.add_f16(P_ + "mlp.fc1.weight", h->Hm, D, w.w_fc1, h->Hm_pad, D, grp);
@@ -444,8 +453,10 @@ int gtav_dit_finalize(gtav_dit* h, void* stream) {
         }
         RET_IF(upload(h->sincos, tab));
     }
-    for (auto& w : h->halves)
-        if (w.w_qkv_hm) RET_IF(launch_qkv_head_major(w.w_qkv, w.w_qkv_hm, D, s));
+    for (size_t hb = 0; hb < h->halves.size(); ++hb) {
+        gtav_dit::Half& w = h->halves[hb];
+        if (w.w_qkv_hm) RET_IF(launch_qkv_head_major(w.w_qkv, w.w_qkv_hm, D, s, (hb & 1) ? 0 : 1));
+    }
     RET_IF(launch_rope_interleave(h->rope_s.cos_dev, h->rope_s.sin_dev, h->rope_s.cs_dev, h->P, s));
     RET_IF(launch_rope_interleave(h->rope_t.cos_dev, h->rope_t.sin_dev, h->rope_t.cs_dev, h->maxT, s));
     GTAV_CHECK_HIP(hipStreamSynchronize(s));
@@ -662,6 +673,27 @@ int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable) {
         if (h->finalized) GTAV_CHECK_HIP(hipDeviceSynchronize());
     }
     h->fuse_tattn = enable != 0;
+    return 0;
+}
+
+int gtav_dit_set_fused_spatial(gtav_dit* h, int32_t enable) {
+    GTAV_REQUIRE(h, "dit_set_fused_spatial: null handle");
+    if (h->fuse_sattn != (enable != 0)) {   // captured sampler steps contain the other kernel sequence
+        for (auto& kv : h->graphs)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+    }
+    if (enable && h->P == 144 && h->D % 256 == 0) {
+        // first enable: head-major copies of the spatial to_qkv weights (3 D^2 halves per block), as for the temporal switch
+        for (int l = 0; l < h->L; ++l) {
+            gtav_dit::Half& w = h->halves[l * 2];
+            if (w.w_qkv_hm) continue;
+            RET_IF(h->arena.alloc_t(&w.w_qkv_hm, (size_t)3 * h->D * h->D));
+            if (h->finalized) RET_IF(launch_qkv_head_major(w.w_qkv, w.w_qkv_hm, h->D, nullptr, 1));
+        }
+        if (h->finalized) GTAV_CHECK_HIP(hipDeviceSynchronize());
+    }
+    h->fuse_sattn = enable != 0;
     return 0;
 }
 

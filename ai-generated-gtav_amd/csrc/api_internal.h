@@ -261,7 +261,7 @@ struct gtav_dit {
     WeightTable wt;
     // fp16 GEMM weights
     f16 *w_pe = nullptr, *w_final = nullptr;
-    struct Half { f16 *w_qkv, *w_out, *w_fc1, *w_fc2; float *b_out, *b_fc1, *b_fc2; f16* w_qkv_hm; };   // w_qkv_hm: temporal halves only, head-major rows (fused QKV + attention GEMM), made by finalize
+    struct Half { f16 *w_qkv, *w_out, *w_fc1, *w_fc2; float *b_out, *b_fc1, *b_fc2; f16* w_qkv_hm; };   // w_qkv_hm: head-major rows for the fused QKV + attention GEMMs (temporal halves: launch_qkv_head_major mode 0, spatial halves: mode 1), made by finalize / the set_fused switches
     std::vector<Half> halves;  // [L*2]
     float *b_pe = nullptr, *b_final = nullptr;
     // fp32 conditioning path
@@ -313,6 +313,10 @@ struct gtav_dit {
     // forward_ab_B1_fused_temporal.txt).  gtav_dit_set_fused_temporal() is the switch (it allocates the head-major weight copies);
     // handles with training enabled keep the split path (the copies are not refreshed by the optimizer).
     bool fuse_tattn = false;
+    // steps of 5 or more frames of 144 tokens: spatial QKV projection + spatial attention in one launch (gemm.hip gemm_qkvs_attn_kernel; bit-identical to the split path;
+    // round 6: faster at every size measured, 80 ... 1280 blocks).  ON by default where the geometry allows (gtav_dit_create allocates the head-major weight copies of the
+    // spatial halves); gtav_dit_set_fused_spatial() is the switch; training handles and bf16 half-blocks keep the split path.
+    bool fuse_sattn = false;
     bool w_prefetch = true;   // L2 prefetch of the next GEMM's weight at small M (gemm.h pf_next)
     // per consumer class (0 out-proj, 1 fc1, 2 fc2, 3 to_qkv): 0 skip, 1 the whole slice, k >= 2 the first k K tiles (PrefetchDesc::kt_limit).  The default is the
     // setting that was never slower than no prefetch on any GPU of the round-5 survey (-2 ... -5 % per batch-1 step on every one of them); prefetching every

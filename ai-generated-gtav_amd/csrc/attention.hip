@@ -11,6 +11,7 @@
 // attn_temporal: causal attention over the <= 8 frames of the sliding window per (b, position, head);
 // 25 dot products of length 64 per head: VALU + 16-lane xor-shuffle reductions, everything in registers.
 #include "ops.h"
+#include "attn_tile.h"
 
 #include <cstdlib>
 
@@ -104,72 +105,7 @@ __global__ __launch_bounds__(64 * NW) void attn_spatial_1p_kernel(const f16* __r
             qf[0] = *(const f16x8*)(Qg + (size_t)qr * 64 + 8 * g);
             qf[1] = *(const f16x8*)(Qg + (size_t)qr * 64 + 32 + 8 * g);
         }
-        // S^T = K Q^T for every key tile: NK independent accumulators
-        f32x4 sc[NK];
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt) {
-            const int key = kt * 16 + li;
-            const char* kr = Ks + key * 128;
-            const f16x8 k0 = *(const f16x8*)(kr + (((0 + g) ^ (key & 7)) << 4));
-            const f16x8 k1 = *(const f16x8*)(kr + (((4 + g) ^ (key & 7)) << 4));
-            sc[kt] = mfma16(k0, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            sc[kt] = mfma16(k1, qf[1], sc[kt], 0, 0, 0);
-        }
-        // padded keys (only the last tiles can hold any) never win the maximum and contribute exp2(-inf) = 0
-        float bmax = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt * 16 + 15 >= S && kt * 16 + 4 * g + r >= S) sc[kt][r] = -INFINITY;
-                bmax = fmaxf(bmax, sc[kt][r]);
-            }
-        bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
-        bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
-        float psum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NK; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __builtin_amdgcn_exp2f((sc[kt][r] - bmax) * kScaleLog2e);   // raw v_exp_f32: argument <= 0
-                sc[kt][r] = pv;
-                psum += pv;
-            }
-        // O^T = Vt P^T, 32 keys per step; P^T straight from the score registers (k-slot j of the B operand <-> key 32 s + 16 (j >> 2) + 4 g + (j & 3))
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < NK / 2; ++s2) {
-            f16x8 pf;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                pf[r] = (f16)sc[2 * s2][r];
-                pf[4 + r] = (f16)sc[2 * s2 + 1][r];
-            }
-            const int kcol = (32 * s2 + 4 * g) * 2;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const char* vr = Vs + (dt * 16 + li) * vstride + kcol;
-                union { f16x8 v8; f16x4 v4[2]; } vf;
-                vf.v4[0] = *(const f16x4*)(vr);
-                vf.v4[1] = *(const f16x4*)(vr + 32);
-                o[dt] = mfma16(vf.v8, pf, o[dt], 0, 0, 0);
-            }
-        }
-        float lt = psum + __shfl_xor(psum, 16, 64);
-        lt = lt + __shfl_xor(lt, 32, 64);
-        const float inv = 1.0f / lt;
-        if (q0 + li < S) {
-            const int mrow = nb * S + q0 + li;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f16x4 h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (f16)(o[dt][r] * inv);
-                store_f16x4_paired<16>(O + tiled_off(mrow, head * 64 + dt * 16 + 4 * g, Dm), h, lane, sc1);
-            }
-        }
+        attn_1p_tile<NK>(Ks, Vs, qf, S, q0, O, nb * S + q0, head * 64, Dm, lane, sc1);   // attn_tile.h: shared with the fused to_qkv + attention GEMM
     }
 }
 

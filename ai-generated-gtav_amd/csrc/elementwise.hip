@@ -640,14 +640,24 @@ inline int grid_for(size_t total, int block = 256) {
     return (int)g;
 }
 
-// to_qkv weight rows [q D | k D | v D] (tile-major fp16, K = D) -> head-major rows [head][q 64 | k 64 | v 64]: 16-byte chunks keep
-// their place inside the row (both row indices are congruent mod 8, so the tile swizzle maps chunk to chunk)
-__global__ void qkv_head_major_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int D) {
+// to_qkv weight rows [q D | k D | v D] (tile-major fp16, K = D) -> head-major rows: 16-byte chunks keep their place inside the row (both row indices are
+// congruent mod 8, so the tile swizzle maps chunk to chunk).  mode 0: [head][q 64 | k 64 | v 64] (the fused temporal kernel's W); mode 1: [head][wave w of 4][q | k | v
+// features 16 w .. 16 w + 15] (the fused spatial kernel's W: every compute wave holds the same 16 head features of q, k and v)
+__global__ void qkv_head_major_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int D, int mode) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int cpr = D >> 3;
     if (i >= (size_t)3 * D * cpr) return;
     const int nd = (int)(i / cpr), kc = (int)(i - (size_t)nd * cpr);
-    const int hd = nd / 192, rem = nd - hd * 192, which = rem >> 6, d = rem & 63;
+    const int hd = nd / 192, rem = nd - hd * 192;
+    int which, d;
+    if (mode == 0) {
+        which = rem >> 6;
+        d = rem & 63;
+    } else {
+        const int w = rem / 48, r48 = rem - w * 48;
+        which = r48 >> 4;
+        d = 16 * w + (r48 & 15);
+    }
     const int ns = which * D + hd * 64 + d;
     *(uint4*)(dst + tiled_off(nd, kc * 8, D)) = *(const uint4*)(src + tiled_off(ns, kc * 8, D));
 }
@@ -755,9 +765,9 @@ int launch_convert_pad_f16(const float* src, int lds, int R, int C, f16* dst, in
     return 0;
 }
 
-int launch_qkv_head_major(const f16* src, f16* dst, int D, hipStream_t stream) {
-    GTAV_REQUIRE(D % 128 == 0, "qkv_head_major: D=%d must be a multiple of 128", D);
-    hipLaunchKernelGGL(qkv_head_major_kernel, dim3(grid_for((size_t)3 * D * (D / 8))), dim3(256), 0, stream, src, dst, D);
+int launch_qkv_head_major(const f16* src, f16* dst, int D, hipStream_t stream, int mode) {
+    GTAV_REQUIRE(D % 128 == 0 && (mode == 0 || mode == 1), "qkv_head_major: D=%d must be a multiple of 128, mode=%d 0 or 1", D, mode);
+    hipLaunchKernelGGL(qkv_head_major_kernel, dim3(grid_for((size_t)3 * D * (D / 8))), dim3(256), 0, stream, src, dst, D, mode);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -120,6 +120,10 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 // tperm order, W = head-major to_qkv weight; writes the temporal K/V cache (p.k) and the attention output (p.out, f16 tile-major).
 bool gemm_qkvt_attn_ok(int M, int D, int S, int Tq, int t0);
 int launch_gemm_qkvt_attn(const GemmParams& p, hipStream_t stream);
+// Spatial QKV projection + spatial attention in one launch (gemm.hip: gemm_qkvs_attn_kernel; frames of S = 144 tokens): X rows in (b, frame, position) order,
+// W = the to_qkv weight in launch_qkv_head_major's mode-1 order, p.rope_cs = the spatial table; writes the attention output (p.out, f16 tile-major) and nothing else.
+bool gemm_qkvs_attn_ok(int M, int D, int S);
+int launch_gemm_qkvs_attn(const GemmParams& p, hipStream_t stream);
 // Weight-gradient GEMM without operand transposes: out[m][n] (f32 row-major, ldo) += sum_t X[t][m] W[t][n]; X, W tile-major fp16
 // [tokens][features] (p.M = X features, p.N = W features, p.K = tokens).  M, N multiples of 128, K of 64 (gemm_tn_ok); gemm_tn_pays: also at
 // least 128 output tiles (where it beats two operand transposes + the NT kernel).

@@ -20,6 +20,7 @@
 // operands (D[row = token][col = feature]) so that V is written already transposed (Vt[d][s]), which
 // is the layout the PV product wants as its MFMA A operand.
 #include "gemm.h"
+#include "attn_tile.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -2018,7 +2019,8 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_grouped_kernel(GemmParams p0
 // so after barrier t tile t is complete and visible and nobody reads tile t - 1 any more.  Loader waves take part in the epilogue's
 // barriers and in its copy-out loops (they have nothing else to do).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, typename AfterPrologue>
+// TRI: feature groups i >= TRI of every wave are accumulated TRANSPOSED (token rows, feature columns — the V^T part of the fused spatial to_qkv + attention kernel)
+template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, int TRI = FI, typename AfterPrologue>
 __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
                                            f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
     static_assert(NS >= 3 && NL >= 1, "loader-wave ring: at least 3 stages and one loader wave");
@@ -2106,7 +2108,7 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    if (TR) acc[i][j] = mfma16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
+                    if (TR || i >= TRI) acc[i][j] = mfma16(xf[s][j], wf[s][i], acc[i][j], 0, 0, 0);
                     else acc[i][j] = mfma16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                 }
     };
@@ -2128,7 +2130,7 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j) {
-                    if (TR) acc[i][j] = mfma16(xf[j], wf[i], acc[i][j], 0, 0, 0);
+                    if (TR || i >= TRI) acc[i][j] = mfma16(xf[j], wf[i], acc[i][j], 0, 0, 0);
                     else acc[i][j] = mfma16(wf[i], xf[j], acc[i][j], 0, 0, 0);
                 }
         };
@@ -2615,6 +2617,91 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
             const int row = (b * p.Tq + tl) * p.S + 16 * pg + pl;   // the token's row in (b, frame, position) order: the out-projection's X
             store16_sc1((f16*)p.out + tiled_off(row, head * 64 + c * 8, p.D), o8.u);
         }
+    }
+    bs.template end<true>(p);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Spatial QKV projection + spatial attention in ONE launch (round 6: the window step at batch 1, frames of 144 tokens).
+//
+// The spatial attention of one (frame, head) needs q, k, v of that head for the 144 tokens of the frame and nothing else (model/attention.py:16-38), and
+// nothing downstream reads the spatial q / k / v again.  So a block of the loader-wave GEMM whose tile is (one head's 192 q | k | v features) x (one frame's 144
+// tokens) owns every operand of that attention item: 4 loader waves + 4 compute waves of 48 features x 144 tokens.  The weight rows come in an order of their
+// own (gtav_op_qkv_head_major, mode 1): compute wave w holds features 16 w .. 16 w + 15 of q, of k AND of v (feature groups i = 0, 1, 2), so
+//   * q and k of a wave rotate by the SAME (cos, sin) values — one set of 9 RoPE loads per lane, fetched before the main loop;
+//   * the v group is accumulated transposed (mainloop_l TRI = 2: tokens on accumulator rows), exactly the arithmetic of the split path's transposed V tiles,
+//     and leaves as 8-byte rows of the V^T image.
+// Epilogue: RoPE in registers -> fp16 Q | K | V^T images in LDS, in the layouts attn_spatial_1p_kernel stages from memory (the same fp16 values the split path
+// stores) -> attn_1p_tile (attn_tile.h, the body that kernel runs), one 16-query tile per wave (all 8 waves; the ninth tile is a second round of wave 0) ->
+// the out-projection's tile-major X operand.  One launch and the q / k / v^T round trip through memory (2 x 4.4 MB at 720 tokens) fewer per block: 16 launches
+// per step.  Grid = frames x heads: 80 blocks at batch 1 (-0.8 us per spatial half-block against the two launches), 128 at the context-cached step of batch 8
+// (-4 us), 640 at the window step of batch 8 (2.5 residency rounds: -11 us) — profiles/round6/fused_spatial_*.txt.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(512, 1) void gemm_qkvs_attn_kernel(GemmParams p) {
+    constexpr int FI = 3, FJ = 9, WN = 4, WM = 1, NL = 4, TNB = 192, TM = 144, NK = 10;
+    constexpr int S_pad = 16 * NK, vstride = (S_pad + 8) * 2;                                     // attn_tile.h's K / V^T image geometry
+    constexpr int QS = 0, KS = TM * 128, VS = KS + S_pad * 128, IMG = VS + 64 * vstride;          // LDS image behind the main loop: Q | K | V^T
+    extern __shared__ __attribute__((aligned(16))) char smem_l[];
+    static_assert(NS * (2 * FI * WN + 2 * FJ * WM) * 1024 >= IMG, "the ring must cover the epilogue's LDS image");
+    char* smem = smem_l;
+#define GTAV_PIN_S(x) asm volatile("" ::"s"(x))
+    GTAV_PIN_S(p.X); GTAV_PIN_S(p.W); GTAV_PIN_S(p.M); GTAV_PIN_S(p.N); GTAV_PIN_S(p.K);
+    GTAV_PIN_S(p.tm.tiles_m); GTAV_PIN_S(p.tm.tiles_n); GTAV_PIN_S(p.tm.gn); GTAV_PIN_S(p.tm.group); GTAV_PIN_S(p.tm.tiles);
+    GTAV_PIN_S(p.tm.rcp_group); GTAV_PIN_S(p.tm.rcp_gn); GTAV_PIN_S(p.tm.rcp_gnlast);
+#undef GTAV_PIN_S
+    BlockStamps bs;
+    bs.begin(p);
+    int n0, m0, ks, kt0, nkt;
+    tile_map_fast<false, TNB, TM>(p, n0, m0, ks, kt0, nkt);
+    const int tid = threadIdx.x, lane = tid & 63, wraw = tid >> 6, w = wraw - NL, li = lane & 15, g = lane >> 4;
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 cs[FJ];   // (cos, sin, cos, sin) of head features 16 w + 4 g .. + 3 at positions 16 j + li: q and k alike
+    auto pf = [&]() {
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) cs[j] = *(const f32x4*)(p.rope_cs + (16 * j + li) * 64 + 16 * w + 4 * g);
+    };
+    mainloop_l<false, NS, FI, FJ, WN, WM, NL, 2>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    GTAV_STAMP(bs.t[2]);
+    const int head = n0 / TNB, frame = m0 / TM;
+    float amax = 0.f;
+    __syncthreads();   // every wave is done reading the last K-step's stage
+    if (w >= 0) {
+        const int d = 16 * w + 4 * g;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int ml = 16 * j + li;
+            const int off = ml * 128 + (((d >> 3) ^ (ml & 7)) << 4) + ((d >> 2) & 1) * 8;
+            const f32x4 qv = rope4(acc[0][j], cs[j]), kv = rope4(acc[1][j], cs[j]);
+            *(uint2*)(smem + QS + off) = pack4(amax, qv[0], qv[1], qv[2], qv[3]);
+            *(uint2*)(smem + KS + off) = pack4(amax, kv[0], kv[1], kv[2], kv[3]);
+            const f32x4 vv = acc[2][j];   // transposed tile: feature 16 w + li, tokens 16 j + 4 g .. + 3
+            *(uint2*)(smem + VS + (16 * w + li) * vstride + (16 * j + 4 * g) * 2) = pack4(amax, vv[0], vv[1], vv[2], vv[3]);
+        }
+    } else {
+        // the loader waves clear what the tile body reads beyond the 144 tokens: key rows 144 .. 159 (masked, but kept as attn_spatial_1p_kernel has them)
+        // and V^T columns 144 .. 159 (probability 0 times whatever the ring left there must be 0)
+        for (int q = tid; q < (S_pad - TM) * 8; q += 64 * NL) *(uint4*)(smem + KS + TM * 128 + q * 16) = make_uint4(0, 0, 0, 0);
+        for (int q = tid; q < 64 * (S_pad - TM) / 8; q += 64 * NL) {
+            const int dd = q / ((S_pad - TM) / 8), c = q - dd * ((S_pad - TM) / 8);
+            *(uint4*)(smem + VS + dd * vstride + TM * 2 + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    sat_report(amax, p.err_flag);
+    __syncthreads();
+    if (GTAV_DBG(p, 64)) GTAV_STAMP(bs.t[2]);   // experiments build, debug bit 6: the "main loop end" stamp moves behind the image (tools/gemm_stamps.py then splits the epilogue)
+    for (int qt = wraw; qt < TM / 16; qt += NL + WN * WM) {
+        const int qr = qt * 16 + li;
+        const char* qrow = smem + QS + qr * 128;
+        f16x8 qf[2];
+        qf[0] = *(const f16x8*)(qrow + ((g ^ (qr & 7)) << 4));
+        qf[1] = *(const f16x8*)(qrow + (((4 + g) ^ (qr & 7)) << 4));
+        attn_1p_tile<NK>(smem + KS, smem + VS, qf, TM, qt * 16, (f16*)p.out, frame * TM + qt * 16, head * 64, p.D, lane, 0);
     }
     bs.template end<true>(p);
 }
@@ -3229,6 +3316,40 @@ int launch_gemm_qkvt_attn(const GemmParams& p_in, hipStream_t stream) {
     q.splitk = 1;
     if (int rc_ = fill_tile_map(q.tm, q.M, q.N, q.K, 80, 192, 1)) return rc_;
     GTAV_LAUNCH((gemm_qkvt_attn_kernel<NS>), dim3(q.tm.tiles), dim3(512), LDS, stream, q);
+    GTAV_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Fused spatial QKV GEMM + attention (gemm_qkvs_attn_kernel).  p: X = the LayerNorm output (rows in (b, frame, position) order), W = the to_qkv weight in
+// the wave-interleaved head-major row order (launch_qkv_head_major mode 1), M tokens = frames * 144, N = 3 D, K = D, D, S = 144, rope_cs = the spatial table
+// [144][64], out = the attention output (f16, tile-major, logical row length D).
+bool gemm_qkvs_attn_ok(int M, int D, int S) {
+    static const int max_blocks = GTAV_ENV_INT("GTAV_QKVS_MAX_BLOCKS", 65535);   // experiments build: A/B against the split path per grid size (65535: the tile map's limit)
+    return S == 144 && D % 64 == 0 && M > 0 && M % S == 0 && (long long)(M / S) * (D / 64) <= max_blocks;
+}
+int launch_gemm_qkvs_attn(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams q = p_in;
+    GTAV_REQUIRE(gemm_qkvs_attn_ok(q.M, q.D, q.S), "gemm/qkvs_attn: unsupported geometry M=%d D=%d S=%d", q.M, q.D, q.S);
+    GTAV_REQUIRE(q.N == 3 * q.D && q.K % TK == 0 && q.out && q.rope_cs && !q.rope_cs_q && !q.bias, "gemm/qkvs_attn: missing buffers (or a bias / a separate q table)");
+    GTAV_REQUIRE(((uintptr_t)q.X & 15) == 0 && ((uintptr_t)q.W & 15) == 0, "gemm: operands must be 16-byte aligned");
+    constexpr int NS = 3, LDS = NS * 42 * 1024;
+    static unsigned long long attr_devs = 0;
+    int dev = 0;
+    GTAV_REQUIRE(device_cus(&dev) > 0, "gemm: no current device");
+    if (!(attr_devs >> (dev & 63) & 1)) {
+        GTAV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_qkvs_attn_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_devs |= 1ull << (dev & 63);
+    }
+#ifdef GTAV_EXPERIMENTS
+    q.debug = g_debug & (3 | 32 | 64);
+    q.stamps = g_stamps;
+#endif
+    q.splitk = 1;
+    q.qkv_mode = QKV_SPATIAL;
+    if (int rc_ = fill_tile_map(q.tm, q.M, q.N, q.K, 144, 192, 1)) return rc_;
+    // (Two blocks per (frame, head) on grids of at most half the chip — both run the whole projection, each walks half of the query tiles in one round of its eight
+    // waves — was measured and is not kept: 19.2 -> 19.4 us at 80 blocks, 19.8 -> 20.9 at 128.)
+    GTAV_LAUNCH((gemm_qkvs_attn_kernel<NS>), dim3(q.tm.tiles), dim3(512), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -107,7 +107,7 @@ int launch_resize_aa(const void* src, int src_is_u8_strip, float* dst, int n, in
 // fp32 strided copy with padding (used to build concatenated fp32 weights): dst[r][c0 + c] = src[r][c]
 int launch_copy_f32(const float* src, int lds, int R, int C, float* dst, int ldd, int c0, hipStream_t stream);
 // tile-major to_qkv weight [3 D][D] -> head-major row order [head][q 64 | k 64 | v 64] (the fused temporal QKV + attention GEMM's W)
-int launch_qkv_head_major(const f16* src, f16* dst, int D, hipStream_t stream);
+int launch_qkv_head_major(const f16* src, f16* dst, int D, hipStream_t stream, int mode = 0);   // mode 1: the fused spatial kernel's wave-interleaved order (elementwise.hip)
 int launch_fill_f32(float* dst, size_t n, float v, hipStream_t stream);
 // cs[pos][k] = (cos[pos][2k], sin[pos][2k]) for k < 32: the GEMM epilogue's interleaved RoPE table
 int launch_rope_interleave(const float* cos_t, const float* sin_t, float* cs, int npos, hipStream_t stream);

@@ -110,7 +110,7 @@ def prefetch_mode(cls) -> int:
 
 @torch.inference_mode()
 def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps: int = 24, rounds: int = 2, use_actions: bool = False,
-                         latent_hw=None, per_class: bool = True, fused_temporal: bool = True) -> dict:
+                         latent_hw=None, per_class: bool = True, fused_temporal: bool = True, fused_spatial: bool = True) -> dict:
     """Times the captured full-window sampler step of batch B under different settings of the next-weight L2 prefetch (docs/LABNOTES.md 4.10) and leaves
     the model on the fastest.  The results are bit-identical under every setting, only the speed differs, and what pays depends on the GPU: on some
     MI355X GPUs prefetching every weight takes 7-12 % off the step; on the others that costs 1-8 % (the prefetched lines are gone before their consumer
@@ -118,8 +118,9 @@ def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps:
     (profiles/round5/prefetch_box_survey.txt).  First off, on for every weight and the library's default against each other (`rounds` alternations, `steps` replays each, a fresh
     capture per switch); then, with `per_class`, from the fastest of them one pass over the four weight classes (fc2, fc1, out-proj, to_qkv) trying skip / first 4 K tiles / whole
     slice for each while the others stay.  About 0.5 s + 2.5 s at batch 1; synthetic latents.
-    With `fused_temporal` the fused temporal to_qkv + attention launch is timed the same way afterwards (eligible windows only) and kept where it is faster.
-    Returns {"on_ms", "off_ms", "chosen": "on" | "off" | "per-class", "classes": {...}, "mode", "tuned_ms", "fused_temporal_qkv_attention": {...} | None}
+    With `fused_temporal` / `fused_spatial` the fused to_qkv + attention launches are timed the same way afterwards (eligible windows only) and kept where faster.
+    Returns {"on_ms", "off_ms", "chosen": "on" | "off" | "per-class", "classes": {...}, "mode", "tuned_ms", "fused_temporal_qkv_attention": {...} | None,
+    "fused_spatial_qkv_attention": {...} | None}
     (milliseconds per step)."""
     dev = model.device
     T = int(window or model.max_frames)
@@ -181,10 +182,27 @@ def tune_weight_prefetch(model, B: int = 1, window: Optional[int] = None, steps:
         timed(cur)                                            # leaves the handle warmed up (and its step captured) under the kept setting
         fused = {"on_ms": round(t_on, 4), "off_ms": round(t_off, 4), "chosen": "on" if keep else "off", "was": was}
         cur_ms = min(cur_ms, t_on) if keep else cur_ms
+    # The spatial counterpart (gtav_dit_set_fused_spatial: frames of 144 tokens, 5 or more frames per step; the library's default where eligible), timed the same
+    # way on top of whatever the temporal switch was left at.
+    fused_s = None
+    if fused_spatial and (h // model.patch_size) * (w // model.patch_size) == 144 and B * T >= 5 and model.hidden_size % 256 == 0 and not getattr(model, "_trainable", False):
+        was = getattr(model, "_fused_spatial", None)
+        was = True if was is None else bool(was)              # None: the library's default, on for this geometry
+        t_off = t_on = float("inf")
+        for _ in range(rounds):
+            model.set_fused_spatial(False)
+            t_off = min(t_off, timed(cur))
+            model.set_fused_spatial(True)
+            t_on = min(t_on, timed(cur))
+        keep = t_on < t_off * 0.997
+        model.set_fused_spatial(keep)
+        timed(cur)
+        fused_s = {"on_ms": round(t_on, 4), "off_ms": round(t_off, 4), "chosen": "on" if keep else "off", "was": was}
+        cur_ms = min(cur_ms, t_on) if keep else cur_ms
     model.check()
     chosen = "on" if cur == on else "off" if cur == off else "per-class"
     return {"on_ms": round(best[on], 4), "off_ms": round(best[off], 4), "chosen": chosen, "classes": dict(zip(PREFETCH_CLASSES, cur)),
-            "mode": prefetch_mode(cur), "tuned_ms": round(cur_ms, 4), "fused_temporal_qkv_attention": fused}
+            "mode": prefetch_mode(cur), "tuned_ms": round(cur_ms, 4), "fused_temporal_qkv_attention": fused, "fused_spatial_qkv_attention": fused_s}
 
 
 def sample_inputs(gid: int, n_prompt: int, total_frames: int, frame_hw, latent_hw, latent_ch: int = 16, seed: int = 1000):

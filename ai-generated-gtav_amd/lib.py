@@ -88,6 +88,7 @@ SIGNATURES = {
     "gtav_dit_set_opt_step": [_p, _l, _l, _p],
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_set_fused_temporal": [_p, _i],
+    "gtav_dit_set_fused_spatial": [_p, _i],
     "gtav_dit_set_weight_prefetch": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
@@ -133,6 +134,8 @@ SIGNATURES = {
     "gtav_op_gemm_dw_grouped": [_i, _p, _p, _p, _p, _p, _p, _i, _p],
     "gtav_op_attn_spatial_bwd": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "gtav_op_gemm_qkvt_attn": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p],
+    "gtav_op_qkv_head_major_spatial": [_p, _p, _i, _p],
+    "gtav_op_gemm_qkvs_attn": [_p, _p, _i, _i, _i, _p, _p, _p],
     "gtav_op_convert_f16": [_p, _i, _i, _i, _p, _i, _i, _i, _p],
     "gtav_op_gemm_splitk_ln": [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p, _p, _i, _p],
     "gtav_op_gemm_choose_splitk": [_i, _i, _i],

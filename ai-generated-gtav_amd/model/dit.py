@@ -240,6 +240,8 @@ class DiT(_HipModule):
                 _lib.check(L.gtav_dit_create(C.byref(cfg), C.byref(self._handle)))
                 if getattr(self, "_fused_temporal", False):
                     _lib.check(L.gtav_dit_set_fused_temporal(self._handle, 1))
+                if getattr(self, "_fused_spatial", None) is not None:     # None: the library's default (on where the geometry allows)
+                    _lib.check(L.gtav_dit_set_fused_spatial(self._handle, int(self._fused_spatial)))
                 if getattr(self, "_fold", None) is not None:
                     _lib.check(L.gtav_dit_set_fold(self._handle, *self._fold))
                 if getattr(self, "_weight_prefetch", None) is not None:
@@ -485,11 +487,18 @@ class DiT(_HipModule):
         _lib.check(_lib.load().gtav_dit_set_graph(self._handle, int(bool(enable))))
 
     def set_fused_temporal(self, enable: bool):
-        """Temporal QKV projection + temporal attention as one kernel on batch-1 full-window steps (off by default: bit-identical
-        to the two-kernel path but measured 1-2 % slower per forward)."""
+        """Temporal QKV projection + temporal attention as one kernel on batch-1 full-window steps (off by default; bit-identical to the two-kernel path;
+        1-2 % slower per eager forward, 1-1.6 % faster per replayed captured step: generate.tune_weight_prefetch times both and keeps the faster)."""
         self._fused_temporal = bool(enable)
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fused_temporal(self._handle, int(self._fused_temporal)))
+
+    def set_fused_spatial(self, enable: bool):
+        """Spatial QKV projection + spatial attention as one kernel on steps of 5 or more frames of 144 tokens (gtav_dit_set_fused_spatial; ON by default where
+        the geometry allows; bit-identical to the two-kernel path; generate.tune_weight_prefetch times both on the shape it tunes and keeps the faster)."""
+        self._fused_spatial = bool(enable)
+        if self._handle:
+            _lib.check(_lib.load().gtav_dit_set_fused_spatial(self._handle, int(self._fused_spatial)))
 
     def set_weight_prefetch(self, mode):
         """L2 prefetch of the next GEMM's weight at small token counts (gtav_dit_set_weight_prefetch; on by default, bit-identical results under every

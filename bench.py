@@ -571,6 +571,17 @@ def bench_generate(args, world, rank, dev, dist, torch):
             el = t.item()
         return el
 
+    def qkv_class(M, prof, classes):
+        """FLOPs per launch of the to_qkv class: 2 M N K, plus — when the spatial attention ran inside the spatial half's to_qkv launch (gtav_dit_set_fused_spatial, the
+        default at 144 tokens per frame: the attention class then has no launches of its own) — that attention's 4 frames heads P^2 64, averaged over the class's two halves"""
+        fl = 2.0 * M * 3 * D_MODEL * D_MODEL
+        if prof["attn_spatial"][1] == 0 and prof["gemm_qkv"][1] > 0:
+            fl += 0.5 * 4.0 * (M // P_TOK) * (D_MODEL // 64) * P_TOK * P_TOK * 64
+            classes["gemm_qkv"]["includes"] = "the spatial attention (fused to_qkv + attention launch, csrc/gemm.hip gemm_qkvs_attn_kernel): its FLOPs are counted in this class"
+        if prof["attn_temporal"][1] == 0 and prof["gemm_qkv"][1] > 0:
+            classes["gemm_qkv"]["includes_also"] = "the temporal attention (fused temporal launch; its FLOPs are negligible and not counted)"
+        return fl
+
     def profile_forward(b, actions):
         """in-situ per-class kernel times over real forwards of (b, T = 5): dispatch-attached HIP events (gtav_dit_profile)"""
         g = torch.Generator().manual_seed(3)
@@ -599,7 +610,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
         ev_ms, ev_n = prof.pop("empty_event_pair")
         classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
         # per GEMM class: achieved TFLOP/s from its algorithmic FLOPs (2 M N K per launch)
-        gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": flops_fc1,
+        gflop = {"gemm_qkv": qkv_class(M, prof, classes), "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": flops_fc1,
                  "gemm_fc2": flops_fc1}
         shape_of = {"gemm_qkv": "to_qkv GEMM + RoPE / head-layout epilogue (N=3072 K=1024)", "gemm_out": "out-proj GEMM (N=1024 K=1024, residual epilogue / split-K slabs)",
                     "gemm_fc1": "fc1 GEMM + GELU-tanh epilogue (N=4096 K=1024)", "gemm_fc2": "fc2 GEMM (N=1024 K=4096, residual epilogue / split-K slabs)"}
@@ -672,7 +683,7 @@ def bench_generate(args, world, rank, dev, dist, torch):
         M = b * P_TOK
         ev_ms, ev_n = prof.pop("empty_event_pair")
         classes = {k: {"ms_per_step": round(v[0] / nst, 4), "launches_per_step": v[1] // nst} for k, v in prof.items()}
-        gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": 2.0 * M * HM * D_MODEL,
+        gflop = {"gemm_qkv": qkv_class(M, prof, classes), "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": 2.0 * M * HM * D_MODEL,
                  "gemm_fc2": 2.0 * M * HM * D_MODEL}
         tot_fl = tot_ms = 0.0
         for k, fl in gflop.items():

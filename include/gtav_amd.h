@@ -22,7 +22,7 @@
  *                            (once per handle), captures the step on it and instantiates a hipGraph (host work only, nothing
  *                            executes during capture); later calls are one hipGraphLaunch.  gtav_dit_set_graph(h, 0) selects
  *                            plain launches, which never allocate
- *   gtav_dit_set_fused_temporal   first enable: hipMalloc of the head-major weight copies, device synchronise
+ *   gtav_dit_set_fused_temporal / gtav_dit_set_fused_spatial   first enable: hipMalloc of the head-major weight copies, device synchronise
  *   gtav_dit_forward         with gtav_dit_profile enabled only: creates events and synchronises at the end of the forward
  *   gtav_dit_check / gtav_vae_check / gtav_dit_autorange   copy the device error words back and synchronise `stream`
  *   gtav_dit_train_enable    hipMalloc + hipMemset of masters, optimizer state, saved-activation and backward workspace, two small
@@ -111,11 +111,20 @@ int gtav_dit_set_graph(gtav_dit* h, int32_t enable);
 
 /* Optional (default OFF): full-window steps / forwards of up to 256 (80-token tile, head) pairs — batch 1 with a 5-frame window —
  * run the temporal half's to_qkv projection and its causal temporal attention (model/attention.py:41-71) as ONE kernel.  Outputs
- * are bit-identical to the two-kernel path, which every other shape always uses; on MI355X the fused kernel measured 1-2 % slower
- * per forward, so it is kept as a tested alternative, not the default.  The first enabling call allocates
+ * are bit-identical to the two-kernel path, which every other shape always uses.  Per eager forward the fused kernel measured 1-2 %
+ * slower, per replayed captured step 1-1.6 % FASTER: a harness times both at warm-up and keeps the faster
+ * (gtav_amd.generate.tune_weight_prefetch does).  The first enabling call allocates
  * head-major copies of the temporal to_qkv weights (6 D^2 bytes per block) and, on a finalized handle, fills them and
  * synchronises the device; every call drops the captured graphs of the handle.  Ignored on handles with training enabled. */
 int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
+
+/* The spatial counterpart, ON by default on handles whose frames are 144 tokens (hidden_size % 256 == 0): steps / forwards of 5 or more frames (the batch-1
+ * window step: 80 (frame, head) blocks; the context-cached step of 5 or more batch items; every batched window step) run the spatial half's to_qkv projection
+ * and its attention (model/attention.py:16-38) as ONE kernel; the spatial q / k / v^T never leave the chip.  Bit-identical to the two-kernel path, which
+ * every other shape, bf16 half-blocks, training handles and every other geometry always use; measured faster at every eligible size.
+ * enable = 0 selects the two-kernel path.  gtav_dit_create allocates the head-major weight copies (6 D^2 bytes per block); every call that changes the
+ * setting drops the captured graphs of the handle. */
+int gtav_dit_set_fused_spatial(gtav_dit* h, int32_t enable);
 
 /* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (docs/LABNOTES.md 4.10; steps of 256 ... 1536 tokens; default: mode 0x11441).  It changes no
  * arithmetic — results are bit-identical under every setting — and what pays depends on the GPU (profiles/round5/prefetch_box_survey.txt): on some MI355X
@@ -334,6 +343,13 @@ int gtav_op_attn_temporal(const void* q_dev, const void* kv_dev, void* o_dev, in
 int gtav_op_qkv_head_major(const void* w_f16_dev, void* w_hm_f16_dev, int32_t D, void* stream);
 int gtav_op_gemm_qkvt_attn(const void* x_tperm_f16_dev, const void* w_hm_f16_dev, int32_t M, int32_t D, int32_t P, int32_t Tq,
                            int32_t t0, int32_t Tmax, const float* rope_cs_dev, void* kv_dev, void* o_dev, void* stream);
+/* Spatial half of a window step as ONE kernel (gtav_dit_set_fused_spatial): x = the LayerNorm output (f16 tile-major, rows in (b, frame, position) order),
+ * w = the to_qkv weight in the wave-interleaved head-major row order (gtav_op_qkv_head_major_spatial of the tile-major [3 D][D] weight), rope_cs = the spatial
+ * table [P][64]; writes the attention output o (f16 tile-major) and nothing else — no q / k / v^T leave the chip.  Requires P == 144, D % 64 == 0,
+ * (M / 144) * (D / 64) <= 256 (model/attention.py:16-38). */
+int gtav_op_qkv_head_major_spatial(const void* w_f16_dev, void* w_hm_f16_dev, int32_t D, void* stream);
+int gtav_op_gemm_qkvs_attn(const void* x_f16_dev, const void* w_hm_f16_dev, int32_t M, int32_t D, int32_t P, const float* rope_cs_dev, void* o_dev,
+                           void* stream);
 /* Backward of the spatial attention (model/attention.py:99-136) for NB x heads (frame, head) items of S tokens: q, k [item][S][64]
  * (RoPE applied), vt [item][64][S], d_o fp16 row-major [NB S][heads 64]; writes the gradient of the to_qkv output, fp16 tile-major
  * logical [NB S][3 heads 64] (dq | dk | dv, dq / dk rotated back through the RoPE).  S % 16 == 0, S <= 160. */

@@ -136,6 +136,47 @@ def test_fused_temporal_qkv_attention_is_bit_identical(full_dit):
     assert torch.equal(outs[0], outs[1])
 
 
+
+def test_fused_spatial_qkv_attention_is_bit_identical(full_dit):
+    """gtav_dit_set_fused_spatial(h, 1): steps / forwards of 4 ... 16 frames of 144 tokens run the spatial to_qkv projection + spatial attention as one kernel
+    (gemm_qkvs_attn_kernel); every other shape, and the default, the two-kernel path.  Same fp16 operands, the same tile body: the outputs must be EQUAL —
+    batch 1 and 2 through the plain forward, alone and together with the fused temporal launch, and through the sampler (eager, captured, replayed, then a
+    context-cached step, which is too small for the fused kernel and runs the split path on the same caches)."""
+    from gtav_amd.utils import alphas_cumprod
+    m, sd, cfg = full_dit
+    g = torch.Generator().manual_seed(23)
+    a = torch.zeros(2, 5, 25)
+    a[:, :, 7] = 1
+    x = torch.randn(2, 5, 16, 18, 32, generator=g)
+    t = torch.tensor([[15, 15, 15, 15, 700], [15, 15, 15, 15, 320]])
+    try:
+        m.set_fused_spatial(False)
+        m.set_fused_temporal(False)
+        split1, split2 = m(x[:1], t[:1], a[:1]).clone(), m(x, t, a).clone()
+        m.set_fused_spatial(True)
+        fused1, fused2 = m(x[:1], t[:1], a[:1]).clone(), m(x, t, a).clone()
+        m.set_fused_temporal(True)
+        both1 = m(x[:1], t[:1], a[:1]).clone()
+        assert torch.isfinite(fused1).all() and torch.equal(fused1, split1) and torch.equal(fused2, split2) and torch.equal(both1, split1)
+        with torch.no_grad():
+            assert rel_l2(fused1, O.dit_forward(sd, cfg, x[:1], t[:1], a[:1])) < TOL_FULL
+        m.set_fused_temporal(False)
+        m.set_schedule(alphas_cumprod(1e-4))
+        outs = []
+        for fused_on in (False, True):
+            m.set_fused_spatial(fused_on)
+            xd = x[:1].to(dev()).contiguous()
+            for _ in range(3):
+                m.denoise_step_(xd, 0, 4, 15, 600, 500, False, a[:1].to(dev()))
+            m.denoise_step_(xd, 0, 4, 15, 500, 400, False, a[:1].to(dev()), cached=True)
+            outs.append(xd.clone())
+        assert torch.equal(outs[0], outs[1])
+        m.check()
+    finally:
+        m.set_fused_spatial(True)        # the library's default on this geometry
+        m.set_fused_temporal(False)
+
+
 def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
     """gtav_dit_set_weight_prefetch (round 4; per-class modes round 5): the next-weight L2 prefetch of the small-M GEMMs changes no arithmetic — a captured
     batch-1 window step gives EQUAL latents under every mode — and generate.tune_weight_prefetch times the settings, leaves the model on the fastest one and
@@ -161,6 +202,8 @@ def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
         print("weight prefetch on / off / tuned (ms per step):", r)
         ft = r["fused_temporal_qkv_attention"]                  # (round 6) the fused temporal to_qkv + attention launch, timed the same way on this five-frame window
         assert ft is not None and ft["chosen"] in ("on", "off") and ft["on_ms"] > 0 and ft["off_ms"] > 0
+        fs = r["fused_spatial_qkv_attention"]                   # and the fused spatial launch (frames of 144 tokens, 5 frames)
+        assert fs is not None and fs["chosen"] in ("on", "off") and fs["on_ms"] > 0 and fs["off_ms"] > 0
         x = x0.clone()
         for k in range(4):
             m.denoise_step_(x, 0, 4, 15, 900 - 10 * k, 890 - 10 * k, False, None)
@@ -170,9 +213,11 @@ def test_weight_prefetch_switch_is_bit_identical_and_tunable(full_dit):
         # the form bench.py uses for the context-cached step of the batched leg: a one-frame window at batch 2 (288 tokens: inside the prefetch's range)
         r1 = tune_weight_prefetch(m, 2, window=1, steps=4, rounds=1)
         assert r1["tuned_ms"] > 0 and set(r1["classes"]) == {"out", "fc1", "fc2", "qkv"}
+        assert r1["fused_temporal_qkv_attention"] is None and r1["fused_spatial_qkv_attention"] is None   # 2 frames: neither launch is eligible
     finally:
         m.set_weight_prefetch(True)
         m.set_fused_temporal(False)
+        m.set_fused_spatial(True)        # the library's default on this geometry
     m.check()
 
 

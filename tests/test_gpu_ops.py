@@ -288,6 +288,61 @@ def test_attention_temporal(Tq, t0):
     assert rel_l2(untile(o, B * Tq * P, D).float(), ref) < 6e-4
 
 
+@pytest.mark.parametrize("NB,D", [(5, 1024), (1, 256), (7, 512), (16, 1024)])
+def test_fused_spatial_qkv_attention_equals_the_two_kernel_path(NB, D):
+    """gemm_qkvs_attn_kernel (to_qkv projection + RoPE + spatial attention of 144-token frames in one launch; the q / k / v^T images stay in LDS) against
+    gtav_op_gemm_qkv (spatial mode) + gtav_op_attn_spatial on the same operands: a BIT-EQUAL attention output (same fp16 q / k / v, the same tile body —
+    csrc/attn_tile.h), both within fp16 rounding of fp32 math (model/attention.py:16-38).  Repeated launches must agree (race screen: the LDS image reuses the
+    ring), and the rows behind the last frame must stay untouched."""
+    S, heads = 144, D // 64
+    M = NB * S
+    lib = L.load()
+    x = _rand(M, D, seed=1).half()
+    w = _rand(3 * D, D, scale=1 / math.sqrt(D), seed=2)
+    ang = (_rand(S, 32, seed=3) * 3).repeat_interleave(2, dim=-1)
+    cd, sd_ = ang.cos().to(dev()).contiguous(), ang.sin().to(dev()).contiguous()
+    cs = torch.empty_like(cd)
+    L.check(lib.gtav_op_rope_interleave(cd.data_ptr(), sd_.data_ptr(), cs.data_ptr(), S, stream()))
+    w16 = pad_weight_f16(w)
+    xd = to_tiled_f16(x)
+    Mp = (M + 127) // 128 * 128
+    q = torch.zeros(NB, heads, S, 64, device=dev(), dtype=torch.float16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(NB, heads, 64, S, device=dev(), dtype=torch.float16)
+    o = torch.full((Mp, D), 7.0, device=dev(), dtype=torch.float16)
+    L.check(lib.gtav_op_gemm_qkv(xd.data_ptr(), D, w16.data_ptr(), 0, M, D, 0, q.data_ptr(), k.data_ptr(), vt.data_ptr(), S, 0, 0, 0, cs.data_ptr(), stream()))
+    L.check(lib.gtav_op_attn_spatial(q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr(), NB, heads, S, stream()))
+    w_hm = torch.empty_like(w16)
+    L.check(lib.gtav_op_qkv_head_major_spatial(w16.data_ptr(), w_hm.data_ptr(), D, stream()))
+    first = None
+    for rep in range(20):
+        o2 = torch.full_like(o, 7.0)
+        L.check(lib.gtav_op_gemm_qkvs_attn(xd.data_ptr(), w_hm.data_ptr(), M, D, S, cs.data_ptr(), o2.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        if first is None:
+            first = o2.clone()
+            assert torch.equal(untile(o2, M, D), untile(o, M, D)), "attention output differs from the two-kernel path"
+            assert torch.equal(o2, o), "rows / padding outside the frames differ from the two-kernel path"
+        else:
+            assert torch.equal(o2, first), f"launch {rep} differs from launch 0"
+    y = (x.float() @ w.half().float().t()).reshape(NB, S, 3, heads, 64)
+    c, s_ = ang.cos()[None, None], ang.sin()[None, None]
+    qf = _rope_ref(y[:, :, 0].permute(0, 2, 1, 3), c, s_).half().float()
+    kf = _rope_ref(y[:, :, 1].permute(0, 2, 1, 3), c, s_).half().float()
+    vf = y[:, :, 2].permute(0, 2, 1, 3).half().float()
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf).permute(0, 2, 1, 3).reshape(M, D)
+    assert rel_l2(untile(first, M, D).float(), ref) < 1.5e-3
+
+
+def test_fused_spatial_qkv_attention_refuses_other_geometries():
+    lib = L.load()
+    z = torch.zeros(1 << 16, device=dev(), dtype=torch.float16)
+    cs = torch.zeros(144 * 64, device=dev())
+    for M, D, P in ((128, 256, 128), (100, 256, 144), (144, 96, 144), (0, 256, 144)):   # frames of 128 tokens, a ragged frame, hidden % 64, nothing — all refused before any launch
+        with pytest.raises(L.GtavError, match="qkvs_attn"):
+            L.check(lib.gtav_op_gemm_qkvs_attn(z.data_ptr(), z.data_ptr(), M, D, P, cs.data_ptr(), z.data_ptr(), stream()))
+
+
 @pytest.mark.parametrize("B,P,D", [(1, 144, 1024), (2, 32, 256), (3, 16, 256)])
 def test_fused_temporal_qkv_attention_equals_the_two_kernel_path(B, P, D):
     """gemm_qkvt_attn_kernel (to_qkv projection + RoPE + causal temporal attention + K/V cache rows in one launch) against

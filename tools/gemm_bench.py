@@ -26,6 +26,8 @@ def main():
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
     shapes = [("qkv", 3072, 1024, 5), ("qkvt", 3072, 1024, 7), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]   # epi 7 here = temporal QKV
+    if "qkvs" in a.only:    # the spatial half's two forms back to back: to_qkv + attention launches (58) and the fused launch (8), frames of 144 tokens
+        shapes += [("qkv+attn_s", 3072, 1024, 58), ("qkvs", 3072, 1024, 8)]
     if "train" in a.only:   # GEMMs of the training step without an activation: fc1 forward / fc2 dX (fp16 tile-major out, code 70 = EPI_F16_TILED), fc1 dX / to_qkv dX (fp32 out)
         shapes += [("train_f16t", 4096, 1024, 70), ("train_f32_k4096", 1024, 4096, 0), ("train_f32_k3072", 1024, 3072, 0)]
     if "vae" in a.only:     # the ViT-VAE's GEMMs (model/vae.py:115-157): erf-GELU fc1, un-gated in-place residual proj / fc2 (code 40 = EPI_RESID without a gate), QKV at S = 576
@@ -62,6 +64,14 @@ def main():
                         Mq = (M // 144) * 144
                         L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Mq, 1024, 0, q[0].data_ptr(), q[1].data_ptr(),
                                                      q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), st))
+                    elif epi in (58, 8):
+                        Mq = (M // 144) * 144
+                        if epi == 58:
+                            L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, Mq, 1024, 0, q[0].data_ptr(), q[1].data_ptr(),
+                                                         q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), st))
+                            L.check(lib.gtav_op_attn_spatial(q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), out.data_ptr(), Mq // 144, 16, 144, st))
+                        else:
+                            L.check(lib.gtav_op_gemm_qkvs_attn(x.data_ptr(), w.data_ptr(), Mq, 1024, 144, cs.data_ptr(), out.data_ptr(), st))
                     elif epi == 55:     # VAE: S = 576 tokens per attention item
                         Mq = (M // 576) * 576
                         L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), bias.data_ptr(), Mq, 1024, 0, vq[0].data_ptr(), vq[1].data_ptr(),

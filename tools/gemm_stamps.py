@@ -32,7 +32,7 @@ def main():
     lib.gtav_op_gemm_set_debug(a.debug)
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream().cuda_stream
-    shapes = [("qkv", 3072, 1024, 5), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]
+    shapes = [("qkv", 3072, 1024, 5), ("qkvs", 3072, 1024, 8), ("out", 1024, 1024, 6), ("fc1", 4096, 1024, 2), ("fc2", 1024, 4096, 6)]   # qkvs: the fused spatial to_qkv + attention launch (frames of 144 tokens)
     maxb = 16384
     stamps = torch.zeros(maxb * 8, dtype=torch.int64, device=dev)
     for M in a.ms:
@@ -55,6 +55,8 @@ def main():
                     if epi == 5:
                         L.check(lib.gtav_op_gemm_qkv(x.data_ptr(), K, w.data_ptr(), 0, (M // 144) * 144, 1024, 0, q[0].data_ptr(),
                                                      q[1].data_ptr(), q[2].data_ptr(), 144, 0, 0, 0, cs.data_ptr(), st))
+                    elif epi == 8:
+                        L.check(lib.gtav_op_gemm_qkvs_attn(x.data_ptr(), w.data_ptr(), (M // 144) * 144, 1024, 144, cs.data_ptr(), out.data_ptr(), st))
                     elif epi == 6:
                         L.check(lib.gtav_op_gemm_f16(x.data_ptr(), K, w.data_ptr(), 0, out.data_ptr(), N, M, N, K, 6, 0, sk, 1, st))
                     else:

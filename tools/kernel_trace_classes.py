@@ -26,6 +26,10 @@ def classify(rows):
     pos = 0
     bad = 0
     for _, dur, name, grid in rows:
+        if "gemm_qkvs_attn_kernel" in name or "gemm_qkvt_attn_kernel" in name:   # the fused to_qkv + attention launches (template argument = ring stages, not an epilogue)
+            pos = 1
+            out.append(("gemm_qkv", grid, dur))
+            continue
         m = re.search(r"gemm\w*_kernel<(\d+)", name)
         if m and "grouped" not in name and "tn_kernel" not in name:
             epi = int(m.group(1))

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--g256", action="store_true", help="the 256x256-frame preset: 16x16 latents, 64 tokens per frame (M = 320 per window step)")
     ap.add_argument("--product", action="store_true", help="the product library (no debug bits: one variant) instead of the experiments build")
     ap.add_argument("--fused-ab", action="store_true", help="every variant also with the fused temporal QKV + attention kernel")
+    ap.add_argument("--fused-spatial-ab", action="store_true", help="every variant also with the fused spatial QKV + attention kernel, and with both fused kernels")
     ap.add_argument("--graph-ab", action="store_true", help="every variant also with eager (stream-ordered) launches instead of the captured graph")
     a = ap.parse_args()
     lib = L.load() if a.product else L.load_experiments()
@@ -48,12 +49,14 @@ def main():
         act[:, :, 3] = 1
     models = {}
     for v in a.variants:
-        for graph in ((True, False) if a.graph_ab else ((True, "fused") if a.fused_ab else (True,))):
+        for graph in ((True, False) if a.graph_ab else ((True, "fused") if a.fused_ab else (True, "fused", "fused-s", "fused-st") if a.fused_spatial_ab else (True,))):
             lib.gtav_op_gemm_set_debug(v)
             m = DiT(**gkw, init_weights=False, max_batch=B) if a.g256 else DiT_models["DiT-S/2"](init_weights=False, max_batch=B)
             m.load_state_dict(sd)
-            if graph == "fused":
+            if graph in ("fused", "fused-st"):
                 m.set_fused_temporal(True)
+            if a.fused_spatial_ab:                      # explicit either way: the fused spatial launch is the library's default at 144 tokens per frame
+                m.set_fused_spatial(graph in ("fused-s", "fused-st"))
             generate_latents(m, x0, total, 4, nz, act, ctx_cache=a.cached)   # builds the handle; warm-up + capture under this variant's bits
             if not graph:
                 m.set_graph(False)
@@ -72,7 +75,7 @@ def main():
             if ref is None:
                 ref = out.clone()
             nf = a.frames * (a.steps + 1)
-            print(f"round {r} variant {v:9d} {'graph+fused-temporal' if graph == 'fused' else 'graph' if graph else 'eager'}: {dt / nf * 1e3:.4f} ms per sampler step ({nf} steps, batch {B}, {'cached' if a.cached else 'window'}), "
+            print(f"round {r} variant {v:9d} { {'fused': 'graph+fused-temporal', 'fused-s': 'graph+fused-spatial', 'fused-st': 'graph+fused-both'}.get(graph, ('graph, both split' if a.fused_spatial_ab else 'graph') if graph else 'eager') }: {dt / nf * 1e3:.4f} ms per sampler step ({nf} steps, batch {B}, {'cached' if a.cached else 'window'}), "
                   f"rel diff vs first {((out - ref).norm() / ref.norm()).item():.1e}", flush=True)
     lib.gtav_op_gemm_set_debug(0)
 
