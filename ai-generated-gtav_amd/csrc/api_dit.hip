@@ -60,6 +60,9 @@ static int fold_alloc(gtav_dit* h) {
 }
 #endif
 
+// the fused spatial to_qkv + attention launch: from 5 frames on (measured from 80 blocks up; a context-cached batch-1 step is 16 blocks: the split path's skinny kernels serve it)
+static bool fused_spatial_ok(int M, int D, int P) { return gemm_qkvs_attn_ok(M, D, P) && M / P >= 5 && (M / P) * (D / 64) >= 80; }
+
 // LayerNorm fold: which seams run folded at M tokens (seam A = out-proj -> fc1, seam B = fc2 -> next to_qkv / final projection)
 static void fold_policy(const gtav_dit* h, int M, bool& fa, bool& fb) {
     const gtav_dit::Fold& f = h->fold;
@@ -146,8 +149,6 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
     // what the GEMM launch at position `pos` of half-block `hb` (launch order: 0 to_qkv, 1 out-proj, 2 fc1, 3 fc2) prefetches: the weight of the next GEMM
     // launch of the step.  (One more launch of lead — the weight of the GEMM after the next — was measured in round 5 and gained nothing on either kind
     // of GPU: profiles/round5/prefetch_box_survey.txt.)
-    // the fused spatial to_qkv + attention launch: from 5 frames on (measured from 80 blocks up; a context-cached batch-1 step is 16 blocks: the split path's skinny kernels serve it)
-    auto fused_spatial_ok = [](int M_, int D_, int P_) { return gemm_qkvs_attn_ok(M_, D_, P_) && M_ / P_ >= 5 && (M_ / P_) * (D_ / 64) >= 80; };
     struct PfNext { const f16* W; int N, K, sk, consumer; };
     auto pf_target = [&](int hb, int pos) -> PfNext {
         const int q = pos + 1, hb2 = hb + q / 4, p2 = q % 4;
@@ -221,10 +222,10 @@ static int dit_forward_core(gtav_dit* h, const float* x_src, const int* frame_in
             if (fused_t) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_TEMPORAL; g.k = h->kvcache[l]; g.v = h->kvcache[l]; g.out = h->ao; g.ldo = D;
                 g.Tq = Tq; g.t0 = t0; g.Tmax = h->maxT; g.rope_cs = h->rope_t.cs_dev;
-                PROF(h, PC_QKV, s, launch_gemm_qkvt_attn(g, s));
+                PROF(h, PC_ATTN_T, s, launch_gemm_qkvt_attn(g, s));   // profiled as the attention class: one class = one kernel (gtav_dit_fused_launches tells a reader which it was)
             } else if (fused_s) {
                 g.W = w.w_qkv_hm; g.qkv_mode = QKV_SPATIAL; g.out = h->ao; g.ldo = D; g.rope_cs = h->rope_s.cs_dev;
-                PROF(h, PC_QKV, s, launch_gemm_qkvs_attn(g, s));
+                PROF(h, PC_ATTN_S, s, launch_gemm_qkvs_attn(g, s));
             } else {
                 if (hf == 0) {
                     g.qkv_mode = QKV_SPATIAL; g.q = h->qs; g.k = h->ks; g.v = h->vts;
@@ -695,6 +696,19 @@ int gtav_dit_set_fused_spatial(gtav_dit* h, int32_t enable) {
     }
     h->fuse_sattn = enable != 0;
     return 0;
+}
+
+int gtav_dit_fused_launches(gtav_dit* h, int32_t B, int32_t T, int32_t t0) {
+    if (!h || B < 1 || T < 1) return 0;
+    const int M = B * T * h->P;
+    int mask = 0;
+    for (int hb = 0; hb < 2 * h->L; ++hb) {
+        const gtav_dit::Half& w = h->halves[hb];
+        if (h->tr.on || h->ops(hb).bf16 || !w.w_qkv_hm) continue;
+        if (!(hb & 1) && h->fuse_sattn && fused_spatial_ok(M, h->D, h->P)) mask |= 1;
+        if ((hb & 1) && h->fuse_tattn && gemm_qkvt_attn_ok(M, h->D, h->P, T, t0)) mask |= 2;
+    }
+    return mask;
 }
 
 int gtav_dit_profile(gtav_dit* h, int32_t enable) {

@@ -89,6 +89,7 @@ SIGNATURES = {
     "gtav_dit_set_graph": [_p, _i],
     "gtav_dit_set_fused_temporal": [_p, _i],
     "gtav_dit_set_fused_spatial": [_p, _i],
+    "gtav_dit_fused_launches": [_p, _i, _i, _i],
     "gtav_dit_set_weight_prefetch": [_p, _i],
     "gtav_dit_profile": [_p, _i],
     "gtav_dit_profile_read": [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

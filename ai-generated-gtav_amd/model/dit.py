@@ -500,6 +500,12 @@ class DiT(_HipModule):
         if self._handle:
             _lib.check(_lib.load().gtav_dit_set_fused_spatial(self._handle, int(self._fused_spatial)))
 
+    def fused_launches(self, B: int, T: int, t0: int = 0) -> int:
+        """Bit 0: a step of B x T frames runs the fused spatial to_qkv + attention launch on this handle as it is now; bit 1: the fused temporal one
+        (gtav_dit_fused_launches).  The profiler books those launches under attn_spatial / attn_temporal."""
+        self._ensure(B, T)
+        return int(_lib.load().gtav_dit_fused_launches(self._handle, int(B), int(T), int(t0)))
+
     def set_weight_prefetch(self, mode):
         """L2 prefetch of the next GEMM's weight at small token counts (gtav_dit_set_weight_prefetch; on by default, bit-identical results under every
         mode): False / 0 off, True / 1 every weight, or a per-class word from gtav_amd.generate.prefetch_mode."""

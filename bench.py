@@ -571,16 +571,18 @@ def bench_generate(args, world, rank, dev, dist, torch):
             el = t.item()
         return el
 
-    def qkv_class(M, prof, classes):
-        """FLOPs per launch of the to_qkv class: 2 M N K, plus — when the spatial attention ran inside the spatial half's to_qkv launch (gtav_dit_set_fused_spatial, the
-        default at 144 tokens per frame: the attention class then has no launches of its own) — that attention's 4 frames heads P^2 64, averaged over the class's two halves"""
-        fl = 2.0 * M * 3 * D_MODEL * D_MODEL
-        if prof["attn_spatial"][1] == 0 and prof["gemm_qkv"][1] > 0:
-            fl += 0.5 * 4.0 * (M // P_TOK) * (D_MODEL // 64) * P_TOK * P_TOK * 64
-            classes["gemm_qkv"]["includes"] = "the spatial attention (fused to_qkv + attention launch, csrc/gemm.hip gemm_qkvs_attn_kernel): its FLOPs are counted in this class"
-        if prof["attn_temporal"][1] == 0 and prof["gemm_qkv"][1] > 0:
-            classes["gemm_qkv"]["includes_also"] = "the temporal attention (fused temporal launch; its FLOPs are negligible and not counted)"
-        return fl
+    def fused_gflop(M, frames_b, frames_t, prof, classes, gflop):
+        """The fused to_qkv + attention launches (gtav_dit_fused_launches) are booked under the attention class of their half — one class, one kernel.  Their algorithmic
+        FLOPs per launch are the to_qkv GEMM's 2 M N K plus that attention's; they join `gflop` so that the GEMM aggregate and the choice of the dominant kernel see them."""
+        mask = dit.fused_launches(frames_b, frames_t)
+        fl_qkv = 2.0 * M * 3 * D_MODEL * D_MODEL
+        if mask & 1 and prof["attn_spatial"][1]:
+            gflop["attn_spatial"] = fl_qkv + 4.0 * (M // P_TOK) * (D_MODEL // 64) * P_TOK * P_TOK * 64
+            classes["attn_spatial"]["kernel"] = "fused spatial to_qkv GEMM + RoPE + attention launch (csrc/gemm.hip gemm_qkvs_attn_kernel): FLOPs = 2 M N K + 4 frames heads P^2 64"
+        if mask & 2 and prof["attn_temporal"][1]:
+            gflop["attn_temporal"] = fl_qkv + 4.0 * (M // frames_t) * 64 * (D_MODEL // 64) * (frames_t + 1) / 2
+            classes["attn_temporal"]["kernel"] = "fused temporal to_qkv GEMM + RoPE + causal attention launch (csrc/gemm.hip gemm_qkvt_attn_kernel)"
+        return mask
 
     def profile_forward(b, actions):
         """in-situ per-class kernel times over real forwards of (b, T = 5): dispatch-attached HIP events (gtav_dit_profile)"""
@@ -610,10 +612,13 @@ def bench_generate(args, world, rank, dev, dist, torch):
         ev_ms, ev_n = prof.pop("empty_event_pair")
         classes = {k: {"ms_per_forward": round(v[0] / nprof, 4), "launches_per_forward": v[1] // nprof} for k, v in prof.items()}
         # per GEMM class: achieved TFLOP/s from its algorithmic FLOPs (2 M N K per launch)
-        gflop = {"gemm_qkv": qkv_class(M, prof, classes), "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": flops_fc1,
+        gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": flops_fc1,
                  "gemm_fc2": flops_fc1}
+        fused_mask = fused_gflop(M, b, 5, prof, classes, gflop)
         shape_of = {"gemm_qkv": "to_qkv GEMM + RoPE / head-layout epilogue (N=3072 K=1024)", "gemm_out": "out-proj GEMM (N=1024 K=1024, residual epilogue / split-K slabs)",
-                    "gemm_fc1": "fc1 GEMM + GELU-tanh epilogue (N=4096 K=1024)", "gemm_fc2": "fc2 GEMM (N=1024 K=4096, residual epilogue / split-K slabs)"}
+                    "gemm_fc1": "fc1 GEMM + GELU-tanh epilogue (N=4096 K=1024)", "gemm_fc2": "fc2 GEMM (N=1024 K=4096, residual epilogue / split-K slabs)",
+                    "attn_spatial": "fused spatial to_qkv GEMM + RoPE + attention launch (N=3072 K=1024; gemm_qkvs_attn_kernel)",
+                    "attn_temporal": "fused temporal to_qkv GEMM + RoPE + attention launch (N=3072 K=1024; gemm_qkvt_attn_kernel)"}
         tot_fl = tot_ms = 0.0
         for k, fl in gflop.items():
             ms, n = prof[k]
@@ -637,7 +642,9 @@ def bench_generate(args, world, rank, dev, dist, torch):
                     "timing": "HIP events attached to the dispatch (hipExtLaunchKernel), less the calibrated offset of the pair (timer.bias_us of the line)",
                     "timer_bias_us": timer_calibration()["bias_us"], "empty_event_pair_us": round(ev_ms / max(ev_n, 1) * 1e3, 2),
                     "gemm_aggregate_frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if tot_ms > 0 else None,
-                    "gemm_aggregate_note": "FLOP-weighted over the four GEMM classes: sum of 2 M N K over their launches / sum of their launch times",
+                    "gemm_aggregate_note": "FLOP-weighted over the GEMM classes (the four plain ones and, where they run, the fused to_qkv + attention launches with their attention FLOPs): "
+                                           "sum of FLOPs over their launches / sum of their launch times",
+                    "fused_launches": {"spatial_to_qkv_attention": bool(fused_mask & 1), "temporal_to_qkv_attention": bool(fused_mask & 2)},
                     "worst_class": {"kernel": shape_of[worst], "frac": classes[worst].get("frac_of_mfma_peak")},
                     "per_class_frac": {k.replace("gemm_", ""): classes[k].get("frac_of_mfma_peak") for k in gflop}}
         fwd_flops = dit_forward_flops(M, b * 5, 15, b)
@@ -683,8 +690,9 @@ def bench_generate(args, world, rank, dev, dist, torch):
         M = b * P_TOK
         ev_ms, ev_n = prof.pop("empty_event_pair")
         classes = {k: {"ms_per_step": round(v[0] / nst, 4), "launches_per_step": v[1] // nst} for k, v in prof.items()}
-        gflop = {"gemm_qkv": qkv_class(M, prof, classes), "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": 2.0 * M * HM * D_MODEL,
+        gflop = {"gemm_qkv": 2.0 * M * 3 * D_MODEL * D_MODEL, "gemm_out": 2.0 * M * D_MODEL * D_MODEL, "gemm_fc1": 2.0 * M * HM * D_MODEL,
                  "gemm_fc2": 2.0 * M * HM * D_MODEL}
+        fused_gflop(M, b, 1, prof, classes, gflop)
         tot_fl = tot_ms = 0.0
         for k, fl in gflop.items():
             ms, n = prof[k]

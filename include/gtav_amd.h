@@ -125,6 +125,10 @@ int gtav_dit_set_fused_temporal(gtav_dit* h, int32_t enable);
  * enable = 0 selects the two-kernel path.  gtav_dit_create allocates the head-major weight copies (6 D^2 bytes per block); every call that changes the
  * setting drops the captured graphs of the handle. */
 int gtav_dit_set_fused_spatial(gtav_dit* h, int32_t enable);
+/* Which of the two fused launches a forward / sampler step of B x T frames starting at window frame t0 runs on this handle as it is now (switches, operand types,
+ * training): bit 0 the spatial one, bit 1 the temporal one (in any block).  NOT a status code.  gtav_dit_profile books a fused launch under the attention class of
+ * its half (attn_spatial / attn_temporal) — one class, one kernel — and the to_qkv class then holds the remaining plain to_qkv launches only. */
+int gtav_dit_fused_launches(gtav_dit* h, int32_t B, int32_t T, int32_t t0);
 
 /* L2 prefetch of the NEXT GEMM's weight by the small-M GEMM launches (docs/LABNOTES.md 4.10; steps of 256 ... 1536 tokens; default: mode 0x11441).  It changes no
  * arithmetic — results are bit-identical under every setting — and what pays depends on the GPU (profiles/round5/prefetch_box_survey.txt): on some MI355X

@@ -152,10 +152,18 @@ def test_fused_spatial_qkv_attention_is_bit_identical(full_dit):
     try:
         m.set_fused_spatial(False)
         m.set_fused_temporal(False)
+        assert m.fused_launches(1, 5) == 0
         split1, split2 = m(x[:1], t[:1], a[:1]).clone(), m(x, t, a).clone()
         m.set_fused_spatial(True)
         fused1, fused2 = m(x[:1], t[:1], a[:1]).clone(), m(x, t, a).clone()
+        assert m.fused_launches(1, 5) == 1 and m.fused_launches(2, 5) == 1 and m.fused_launches(1, 1) == 0 and m.fused_launches(8, 1) == 1
+        m.profile(True)                                   # the profiler books a fused launch under the attention class of its half: one class, one kernel
+        m(x[:1], t[:1], a[:1])
+        pr = m.profile_read()
+        m.profile(False)
+        assert pr["gemm_qkv"][1] == cfg.depth and pr["attn_spatial"][1] == cfg.depth and pr["attn_temporal"][1] == cfg.depth
         m.set_fused_temporal(True)
+        assert m.fused_launches(1, 5) == 3 and m.fused_launches(2, 5) == 1
         both1 = m(x[:1], t[:1], a[:1]).clone()
         assert torch.isfinite(fused1).all() and torch.equal(fused1, split1) and torch.equal(fused2, split2) and torch.equal(both1, split1)
         with torch.no_grad():

@@ -28,7 +28,7 @@ def classify(rows):
     for _, dur, name, grid in rows:
         if "gemm_qkvs_attn_kernel" in name or "gemm_qkvt_attn_kernel" in name:   # the fused to_qkv + attention launches (template argument = ring stages, not an epilogue)
             pos = 1
-            out.append(("gemm_qkv (fused with the %s attention; in situ it is pooled with the other half's to_qkv launches)" % ("spatial" if "qkvs" in name else "temporal"), grid, dur))
+            out.append(("attn_%s (the fused to_qkv + attention launch: the in-situ profiler books it under this class too)" % ("spatial" if "qkvs" in name else "temporal"), grid, dur))
             continue
         m = re.search(r"gemm\w*_kernel<(\d+)", name)
         if m and "grouped" not in name and "tn_kernel" not in name:
