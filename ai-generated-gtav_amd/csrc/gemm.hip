@@ -2020,7 +2020,7 @@ __global__ __launch_bounds__(128 * WM, 1) void gemm_grouped_kernel(GemmParams p0
 // barriers and in its copy-out loops (they have nothing else to do).
 // ---------------------------------------------------------------------------------------------------------------------
 // TRI: feature groups i >= TRI of every wave are accumulated TRANSPOSED (token rows, feature columns — the V^T part of the fused spatial to_qkv + attention kernel)
-template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, int TRI = FI, typename AfterPrologue>
+template <bool TR, int NS, int FI, int FJ, int WN, int WM, int NL, int TRI = FI, bool HALFSTEP = (FI * FJ >= 16), typename AfterPrologue>   // HALFSTEP: the half-K-step pipeline (one fragment set per half) also for smaller wave tiles that are short of registers
 __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int n0, int m0, int kt0, int nkt,
                                            f32x4 (&acc)[FI][FJ], BlockStamps& bs, AfterPrologue after_prologue) {
     static_assert(NS >= 3 && NL >= 1, "loader-wave ring: at least 3 stages and one loader wave");
@@ -2112,7 +2112,7 @@ __device__ __forceinline__ void mainloop_l(const GemmParams& p, char* smem, int 
                     else acc[i][j] = mfma16(wf[s][i], xf[s][j], acc[i][j], 0, 0, 0);
                 }
     };
-    if constexpr (FI * FJ >= 16) {
+    if constexpr (HALFSTEP) {
         // Large wave tiles (64 x 64: 16 MFMAs per 32-deep half of a K-step): pipeline by HALF K-steps with one register set per half —
         //   barrier t | read (t, half 0) -> A | MFMA (t - 1, half 1) from B | read (t, half 1) -> B | MFMA (t, half 0) from A
         // every batch of reads is in flight under 16 MFMAs (256 cycles), the fragments cost (FI + FJ) x 8 registers instead of the
@@ -2623,28 +2623,34 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvt_attn_kernel(GemmParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Spatial QKV projection + spatial attention in ONE launch (round 6: the window step at batch 1, frames of 144 tokens).
+// Spatial QKV projection + spatial attention in ONE launch (round 6; frames of 144 tokens, the default from 5 frames per step on).
 //
 // The spatial attention of one (frame, head) needs q, k, v of that head for the 144 tokens of the frame and nothing else (model/attention.py:16-38), and
 // nothing downstream reads the spatial q / k / v again.  So a block of the loader-wave GEMM whose tile is (one head's 192 q | k | v features) x (one frame's 144
-// tokens) owns every operand of that attention item: 4 loader waves + 4 compute waves of 48 features x 144 tokens.  The weight rows come in an order of their
-// own (gtav_op_qkv_head_major, mode 1): compute wave w holds features 16 w .. 16 w + 15 of q, of k AND of v (feature groups i = 0, 1, 2), so
-//   * q and k of a wave rotate by the SAME (cos, sin) values — one set of 9 RoPE loads per lane, fetched before the main loop;
+// tokens) owns every operand of that attention item: 4 loader waves + 8 compute waves (4 along the features x 2 along the tokens, 48 x 80 each; the X tile is
+// padded to 160 rows with whatever follows the frame, computed and dropped).  The weight rows come in an order of their own (gtav_op_qkv_head_major_spatial):
+// the compute waves of feature quarter wn hold features 16 wn .. 16 wn + 15 of q, of k AND of v (feature groups i = 0, 1, 2), so
+//   * q and k of a wave rotate by the SAME (cos, sin) values — one set of 5 RoPE loads per lane, fetched before the main loop;
 //   * the v group is accumulated transposed (mainloop_l TRI = 2: tokens on accumulator rows), exactly the arithmetic of the split path's transposed V tiles,
 //     and leaves as 8-byte rows of the V^T image.
 // Epilogue: RoPE in registers -> fp16 Q | K | V^T images in LDS, in the layouts attn_spatial_1p_kernel stages from memory (the same fp16 values the split path
-// stores) -> attn_1p_tile (attn_tile.h, the body that kernel runs), one 16-query tile per wave (all 8 waves; the ninth tile is a second round of wave 0) ->
-// the out-projection's tile-major X operand.  One launch and the q / k / v^T round trip through memory (2 x 4.4 MB at 720 tokens) fewer per block: 16 launches
-// per step.  Grid = frames x heads: 80 blocks at batch 1 (-0.8 us per spatial half-block against the two launches), 128 at the context-cached step of batch 8
-// (-4 us), 640 at the window step of batch 8 (2.5 residency rounds: -11 us) — profiles/round6/fused_spatial_*.txt.
+// stores) -> attn_1p_tile (attn_tile.h, the body that kernel runs), one 16-query tile per wave (nine tiles on twelve waves: one round) -> the out-projection's
+// tile-major X operand.  One launch and the q / k / v^T round trip through memory (2 x 4.4 MB at 720 tokens) fewer per block: 16 launches per step.
+// Grid = frames x heads: 80 blocks at batch 1 (-1.3 us per spatial half-block against the two launches), 128 at the context-cached step of batch 8 (-4.9 us),
+// 640 at the window step of batch 8 (2.5 residency rounds: -12.8 us) — profiles/round6/fused_spatial_*.txt.  The K-step (0.60 us) is the LDS port's: 128 KB of
+// fragment reads + 44 KB of fills per step against 0.42 us of MFMA issue per SIMD.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NS>
-__global__ __launch_bounds__(512, 1) void gemm_qkvs_attn_kernel(GemmParams p) {
-    constexpr int FI = 3, FJ = 9, WN = 4, WM = 1, NL = 4, TNB = 192, TM = 144, NK = 10;
+__global__ __launch_bounds__(768, 1) void gemm_qkvs_attn_kernel(GemmParams p) {
+    // 4 loader + 8 compute waves (4 along the features x 2 along the tokens, 48 x 80 each): the X tile is 160 rows — the frame's 144 tokens and 16 rows of whatever
+    // follows, computed and dropped — so that the tokens divide over two waves per SIMD (with ONE compute wave per SIMD, 48 x 144, a fragment read stuck behind the
+    // LDS port held that SIMD's MFMA issue too: K loop 10.0 us for 6.0 us of MFMA issue, profiles/round6/fused_spatial_*_block_stamps*.txt)
+    constexpr int FI = 3, FJ = 5, WN = 4, WM = 2, NL = 4, TNB = 192, TM = 144, NQT = TM / 16, NK = 10;
     constexpr int S_pad = 16 * NK, vstride = (S_pad + 8) * 2;                                     // attn_tile.h's K / V^T image geometry
     constexpr int QS = 0, KS = TM * 128, VS = KS + S_pad * 128, IMG = VS + 64 * vstride;          // LDS image behind the main loop: Q | K | V^T
     extern __shared__ __attribute__((aligned(16))) char smem_l[];
     static_assert(NS * (2 * FI * WN + 2 * FJ * WM) * 1024 >= IMG, "the ring must cover the epilogue's LDS image");
+    static_assert(16 * FJ * WM >= TM && 16 * FJ * WM == S_pad, "two token halves cover the frame");
     char* smem = smem_l;
 #define GTAV_PIN_S(x) asm volatile("" ::"s"(x))
     GTAV_PIN_S(p.X); GTAV_PIN_S(p.W); GTAV_PIN_S(p.M); GTAV_PIN_S(p.N); GTAV_PIN_S(p.K);
@@ -2654,34 +2660,41 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvs_attn_kernel(GemmParams p) {
     BlockStamps bs;
     bs.begin(p);
     int n0, m0, ks, kt0, nkt;
-    tile_map_fast<false, TNB, TM>(p, n0, m0, ks, kt0, nkt);
+    tile_map_fast<false, TNB, TM>(p, n0, m0, ks, kt0, nkt);   // tiles step by the frame's 144 rows; the main loop reads 160 from m0 (past the last frame: a valid tile again, dropped)
     const int tid = threadIdx.x, lane = tid & 63, wraw = tid >> 6, w = wraw - NL, li = lane & 15, g = lane >> 4;
+    const int wn = w & (WN - 1), wm = w >> 2;   // compute waves: feature quarter, token half
     f32x4 acc[FI][FJ];
 #pragma unroll
     for (int i = 0; i < FI; ++i)
 #pragma unroll
         for (int j = 0; j < FJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 cs[FJ];   // (cos, sin, cos, sin) of head features 16 w + 4 g .. + 3 at positions 16 j + li: q and k alike
+    f32x4 cs[FJ];   // (cos, sin, cos, sin) of head features 16 wn + 4 g .. + 3 at positions 16 (5 wm + j) + li: q and k alike
     auto pf = [&]() {
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) cs[j] = *(const f32x4*)(p.rope_cs + (16 * j + li) * 64 + 16 * w + 4 * g);
+        for (int j = 0; j < FJ; ++j) {
+            const int pos = 16 * (FJ * wm + j) + li;
+            cs[j] = *(const f32x4*)(p.rope_cs + (pos < TM ? pos : TM - 1) * 64 + 16 * wn + 4 * g);
+        }
     };
-    mainloop_l<false, NS, FI, FJ, WN, WM, NL, 2>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
+    mainloop_l<false, NS, FI, FJ, WN, WM, NL, 2, true>(p, smem, n0, m0, kt0, nkt, acc, bs, pf);
     GTAV_STAMP(bs.t[2]);
     const int head = n0 / TNB, frame = m0 / TM;
     float amax = 0.f;
     __syncthreads();   // every wave is done reading the last K-step's stage
     if (w >= 0) {
-        const int d = 16 * w + 4 * g;
+        const int d = 16 * wn + 4 * g;
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
-            const int ml = 16 * j + li;
-            const int off = ml * 128 + (((d >> 3) ^ (ml & 7)) << 4) + ((d >> 2) & 1) * 8;
-            const f32x4 qv = rope4(acc[0][j], cs[j]), kv = rope4(acc[1][j], cs[j]);
-            *(uint2*)(smem + QS + off) = pack4(amax, qv[0], qv[1], qv[2], qv[3]);
-            *(uint2*)(smem + KS + off) = pack4(amax, kv[0], kv[1], kv[2], kv[3]);
-            const f32x4 vv = acc[2][j];   // transposed tile: feature 16 w + li, tokens 16 j + 4 g .. + 3
-            *(uint2*)(smem + VS + (16 * w + li) * vstride + (16 * j + 4 * g) * 2) = pack4(amax, vv[0], vv[1], vv[2], vv[3]);
+            const int jj = FJ * wm + j;          // token group of the frame; group 9 (rows 144 .. 159) belongs to whatever follows the frame
+            if (jj < NQT) {
+                const int ml = 16 * jj + li;
+                const int off = ml * 128 + (((d >> 3) ^ (ml & 7)) << 4) + ((d >> 2) & 1) * 8;
+                const f32x4 qv = rope4(acc[0][j], cs[j]), kv = rope4(acc[1][j], cs[j]);
+                *(uint2*)(smem + QS + off) = pack4(amax, qv[0], qv[1], qv[2], qv[3]);
+                *(uint2*)(smem + KS + off) = pack4(amax, kv[0], kv[1], kv[2], kv[3]);
+                const f32x4 vv = acc[2][j];   // transposed tile: feature 16 wn + li, tokens 16 jj + 4 g .. + 3
+                *(uint2*)(smem + VS + (16 * wn + li) * vstride + (16 * jj + 4 * g) * 2) = pack4(amax, vv[0], vv[1], vv[2], vv[3]);
+            }
         }
     } else {
         // the loader waves clear what the tile body reads beyond the 144 tokens: key rows 144 .. 159 (masked, but kept as attn_spatial_1p_kernel has them)
@@ -2695,13 +2708,13 @@ __global__ __launch_bounds__(512, 1) void gemm_qkvs_attn_kernel(GemmParams p) {
     sat_report(amax, p.err_flag);
     __syncthreads();
     if (GTAV_DBG(p, 64)) GTAV_STAMP(bs.t[2]);   // experiments build, debug bit 6: the "main loop end" stamp moves behind the image (tools/gemm_stamps.py then splits the epilogue)
-    for (int qt = wraw; qt < TM / 16; qt += NL + WN * WM) {
-        const int qr = qt * 16 + li;
+    if (wraw < NQT) {   // nine query tiles, twelve waves: one round
+        const int qr = wraw * 16 + li;
         const char* qrow = smem + QS + qr * 128;
         f16x8 qf[2];
         qf[0] = *(const f16x8*)(qrow + ((g ^ (qr & 7)) << 4));
         qf[1] = *(const f16x8*)(qrow + (((4 + g) ^ (qr & 7)) << 4));
-        attn_1p_tile<NK>(smem + KS, smem + VS, qf, TM, qt * 16, (f16*)p.out, frame * TM + qt * 16, head * 64, p.D, lane, 0);
+        attn_1p_tile<NK>(smem + KS, smem + VS, qf, TM, wraw * 16, (f16*)p.out, frame * TM + wraw * 16, head * 64, p.D, lane, 0);
     }
     bs.template end<true>(p);
 }
@@ -3332,7 +3345,7 @@ int launch_gemm_qkvs_attn(const GemmParams& p_in, hipStream_t stream) {
     GTAV_REQUIRE(gemm_qkvs_attn_ok(q.M, q.D, q.S), "gemm/qkvs_attn: unsupported geometry M=%d D=%d S=%d", q.M, q.D, q.S);
     GTAV_REQUIRE(q.N == 3 * q.D && q.K % TK == 0 && q.out && q.rope_cs && !q.rope_cs_q && !q.bias, "gemm/qkvs_attn: missing buffers (or a bias / a separate q table)");
     GTAV_REQUIRE(((uintptr_t)q.X & 15) == 0 && ((uintptr_t)q.W & 15) == 0, "gemm: operands must be 16-byte aligned");
-    constexpr int NS = 3, LDS = NS * 42 * 1024;
+    constexpr int NS = 3, LDS = NS * 44 * 1024;
     static unsigned long long attr_devs = 0;
     int dev = 0;
     GTAV_REQUIRE(device_cus(&dev) > 0, "gemm: no current device");
@@ -3349,7 +3362,7 @@ int launch_gemm_qkvs_attn(const GemmParams& p_in, hipStream_t stream) {
     if (int rc_ = fill_tile_map(q.tm, q.M, q.N, q.K, 144, 192, 1)) return rc_;
     // (Two blocks per (frame, head) on grids of at most half the chip — both run the whole projection, each walks half of the query tiles in one round of its eight
     // waves — was measured and is not kept: 19.2 -> 19.4 us at 80 blocks, 19.8 -> 20.9 at 128.)
-    GTAV_LAUNCH((gemm_qkvs_attn_kernel<NS>), dim3(q.tm.tiles), dim3(512), LDS, stream, q);
+    GTAV_LAUNCH((gemm_qkvs_attn_kernel<NS>), dim3(q.tm.tiles), dim3(768), LDS, stream, q);
     GTAV_CHECK_HIP(hipGetLastError());
     return 0;
 }
