@@ -144,7 +144,9 @@ int gtav_dit_set_weight_prefetch(gtav_dit* h, int32_t mode);
  * HIP events on the launch stream and the forward synchronises at its end (measurement passes only).
  * Classes: 0 LN+modulate, 1 QKV GEMM, 2 spatial attention, 3 temporal attention, 4 out-proj GEMM, 5 fc1 GEMM,
  * 6 fc2 GEMM, 7 other (patchify, embed, final, unpatchify), 8 an EMPTY event pair (the timing overhead per pair, to be
- * subtracted from every class average).  Conditioning kernels are not included. */
+ * subtracted from every class average).  Conditioning kernels are not included.  A fused to_qkv + attention launch
+ * (gtav_dit_fused_launches) is ONE kernel and is booked under the attention class of its half (2 or 3); class 1 then holds
+ * the remaining plain to_qkv launches only. */
 #define GTAV_PROFILE_CLASSES 9
 int gtav_dit_profile(gtav_dit* h, int32_t enable);
 int gtav_dit_profile_read(gtav_dit* h, double* ms_by_class, int64_t* launches_by_class);
