@@ -41,7 +41,7 @@ def test_product_library_has_no_experiment_knobs():
     assert not hasattr(dll, "gtav_op_gemm_set_debug")
     nm = subprocess.run(["nm", "-D", "--undefined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in nm, "libgtav_amd.so imports getenv: an environment knob leaked into the product build"
-    for src in ("gemm.hip", "api.hip", "api_dit.hip", "api_train.hip", "api_vae.hip", "api_internal.h", "attention.hip", "elementwise.hip", "skinny.hip"):
+    for src in ("gemm.hip", "api.hip", "api_dit.hip", "api_train.hip", "api_vae.hip", "api_internal.h", "attention.hip", "attn_tile.h", "elementwise.hip", "skinny.hip"):
         text = open(os.path.join(ROOT, "ai-generated-gtav_amd", "csrc", src)).read()
         assert "getenv(" not in text, f"{src}: raw getenv outside GTAV_ENV_INT"
 
