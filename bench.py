@@ -579,6 +579,11 @@ def bench_generate(args, world, rank, dev, dist, torch):
         if mask & 1 and prof["attn_spatial"][1]:
             gflop["attn_spatial"] = fl_qkv + 4.0 * (M // P_TOK) * (D_MODEL // 64) * P_TOK * P_TOK * 64
             classes["attn_spatial"]["kernel"] = "fused spatial to_qkv GEMM + RoPE + attention launch (csrc/gemm.hip gemm_qkvs_attn_kernel): FLOPs = 2 M N K + 4 frames heads P^2 64"
+            tr_b, tr_busy, _ = traffic_for("qkvs", M)
+            if tr_b:
+                classes["attn_spatial"]["hbm_bytes_per_launch_pmc"] = tr_b
+                classes["attn_spatial"]["algorithmic_bytes_per_launch"] = int(2.0 * (3 * D_MODEL * D_MODEL + 2 * M * D_MODEL))   # W + X + attention output, fp16
+                classes["attn_spatial"]["mfma_busy_pmc"] = tr_busy
         if mask & 2 and prof["attn_temporal"][1]:
             gflop["attn_temporal"] = fl_qkv + 4.0 * (M // frames_t) * 64 * (D_MODEL // 64) * (frames_t + 1) / 2
             classes["attn_temporal"]["kernel"] = "fused temporal to_qkv GEMM + RoPE + causal attention launch (csrc/gemm.hip gemm_qkvt_attn_kernel)"

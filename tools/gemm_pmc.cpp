@@ -1,8 +1,8 @@
-// Torch-free driver for rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on the four GEMM classes of a DiT half-block, through the
+// Torch-free driver for rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on the four GEMM classes of a DiT half-block and the fused spatial to_qkv + attention launch, through the
 // C-ABI exactly as the model launches them: to_qkv (spatial layout + RoPE epilogue), out-proj and fc2 (split-K slabs, the model's K-slice
 // heuristic), fc1 (GELU epilogue); M = 720 (batch-1 window step), M = 1152 (batch-8 context-cached step), M = 5760 (batch-8 window step) and M = 11 520 (the training batch);
 // then the ViT-VAE's four at M = 46 080 (encode of the trainer's 80 frames: qkv with bias at S = 576, un-gated in-place projection / fc2, erf-GELU fc1); rotating weight
-// buffers.  Dispatch order is fixed — for M in {720, 1152, 5760, 11520}: qkv, out, fc1, fc2, then the VAE's qkv, proj, fc1, fc2, `iters` launches each — and
+// buffers.  Dispatch order is fixed — for M in {720, 1152, 5760, 11520}: qkv, out, fc1, fc2, qkvs (the fused launch), then the VAE's qkv, proj, fc1, fc2, `iters` launches each — and
 // tools/gemm_traffic.py segments the counter rows by that order.
 //   hipcc -O2 tools/gemm_pmc.cpp -Iinclude -L ai-generated-gtav_amd -lgtav_amd -Wl,-rpath,'$ORIGIN/../ai-generated-gtav_amd' -o tools/gemm_pmc
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- ./tools/gemm_pmc 16
@@ -26,6 +26,12 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&w[c], (size_t)H * D * 2));
         CK(hipMemcpy(w[c], host.data(), (size_t)H * D * 2, hipMemcpyHostToDevice));
     }
+    std::vector<void*> w_hm(copies);   // the to_qkv weight ([3072][1024] of each buffer) in the fused spatial launch's row order
+    for (int c = 0; c < copies; ++c) {
+        CK(hipMalloc(&w_hm[c], (size_t)3 * D * D * 2));
+        GK(gtav_op_qkv_head_major_spatial(w[c], w_hm[c], D, nullptr));
+    }
+    CK(hipDeviceSynchronize());
     float *bias, *cs;
     CK(hipMalloc((void**)&bias, H * 4));
     CK(hipMemset(bias, 0, H * 4));
@@ -58,8 +64,10 @@ int main(int argc, char** argv) {
         for (int it = 0; it < iters; ++it)
             GK(ip_fc2 ? gtav_op_gemm_f16(xh, H, w[it % copies], bias, parts, D, M, D, H, 4, gate, D, 144, nullptr)
                       : gtav_op_gemm_f16(xh, H, w[it % copies], nullptr, parts, D, M, D, H, 6, nullptr, sk_fc2, 1, nullptr));
+        // the fused spatial to_qkv + attention launch (frames of 144 tokens: every M here is a whole number of them, 5 or more): weight rows in its own order
+        for (int it = 0; it < iters; ++it) GK(gtav_op_gemm_qkvs_attn(x, w_hm[it % copies], M, D, 144, cs, q, nullptr));
         CK(hipDeviceSynchronize());
-        printf("M=%d: %d launches each of qkv (N=3072 K=1024), out (N=1024 K=1024, %d K slices), fc1 (N=4096 K=1024), fc2 (N=1024 K=4096, %d K slices)\n", M, iters,
+        printf("M=%d: %d launches each of qkv (N=3072 K=1024), out (N=1024 K=1024, %d K slices), fc1 (N=4096 K=1024), fc2 (N=1024 K=4096, %d K slices), qkvs (fused spatial to_qkv + attention)\n", M, iters,
                ip_out ? 0 : sk_out, ip_fc2 ? 0 : sk_fc2);
         CK(hipFree(gate));
         CK(hipFree(x)); CK(hipFree(xh)); CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(v)); CK(hipFree(hb)); CK(hipFree(parts));

@@ -1,5 +1,5 @@
 """Second half of tools/gemm_traffic.sh: rocprofv3 counter_collection csv files -> profiles/traffic.json.
-tools/gemm_pmc dispatches, for M in (720, 1152, 5760): qkv, out, fc1, fc2 — ITERS launches each; the rows are segmented by dispatch order."""
+tools/gemm_pmc dispatches, for M in (720, 1152, 5760, 11520): qkv, out, fc1, fc2, qkvs — ITERS launches each; the rows are segmented by dispatch order."""
 import csv
 import glob
 import hashlib
@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ITERS = 16
-CLASSES = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096)]
+CLASSES = [("qkv", 3072, 1024), ("out", 1024, 1024), ("fc1", 4096, 1024), ("fc2", 1024, 4096), ("qkvs", 3072, 1024)]   # qkvs: the fused spatial to_qkv + attention launch (gemm_qkvs_attn_kernel): reads X and W, writes the attention output [M][1024] fp16
 MS = (720, 1152, 5760, 11520)
 VAE_M = 46080
 VAE_CLASSES = [("vae_qkv", 3072, 1024), ("vae_proj", 1024, 1024), ("vae_fc1", 4096, 1024), ("vae_fc2", 1024, 4096)]
@@ -67,6 +67,8 @@ def main():
             cyc = gui[(name, M)][0] / 8.0
             splitk = 1
             out_bytes = M * N * (2 if name in ("qkv", "fc1", "vae_qkv", "vae_fc1") else 4)
+            if name == "qkvs":
+                out_bytes = M * 1024 * 2
             res[f"{name}_M{M}"] = {"hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "fetch_size_kb": round(f_kb, 1), "write_size_kb": round(w_kb, 1),
                                    "launches": ITERS, "kernel": kern, "grid_threads": grid,
                                    # (the in-place residual epilogue of the large-M out-proj / fc2 — EPI_RESID, gemm_lp_kernel<4, ..> — also READS its fp32 output tile)
